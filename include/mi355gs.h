@@ -1,0 +1,144 @@
+/*
+ * mi355gs.h — C ABI of libmi355gs.so, the MI355X (gfx950 / CDNA4) implementation of the
+ * InstantSplat train/render hot path.
+ *
+ * Boundary contract:
+ *   - plain pointers, sizes and scalars only; no C++ / torch types cross this line;
+ *   - every buffer (inputs, outputs, scratch) is allocated and owned by the CALLER (PyTorch's
+ *     caching allocator in the Python binding); the library never allocates or frees device memory;
+ *   - every kernel is enqueued on the `stream` argument (a hipStream_t passed as void*; the Python
+ *     binding passes torch.cuda.current_stream().cuda_stream); calls return after enqueueing unless
+ *     stated otherwise;
+ *   - all floating point is fp32, all tensors contiguous and on the same device;
+ *   - return value: 0 on success, a negative MI355GS_E* code otherwise (mi355gs_error_string()).
+ *
+ * Each entry point names the reference interface it replaces. The reference's three native
+ * operators are un-vendored git submodules (reference .gitmodules:1-12), so the citations are
+ * to the reference's CALL SITES, which define the signatures and semantics this ABI must serve.
+ */
+#ifndef MI355GS_H
+#define MI355GS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355GS_ABI_VERSION 1
+
+/* error codes */
+#define MI355GS_OK 0
+#define MI355GS_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported degree) */
+#define MI355GS_ELAUNCH (-2)   /* a HIP launch / runtime call failed (debug mode: which kernel is logged) */
+#define MI355GS_EOVERFLOW (-3) /* instance capacity too small for this frame (see mi355gs_raster_forward_render) */
+
+int mi355gs_abi_version(void);
+const char* mi355gs_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Differentiable Gaussian rasterizer
+ * replaces: diff_gaussian_rasterization._C.rasterize_gaussians / rasterize_gaussians_backward,
+ *           reached through GaussianRasterizer.forward at reference gaussian_renderer/__init__.py:126-135
+ *           with the settings tuple built at gaussian_renderer/__init__.py:60-76.
+ *
+ * Scratch layout (caller allocates `bytes` from the *_bytes() queries, 256-byte aligned):
+ *   geom    : per-Gaussian records written by preprocess, read by render and backward
+ *   tiles   : per-tile counters / offsets; per-pixel final transmittance and contributor counts
+ *   binning : per-instance sort keys and the depth-sorted per-tile Gaussian index lists
+ * The forward is split in two so the caller can size `binning` exactly (one 4-byte D2H read of
+ * *num_rendered between the calls, as the reference operator does internally) or skip the read
+ * and pass a capacity bound (no host sync; overflow is reported through *num_rendered > capacity).
+ * ---------------------------------------------------------------------------------------------- */
+size_t mi355gs_raster_geom_bytes(int P);
+size_t mi355gs_raster_tiles_bytes(int W, int H);
+size_t mi355gs_raster_binning_bytes(int64_t num_instances);
+
+/* Stage 1: per-Gaussian projection (frustum cull, EWA 2-D covariance, conic, radius, tile rect,
+ * SH -> RGB), per-tile instance counts and their exclusive scan.
+ *   means3D[P,3] scales[P,3] rotations[P,4] (w,x,y,z, used un-normalised) opacities[P]
+ *   shs[P,M,3] (D = active degree 0..3, M = coefficients stored per Gaussian) or colors_precomp[P,3]
+ *   cov3D_precomp[P,6] replaces scales/rotations when non-null
+ *   viewmatrix[16], projmatrix[16]: row-vector convention, i.e. the transposed matrices the
+ *     reference stores (scene/cameras.py:54-55) in flat memory; campos[3]
+ *   radii[P] (int32, output); num_rendered: device int32, receives the instance count R */
+int mi355gs_raster_forward_preprocess(
+    void* stream, int P, int D, int M, int W, int H,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tanfovx, float tanfovy, int prefiltered,
+    int32_t* radii, void* geom, void* tiles, int32_t* num_rendered, int debug);
+
+/* Stage 2: scatter instances to their tiles, sort every tile's list front-to-back
+ * (depth, then Gaussian index), alpha-composite.  capacity = instances `binning` was sized for.
+ *   bg[3]; out_color[3,H,W] planar. */
+int mi355gs_raster_forward_render(
+    void* stream, int P, int W, int H, int64_t capacity, const float* bg,
+    const void* geom, void* tiles, void* binning, float* out_color, int debug);
+
+/* Backward of both stages.  dL_dpix[3,H,W] in; gradients out (all written, zero where unused):
+ *   dL_dmeans3D[P,3] dL_dmeans2D[P,3] (x,y in the reference's NDC-scaled screen units, z = 0)
+ *   dL_dshs[P,M,3] or dL_dcolors[P,3] (the other may be null), dL_dopacities[P],
+ *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
+ *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes */
+size_t mi355gs_raster_grad_scratch_bytes(int P);
+int mi355gs_raster_backward(
+    void* stream, int P, int D, int M, int W, int H, const float* bg,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tanfovx, float tanfovy,
+    const void* geom, const void* tiles, const void* binning, const float* dL_dpix,
+    void* grad_scratch,
+    float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
+    float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int debug);
+
+/* Visibility test only — replaces diff_gaussian_rasterization._C.mark_visible
+ * (GaussianRasterizer.markVisible; not called by the reference's scripts). present[P] uint8. */
+int mi355gs_raster_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                                const float* projmatrix, uint8_t* present);
+
+/* ------------------------------------------------------------------------------------------------
+ * fused SSIM (+ optional L1) loss
+ * replaces: fused_ssim.fused_ssim(img1, img2) at reference train.py:173 (same value as the
+ *           reference's own fallback utils/loss_utils.py:55-85: 11x11 Gaussian window, sigma 1.5,
+ *           zero "same" padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements).
+ *   img1,img2 [B,C,H,W]; partial_sums: mi355gs_ssim_partials(B,C,H,W) doubles... see below
+ *   ssim_sum / l1_sum: device double[1] each, receive SUM of the SSIM map / SUM |img1-img2|
+ *   dm_dmu1, dm_dsigma1_sq, dm_dsigma12 [B,C,H,W]: saved partials for backward (null = inference)
+ * ---------------------------------------------------------------------------------------------- */
+size_t mi355gs_ssim_scratch_bytes(int B, int C, int H, int W);
+int mi355gs_ssim_forward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,
+                         float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                         void* scratch, float* ssim_mean, float* l1_mean);
+/* dL_dimg1 = ssim_grad_scale * d(ssim_mean)/dimg1 + l1_grad_scale * d(l1_mean)/dimg1
+ * (scales are read from device scalars so no host sync is needed; null = 0). */
+int mi355gs_ssim_backward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,
+                          const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                          const float* ssim_grad_scale, const float* l1_grad_scale, float* dL_dimg1);
+
+/* ------------------------------------------------------------------------------------------------
+ * simple-knn
+ * replaces: simple_knn._C.distCUDA2(points) at reference scene/gaussian_model.py:156 —
+ *           mean of the squared distances to the 3 nearest other points (exact).
+ * ---------------------------------------------------------------------------------------------- */
+size_t mi355gs_knn_scratch_bytes(int N);
+int mi355gs_knn_dist2(void* stream, int N, const float* points, float* mean_dist2, void* scratch);
+
+/* ------------------------------------------------------------------------------------------------
+ * per-point Adam
+ * replaces: PerPointAdam.step at reference scene/per_point_adam.py:34-100 for one parameter tensor
+ *   n = elements, row = elements per point (per_point_lr has n/row entries, or null)
+ *   grad_sumsq: device float[1] holding sum(grad^2) — the reference gates the moment update on the
+ *   whole-tensor norm being > 0 (per_point_adam.py:62-69); pass null to always update.
+ * ---------------------------------------------------------------------------------------------- */
+int mi355gs_adam_step(void* stream, int64_t n, int row, float* param, const float* grad, float* exp_avg,
+                      float* exp_avg_sq, const float* per_point_lr, const float* grad_sumsq,
+                      float lr, float beta1, float beta2, float eps, int step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355GS_H */
