@@ -82,6 +82,7 @@ int mi355gs_raster_forward_render(
  *   dL_dmeans3D[P,3] dL_dmeans2D[P,3] (x,y in the reference's NDC-scaled screen units, z = 0)
  *   dL_dshs[P,M,3] or dL_dcolors[P,3] (the other may be null), dL_dopacities[P],
  *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
+ *   geom/tiles/binning/capacity/radii: exactly what the forward of this frame used and produced
  *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes */
 size_t mi355gs_raster_grad_scratch_bytes(int P);
 int mi355gs_raster_backward(
@@ -90,8 +91,8 @@ int mi355gs_raster_backward(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tanfovx, float tanfovy,
-    const void* geom, const void* tiles, const void* binning, const float* dL_dpix,
-    void* grad_scratch,
+    const void* geom, const void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
+    const float* dL_dpix, void* grad_scratch,
     float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
     float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int debug);
 

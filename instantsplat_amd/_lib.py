@@ -1,0 +1,110 @@
+"""ctypes binding of libmi355gs.so (C ABI: include/mi355gs.h).
+
+There is NO fallback: if the hipcc-built library is missing this module raises, and every operator
+refuses CPU tensors.  (The CPU test-suite may inject the SIMT-emulated build of the same kernel
+sources through `_use_library_for_testing`; nothing in the product path calls that.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355gs.so")
+_LIB = None
+_TEST_MODE = False
+
+_P = c_void_p
+_SIGNATURES = {
+    "mi355gs_abi_version": (c_int, []),
+    "mi355gs_error_string": (ctypes.c_char_p, [c_int]),
+    "mi355gs_raster_geom_bytes": (c_size_t, [c_int]),
+    "mi355gs_raster_tiles_bytes": (c_size_t, [c_int, c_int]),
+    "mi355gs_raster_binning_bytes": (c_size_t, [c_int64]),
+    "mi355gs_raster_grad_scratch_bytes": (c_size_t, [c_int]),
+    "mi355gs_raster_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P,
+                                                  _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, c_int]),
+    "mi355gs_raster_forward_render": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int]),
+    "mi355gs_raster_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
+                                        _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                        c_int]),
+    "mi355gs_raster_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
+    "mi355gs_ssim_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mi355gs_ssim_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi355gs_ssim_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi355gs_knn_scratch_bytes": (c_size_t, [c_int]),
+    "mi355gs_knn_dist2": (c_int, [_P, c_int, _P, _P, _P]),
+    "mi355gs_adam_step": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _bind(path: str):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not match include/mi355gs.h
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). instantsplat_amd has no CPU or PyTorch fallback.")
+        _LIB = _bind(LIB_PATH)
+    return _LIB
+
+
+def _use_library_for_testing(path: str | None):
+    """tests/ only: run the emulated (g++-compiled) build of the kernel sources on CPU tensors."""
+    global _LIB, _TEST_MODE
+    if path is None:
+        _LIB, _TEST_MODE = None, False
+    else:
+        _LIB, _TEST_MODE = _bind(path), True
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"mi355gs: {what} failed: {lib().mi355gs_error_string(code).decode()} ({code})")
+
+
+def ptr(t: torch.Tensor | None):
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def require_device(*tensors: torch.Tensor | None):
+    """All given tensors must be fp32/int, contiguous, on one HIP device. Returns that device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda and not _TEST_MODE:
+            raise RuntimeError("instantsplat_amd operators run on the GPU only (got a CPU tensor; there is no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("instantsplat_amd operators need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def stream_ptr(device) -> c_void_p:
+    if device is not None and device.type == "cuda":
+        return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return c_void_p(0)
+
+
+def f32c(t: torch.Tensor | None):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    return t.contiguous()

@@ -1,0 +1,161 @@
+// extern "C" entry points of libmi355gs.so (declared in include/mi355gs.h).
+// Host-side only: argument checks, scratch-layout arithmetic, kernel enqueue order.
+#include <stdio.h>
+#include "common.h"
+
+// launchers implemented next to their kernels
+int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*,
+                             const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*, uint32_t*);
+int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, int, int,
+                             const CamParams&, const int32_t*, const float*, const uint8_t*, const GsGrad*, float*, float*,
+                             float*, float*, float*, float*, float*, float*);
+int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
+int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*);
+int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t);
+int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
+                            float*, float*, uint32_t*);
+int gs_launch_composite_bwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
+                            const float*, const uint32_t*, const float*, GsGrad*);
+
+void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
+
+static CamParams make_cam(const float* view, const float* proj, const float* campos, float tanfovx, float tanfovy,
+                          float scale_modifier, int W, int H) {
+  CamParams cp;
+  cp.view = view; cp.proj = proj; cp.campos = campos;
+  cp.tanfovx = tanfovx; cp.tanfovy = tanfovy;
+  cp.focal_x = W / (2.0f * tanfovx); cp.focal_y = H / (2.0f * tanfovy);
+  cp.scale_modifier = scale_modifier;
+  cp.W = W; cp.H = H;
+  cp.gx = (W + GS_TILE - 1) / GS_TILE; cp.gy = (H + GS_TILE - 1) / GS_TILE;
+  return cp;
+}
+
+static inline uint32_t clamp_capacity(int64_t c) { return c <= 0 ? 0u : (c > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)c); }
+
+extern "C" {
+
+int mi355gs_abi_version(void) { return MI355GS_ABI_VERSION; }
+
+const char* mi355gs_error_string(int code) {
+  switch (code) {
+    case MI355GS_OK: return "ok";
+    case MI355GS_EINVAL: return "invalid argument";
+    case MI355GS_ELAUNCH: return "HIP launch or runtime failure";
+    case MI355GS_EOVERFLOW: return "instance capacity exceeded";
+    default: return "unknown error";
+  }
+}
+
+size_t mi355gs_raster_geom_bytes(int P) { return GeomLayout(P).total; }
+size_t mi355gs_raster_tiles_bytes(int W, int H) { return (W > 0 && H > 0) ? TilesLayout(W, H).total : 0; }
+size_t mi355gs_raster_binning_bytes(int64_t n) { return BinningLayout(n).total; }
+size_t mi355gs_raster_grad_scratch_bytes(int P) { return gs_align((size_t)(P > 0 ? P : 1) * sizeof(GsGrad)); }
+
+int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                      const float* colors_precomp, const float* opacities, const float* scales,
+                                      float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                      const float* viewmatrix, const float* projmatrix, const float* campos, float tanfovx,
+                                      float tanfovy, int prefiltered, int32_t* radii, void* geom, void* tiles,
+                                      int32_t* num_rendered, int debug) {
+  (void)prefiltered;  // as in the reference operator it only affects an internal consistency check
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P < 0 || W <= 0 || H <= 0 || W > 65535 * GS_TILE || H > 65535 * GS_TILE || D < 0 || D > 3) return MI355GS_EINVAL;
+  if (!geom || !tiles || !num_rendered || !viewmatrix || !projmatrix || !campos) return MI355GS_EINVAL;
+  if (P > 0 && (!means3D || !opacities || !radii)) return MI355GS_EINVAL;
+  if (P > 0 && ((shs == nullptr) == (colors_precomp == nullptr))) return MI355GS_EINVAL;
+  if (P > 0 && shs && M < (D + 1) * (D + 1)) return MI355GS_EINVAL;
+  if (P > 0 && !cov3D_precomp && (!scales || !rotations)) return MI355GS_EINVAL;
+  const GeomLayout gl(P);
+  const TilesLayout tl(W, H);
+  char* g = (char*)geom;
+  char* t = (char*)tiles;
+  // count + cursor are adjacent
+  if (hipMemsetAsync(t + tl.count, 0, tl.start - tl.count, stream) != hipSuccess) return MI355GS_ELAUNCH;
+  const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
+  gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
+                           (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped),
+                           (uint32_t*)(t + tl.count));
+  GS_CHECK_LAUNCH("preprocess_fwd");
+  gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered);
+  GS_CHECK_LAUNCH("scan_tiles");
+  return MI355GS_OK;
+}
+
+int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t capacity, const float* bg, const void* geom,
+                                  void* tiles, void* binning, float* out_color, int debug) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P < 0 || W <= 0 || H <= 0 || !geom || !tiles || !bg || !out_color) return MI355GS_EINVAL;
+  const uint32_t cap = clamp_capacity(capacity);
+  if (cap > 0 && !binning) return MI355GS_EINVAL;
+  const GeomLayout gl(P);
+  const TilesLayout tl(W, H);
+  const BinningLayout bl(capacity);
+  const char* g = (const char*)geom;
+  char* t = (char*)tiles;
+  char* b = (char*)binning;
+  gs_launch_binning(stream, P, tl.T, tl.gx, (const GsRec*)(g + gl.rec), (const uint2*)(g + gl.rect),
+                    (const uint32_t*)(t + tl.start), (uint32_t*)(t + tl.cursor), (uint64_t*)(b + bl.keys),
+                    (uint32_t*)(b + bl.list), cap);
+  GS_CHECK_LAUNCH("binning");
+  gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
+                          (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib));
+  GS_CHECK_LAUNCH("composite_fwd");
+  return MI355GS_OK;
+}
+
+int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, const float* bg, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                            float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tanfovx, float tanfovy, const void* geom,
+                            const void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
+                            const float* dL_dpix, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                            float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                            int debug) {
+  (void)opacities; (void)colors_precomp;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return MI355GS_EINVAL;
+  if (!geom || !tiles || !dL_dpix || !grad_scratch || !bg || !viewmatrix || !projmatrix || !campos) return MI355GS_EINVAL;
+  if (P > 0 && (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities)) return MI355GS_EINVAL;
+  const int use_shs = shs != nullptr, use_cov = cov3D_precomp != nullptr;
+  if (P > 0 && use_shs && !dL_dshs) return MI355GS_EINVAL;
+  if (P > 0 && !use_shs && !dL_dcolors) return MI355GS_EINVAL;
+  if (P > 0 && !use_cov && (!scales || !rotations || !dL_dscales || !dL_drotations)) return MI355GS_EINVAL;
+  if (P > 0 && use_cov && !dL_dcov3D) return MI355GS_EINVAL;
+  if (P == 0) return MI355GS_OK;
+  const uint32_t cap = clamp_capacity(capacity);
+  if (cap > 0 && !binning) return MI355GS_EINVAL;
+  const GeomLayout gl(P);
+  const TilesLayout tl(W, H);
+  const BinningLayout bl(capacity);
+  const char* g = (const char*)geom;
+  const char* t = (const char*)tiles;
+  const char* b = (const char*)binning;
+  GsGrad* grads = (GsGrad*)grad_scratch;
+  if (hipMemsetAsync(grads, 0, (size_t)P * sizeof(GsGrad), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if (cap > 0) {
+    gs_launch_composite_bwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
+                            (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
+                            dL_dpix, grads);
+    GS_CHECK_LAUNCH("composite_bwd");
+  }
+  const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
+  gs_launch_preprocess_bwd(stream, P, D, M, means3D, shs, scales, rotations, use_shs, use_cov, cp, radii,
+                           (const float*)(g + gl.cov3D), (const uint8_t*)(g + gl.clamped), grads, dL_dmeans3D, dL_dmeans2D,
+                           dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D);
+  GS_CHECK_LAUNCH("preprocess_bwd");
+  return MI355GS_OK;
+}
+
+int mi355gs_raster_mark_visible(void* stream_, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                uint8_t* present) {
+  (void)projmatrix;
+  const int debug = 0;
+  void* stream = stream_;
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return MI355GS_EINVAL;
+  gs_launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+  GS_CHECK_LAUNCH("mark_visible");
+  return MI355GS_OK;
+}
+
+}  // extern "C"

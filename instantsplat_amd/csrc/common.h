@@ -1,0 +1,111 @@
+// Shared definitions for the gfx950 kernels of libmi355gs.so.
+// Scratch-buffer layouts (all offsets 256-byte aligned) are defined here once so that the
+// size queries, the forward and the backward agree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/mi355gs.h"
+
+#define GS_TILE 16
+#define GS_TILE_PIX 256
+#define GS_WAVE 64
+
+// One 48-byte record per Gaussian, written by preprocess and gathered by the composite kernels
+// with three 16-byte loads from one contiguous address (1 cache line most of the time).
+struct alignas(16) GsRec {
+  float4 q0;  // x, y (pixel centre), hx, hy (half extents of the alpha >= 1/255 ellipse's AABB; <0: never visible)
+  float4 q1;  // conic a, b, c, opacity
+  float4 q2;  // r, g, b, depth
+};
+
+// Per-Gaussian screen-space gradient accumulator filled by composite backward (float atomics).
+struct alignas(16) GsGrad {
+  float4 g0;  // dL/dmean2D.x, .y (NDC-scaled, as the reference reports them), dL/dconic a, dL/dconic b (full)
+  float4 g1;  // dL/dconic c, dL/dopacity, dL/dr, dL/dg
+  float4 g2;  // dL/db, unused x3
+};
+
+static inline size_t gs_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct GeomLayout {
+  size_t rec, cov3D, rect, clamped, total;
+  __host__ explicit GeomLayout(int P) {
+    size_t n = P > 0 ? (size_t)P : 1, o = 0;
+    rec = o; o += gs_align(n * sizeof(GsRec));
+    cov3D = o; o += gs_align(n * 6 * sizeof(float));
+    rect = o; o += gs_align(n * sizeof(uint2));
+    clamped = o; o += gs_align(n);
+    total = o;
+  }
+};
+
+struct TilesLayout {
+  size_t count, start, cursor, final_T, n_contrib, total;
+  int gx, gy, T;
+  __host__ TilesLayout(int W, int H) {
+    gx = (W + GS_TILE - 1) / GS_TILE; gy = (H + GS_TILE - 1) / GS_TILE; T = gx * gy;
+    size_t o = 0, npix = (size_t)W * H;
+    count = o; o += gs_align((size_t)T * 4);
+    cursor = o; o += gs_align((size_t)T * 4);   // count and cursor are adjacent: one memset clears both
+    start = o; o += gs_align(((size_t)T + 1) * 4);
+    final_T = o; o += gs_align(npix * 4);
+    n_contrib = o; o += gs_align(npix * 4);
+    total = o;
+  }
+};
+
+struct BinningLayout {
+  size_t keys, list, total;
+  __host__ explicit BinningLayout(int64_t R) {
+    size_t n = R > 0 ? (size_t)R : 1, o = 0;
+    keys = o; o += gs_align(n * 8);
+    list = o; o += gs_align(n * 4);
+    total = o;
+  }
+};
+
+// XCD-aware block -> tile map: hardware places block b on XCD b % 8 (observed, speed only); give
+// each XCD one contiguous band of tile rows so neighbouring tiles (which share Gaussians) share an L2.
+__device__ __forceinline__ int gs_tile_of_block(int b, int T) {
+  const int per = (T + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+static inline int gs_grid_for_tiles(int T) { return ((T + 7) >> 3) << 3; }
+
+// transposed (column-major flat) 4x4 helpers, the storage the reference hands over
+__device__ __forceinline__ float3 gs_tp43(const float* m, float3 p) {
+  return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                     m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 gs_tp44(const float* m, float3 p) {
+  return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                     m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+
+struct CamParams {  // passed by value (kernarg): wave-uniform, lives in SGPRs
+  const float* view;    // device pointers: uniform address -> scalar loads
+  const float* proj;
+  const float* campos;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  int W, H, gx, gy;
+};
+
+// wave64 sum via butterfly shuffles; every lane gets the total
+__device__ __forceinline__ float gs_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+#define GS_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize((hipStream_t)stream); \
+    if (e_ != hipSuccess) {                                                     \
+      gs_log_error(name, hipGetErrorString(e_));                                \
+      return MI355GS_ELAUNCH;                                                   \
+    }                                                                           \
+  } while (0)
+
+void gs_log_error(const char* where, const char* what);

@@ -1,0 +1,256 @@
+// Per-tile alpha compositing, forward and backward (A.4/A.5).
+//
+// Workgroup = one 16x16 tile = 4 wave64; each wave owns an 8x8 pixel quadrant (lane -> pixel inside
+// the quadrant), so a whole wave can skip a Gaussian whose alpha>=1/255 box misses its quadrant:
+// the batch of 256 staged records is tested 64 at a time (one record per lane), the hits are
+// collected with a 64-bit ballot, and the wave then walks the set bits of that (scalar) mask —
+// record addresses in LDS are wave-uniform, so the loads are broadcasts and the loop control is
+// pure SALU.  Records are gathered from the 48-byte per-Gaussian array (L2 / Infinity-Cache
+// resident) through the depth-sorted per-tile index list.
+#include "common.h"
+
+namespace {
+
+constexpr int BATCH = 256;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_MIN = 0.0001f;
+
+struct Quad {
+  int px, py;          // this lane's pixel
+  float fx, fy;        // as float
+  float x0, x1, y0, y1;  // the wave's 8x8 pixel box (inclusive, float)
+  bool inside;
+};
+
+__device__ __forceinline__ Quad make_quad(int tile, int gx, int W, int H) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tx = tile % gx, ty = tile / gx;
+  const int bx = tx * GS_TILE + (wave & 1) * 8, by = ty * GS_TILE + (wave >> 1) * 8;
+  Quad q;
+  q.px = bx + (lane & 7);
+  q.py = by + (lane >> 3);
+  q.fx = (float)q.px; q.fy = (float)q.py;
+  q.x0 = (float)bx; q.x1 = (float)(bx + 7); q.y0 = (float)by; q.y1 = (float)(by + 7);
+  q.inside = q.px < W && q.py < H;
+  return q;
+}
+
+__device__ __forceinline__ bool box_hit(const float4& q0, const Quad& q) {
+  return (q0.x + q0.z >= q.x0) && (q0.x - q0.z <= q.x1) && (q0.y + q0.w >= q.y0) && (q0.y - q0.w <= q.y1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity,
+                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
+                                                        float* __restrict__ out_color, float* __restrict__ final_T,
+                                                        uint32_t* __restrict__ n_contrib) {
+  __shared__ float4 s_q0[BATCH];
+  __shared__ float4 s_q1[BATCH];
+  __shared__ float4 s_q2[BATCH];
+  __shared__ int s_done[4];
+  const int tile = gs_tile_of_block(blockIdx.x, T);
+  if (tile >= T) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const Quad q = make_quad(tile, gx, W, H);
+  const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+
+  float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  uint32_t last = 0;
+  bool done = !q.inside;
+
+  for (uint32_t base = start; base < end; base += BATCH) {
+    const int wave_done = __all(done);
+    if (lane == 0) s_done[wave] = wave_done;
+    __syncthreads();  // also fences the previous batch's LDS reads against the stores below
+    if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+    const uint32_t j = base + tid;
+    if (j < end) {
+      const GsRec* r = recs + list[j];
+      s_q0[tid] = r->q0; s_q1[tid] = r->q1; s_q2[tid] = r->q2;
+    }
+    __syncthreads();
+    if (wave_done) continue;
+    const int cnt = (int)min((uint32_t)BATCH, end - base);
+    for (int k = 0; k < cnt; k += 64) {
+      const int i = k + lane;
+      bool hit = false;
+      if (i < cnt) hit = box_hit(s_q0[i], q);
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        const int b = __ffsll(mask) - 1;
+        mask &= mask - 1;
+        const int i2 = k + b;
+        const float4 a0 = s_q0[i2], a1 = s_q1[i2], a2 = s_q2[i2];
+        if (!done) {
+          const float dx = a0.x - q.fx, dy = a0.y - q.fy;
+          const float power = -0.5f * (a1.x * dx * dx + a1.z * dy * dy) - a1.y * dx * dy;
+          if (power <= 0.0f) {
+            const float alpha = fminf(0.99f, a1.w * __expf(power));
+            if (alpha >= ALPHA_MIN) {
+              const float test_T = Tr * (1.0f - alpha);
+              if (test_T < T_MIN) {
+                done = true;
+              } else {
+                const float w = alpha * Tr;
+                C0 += a2.x * w; C1 += a2.y * w; C2 += a2.z * w;
+                Tr = test_T;
+                last = (base - start) + (uint32_t)i2 + 1u;
+              }
+            }
+          }
+        }
+      }
+      if (__all(done)) break;
+    }
+  }
+  if (q.inside) {
+    const size_t pix = (size_t)q.py * W + q.px, plane = (size_t)W * H;
+    final_T[pix] = Tr;
+    n_contrib[pix] = last;
+    out_color[pix] = C0 + Tr * bg[0];
+    out_color[plane + pix] = C1 + Tr * bg[1];
+    out_color[2 * plane + pix] = C2 + Tr * bg[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 backward: replay each tile back to front.  Per (pixel, Gaussian) the nine screen-space
+// gradient terms are reduced across the wave's 64 pixels in registers (butterfly shuffles) and
+// leave the wave as ONE set of float atomics per Gaussian per wave (the reference operator issues
+// them per pixel).  Gaussians whose box misses the wave's quadrant, or that lie behind every
+// pixel's last contributor, are skipped wave-wide.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int H, uint32_t capacity,
+                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
+                                                        const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                                        const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads) {
+  __shared__ float4 s_q0[BATCH];
+  __shared__ float4 s_q1[BATCH];
+  __shared__ float4 s_q2[BATCH];
+  __shared__ uint32_t s_id[BATCH];
+  __shared__ uint32_t s_max[4];
+  const int tile = gs_tile_of_block(blockIdx.x, T);
+  if (tile >= T) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const Quad q = make_quad(tile, gx, W, H);
+  const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  if (end <= start) return;
+
+  const size_t pix = (size_t)q.py * W + q.px, plane = (size_t)W * H;
+  const float T_final = q.inside ? final_T[pix] : 0.f;
+  const uint32_t last = q.inside ? n_contrib[pix] : 0u;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (q.inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[plane + pix]; g2 = dL_dpix[2 * plane + pix]; }
+  const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+  // the tile only needs instances [0, max over pixels of last)
+  uint32_t wmax = last;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m));
+  if (lane == 0) s_max[wave] = wmax;
+  __syncthreads();
+  const uint32_t tile_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+  if (tile_max == 0) return;
+
+  float Tr = T_final;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+
+  // batches are aligned to the list start so that batch boundaries match contributor numbering
+  const uint32_t nb = (tile_max + BATCH - 1) / BATCH;
+  for (uint32_t bi = nb; bi-- > 0;) {
+    const uint32_t boff = bi * BATCH;  // contributor index (0-based) of this batch's first instance
+    __syncthreads();
+    const uint32_t j = start + boff + tid;
+    if (boff + tid < tile_max) {
+      const uint32_t id = list[j];
+      const GsRec* r = recs + id;
+      s_id[tid] = id; s_q0[tid] = r->q0; s_q1[tid] = r->q1; s_q2[tid] = r->q2;
+    }
+    __syncthreads();
+    if (boff >= wmax) continue;  // nothing in this batch is in front of any of this wave's pixels' last contributor
+    const int cnt = (int)min((uint32_t)BATCH, tile_max - boff);
+    for (int k = ((cnt - 1) >> 6) << 6; k >= 0; k -= 64) {
+      if (boff + (uint32_t)k >= wmax) continue;
+      const int i = k + lane;
+      bool hit = false;
+      if (i < cnt && boff + (uint32_t)i < wmax) hit = box_hit(s_q0[i], q);
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        const int b = 63 - __clzll((long long)mask);
+        mask &= ~(1ull << b);
+        const int i2 = k + b;
+        const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
+        const float4 a0 = s_q0[i2], a1 = s_q1[i2], a2 = s_q2[i2];
+        float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
+        bool contributes = false;
+        if (contributor <= last) {
+          const float dx = a0.x - q.fx, dy = a0.y - q.fy;
+          const float power = -0.5f * (a1.x * dx * dx + a1.z * dy * dy) - a1.y * dx * dy;
+          if (power <= 0.0f) {
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, a1.w * G);
+            if (alpha >= ALPHA_MIN) {
+              contributes = true;
+              Tr = Tr / (1.f - alpha);
+              const float dchannel = alpha * Tr;
+              acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+              acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+              acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+              lc0 = a2.x; lc1 = a2.y; lc2 = a2.z;
+              float dL_dalpha = (a2.x - acc0) * g0 + (a2.y - acc1) * g1 + (a2.z - acc2) * g2;
+              v_r = dchannel * g0; v_g = dchannel * g1; v_b = dchannel * g2;
+              dL_dalpha *= Tr;
+              last_alpha = alpha;
+              dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+              const float dL_dG = a1.w * dL_dalpha;
+              const float gdx = G * dx, gdy = G * dy;
+              const float dG_ddelx = -gdx * a1.x - gdy * a1.y;
+              const float dG_ddely = -gdy * a1.z - gdx * a1.y;
+              v_mx = dL_dG * dG_ddelx * ddelx_dx;
+              v_my = dL_dG * dG_ddely * ddely_dy;
+              v_ca = -0.5f * gdx * dx * dL_dG;
+              v_cb = -gdx * dy * dL_dG;
+              v_cc = -0.5f * gdy * dy * dL_dG;
+              v_op = G * dL_dalpha;
+            }
+          }
+        }
+        if (__any(contributes)) {
+          v_mx = gs_wave_sum(v_mx); v_my = gs_wave_sum(v_my); v_ca = gs_wave_sum(v_ca);
+          v_cb = gs_wave_sum(v_cb); v_cc = gs_wave_sum(v_cc); v_op = gs_wave_sum(v_op);
+          v_r = gs_wave_sum(v_r); v_g = gs_wave_sum(v_g); v_b = gs_wave_sum(v_b);
+          float* dst = reinterpret_cast<float*>(grads + s_id[i2]);
+          // lanes 0..8 each own one component
+          float mine = v_mx;
+          mine = lane == 1 ? v_my : mine; mine = lane == 2 ? v_ca : mine; mine = lane == 3 ? v_cb : mine;
+          mine = lane == 4 ? v_cc : mine; mine = lane == 5 ? v_op : mine; mine = lane == 6 ? v_r : mine;
+          mine = lane == 7 ? v_g : mine; mine = lane == 8 ? v_b : mine;
+          if (lane < 9) atomicAdd(dst + lane, mine);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
+                            const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
+                            uint32_t* n_contrib) {
+  hipLaunchKernelGGL(k_composite_fwd, dim3(gs_grid_for_tiles(T)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
+                     recs, bg, out_color, final_T, n_contrib);
+  return 0;
+}
+
+int gs_launch_composite_bwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
+                            const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
+                            const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads) {
+  hipLaunchKernelGGL(k_composite_bwd, dim3(gs_grid_for_tiles(T)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
+                     recs, bg, final_T, n_contrib, dL_dpix, grads);
+  return 0;
+}

@@ -1,0 +1,429 @@
+// Per-Gaussian stages of the rasterizer: projection (forward) and its closed-form backward.
+// One thread per Gaussian, 256-thread blocks; HBM-bound (131 B/Gaussian at SH
+// degree 0, 311 B at degree 3 forward).  Semantics: SURVEY.md Appendix A.1 / A.5; the operator
+// being replaced is reached at reference gaussian_renderer/__init__.py:126-135.
+#include "common.h"
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+
+struct Cov2D {
+  float a, b, c;  // after the +0.3 low-pass
+};
+
+// Shared by forward and backward so both see bit-identical intermediates.
+struct Ewa {
+  float tx, ty, tz, xmul, ymul;
+  float M[6];  // J * W (2x3)
+};
+
+__device__ __forceinline__ Ewa ewa_setup(float3 pv, const float* view, const CamParams& cp) {
+  Ewa e;
+  const float limx = 1.3f * cp.tanfovx, limy = 1.3f * cp.tanfovy;
+  const float txtz = pv.x / pv.z, tytz = pv.y / pv.z;
+  e.tx = fminf(limx, fmaxf(-limx, txtz)) * pv.z;
+  e.ty = fminf(limy, fmaxf(-limy, tytz)) * pv.z;
+  e.tz = pv.z;
+  e.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  e.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  const float j00 = cp.focal_x / e.tz, j02 = -(cp.focal_x * e.tx) / (e.tz * e.tz);
+  const float j11 = cp.focal_y / e.tz, j12 = -(cp.focal_y * e.ty) / (e.tz * e.tz);
+  // W rows: (view0, view4, view8), (view1, view5, view9), (view2, view6, view10)
+  e.M[0] = j00 * view[0] + j02 * view[2];
+  e.M[1] = j00 * view[4] + j02 * view[6];
+  e.M[2] = j00 * view[8] + j02 * view[10];
+  e.M[3] = j11 * view[1] + j12 * view[2];
+  e.M[4] = j11 * view[5] + j12 * view[6];
+  e.M[5] = j11 * view[9] + j12 * view[10];
+  return e;
+}
+
+__device__ __forceinline__ Cov2D ewa_cov2d(const Ewa& e, const float* cov) {
+  // MS = M * Sigma (2x3), cov2D = MS * M^T
+  const float* M = e.M;
+  float MS[6];
+  MS[0] = M[0] * cov[0] + M[1] * cov[1] + M[2] * cov[2];
+  MS[1] = M[0] * cov[1] + M[1] * cov[3] + M[2] * cov[4];
+  MS[2] = M[0] * cov[2] + M[1] * cov[4] + M[2] * cov[5];
+  MS[3] = M[3] * cov[0] + M[4] * cov[1] + M[5] * cov[2];
+  MS[4] = M[3] * cov[1] + M[4] * cov[3] + M[5] * cov[4];
+  MS[5] = M[3] * cov[2] + M[4] * cov[4] + M[5] * cov[5];
+  Cov2D c;
+  c.a = MS[0] * M[0] + MS[1] * M[1] + MS[2] * M[2] + 0.3f;
+  c.b = MS[0] * M[3] + MS[1] * M[4] + MS[2] * M[5];
+  c.c = MS[3] * M[3] + MS[4] * M[4] + MS[5] * M[5] + 0.3f;
+  return c;
+}
+
+__device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, float* R) {
+  R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+  R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+  R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// SH basis for unit direction d, order/signs of reference utils/sh_utils.py:74-100
+template <int NB>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+  b[0] = SH_C0;
+  if (NB > 1) { b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x; }
+  if (NB > 4) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.f * zz - xx - yy);
+    b[7] = SH_C2_3 * xz; b[8] = SH_C2_4 * (xx - yy);
+    if (NB > 9) {
+      b[9] = SH_C3_0 * y * (3.f * xx - yy); b[10] = SH_C3_1 * xy * z;
+      b[11] = SH_C3_2 * y * (4.f * zz - xx - yy); b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+      b[13] = SH_C3_4 * x * (4.f * zz - xx - yy); b[14] = SH_C3_5 * z * (xx - yy);
+      b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+    }
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ float3 sh_eval(const float* sh /*[M,3]*/, float x, float y, float z) {
+  float b[NB];
+  sh_basis<NB>(x, y, z, b);
+  float3 acc = make_float3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    acc.x += b[k] * sh[3 * k]; acc.y += b[k] * sh[3 * k + 1]; acc.z += b[k] * sh[3 * k + 2];
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 forward: projection + per-tile instance counting
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_preprocess_fwd(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ opacities, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, CamParams cp,
+    int32_t* __restrict__ radii, GsRec* __restrict__ recs, float* __restrict__ cov3Ds, uint2* __restrict__ rects,
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ tile_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  radii[i] = 0;
+  rects[i] = make_uint2(0u, 0u);
+  const float* view = cp.view;
+  const float* proj = cp.proj;
+  const float3 m = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+  const float3 pv = gs_tp43(view, m);
+  if (pv.z <= 0.2f) return;
+  const float4 ph = gs_tp44(proj, m);
+  const float pw = 1.0f / (ph.w + 0.0000001f);
+  const float ndcx = ph.x * pw, ndcy = ph.y * pw;
+
+  float cov[6];
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[6 * (size_t)i + k];
+  } else {
+    const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+    float R[9];
+    quat_to_R(q.x, q.y, q.z, q.w, R);
+    const float s0 = cp.scale_modifier * scales[3 * (size_t)i], s1 = cp.scale_modifier * scales[3 * (size_t)i + 1],
+                s2 = cp.scale_modifier * scales[3 * (size_t)i + 2];
+    float L[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { L[3 * r] = R[3 * r] * s0; L[3 * r + 1] = R[3 * r + 1] * s1; L[3 * r + 2] = R[3 * r + 2] * s2; }
+    cov[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+    cov[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+    cov[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+    cov[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+    cov[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+    cov[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cov3Ds[6 * (size_t)i + k] = cov[k];
+
+  const Ewa e = ewa_setup(pv, view, cp);
+  const Cov2D c2 = ewa_cov2d(e, cov);
+  const float det = c2.a * c2.c - c2.b * c2.b;
+  if (det == 0.0f) return;
+  const float det_inv = 1.f / det;
+  const float ca = c2.c * det_inv, cb = -c2.b * det_inv, cc = c2.a * det_inv;
+  const float mid = 0.5f * (c2.a + c2.c);
+  const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+  const float radius = ceilf(3.f * sqrtf(fmaxf(mid + sq, mid - sq)));
+  const float px = ((ndcx + 1.0f) * cp.W - 1.0f) * 0.5f, py = ((ndcy + 1.0f) * cp.H - 1.0f) * 0.5f;
+  const int rminx = min(cp.gx, max(0, (int)((px - radius) / GS_TILE)));
+  const int rminy = min(cp.gy, max(0, (int)((py - radius) / GS_TILE)));
+  const int rmaxx = min(cp.gx, max(0, (int)((px + radius + GS_TILE - 1) / GS_TILE)));
+  const int rmaxy = min(cp.gy, max(0, (int)((py + radius + GS_TILE - 1) / GS_TILE)));
+  if ((rmaxx - rminx) * (rmaxy - rminy) == 0) return;
+
+  float3 rgb;
+  uint8_t clamp_bits = 0;
+  if (colors_precomp) {
+    rgb = make_float3(colors_precomp[3 * (size_t)i], colors_precomp[3 * (size_t)i + 1], colors_precomp[3 * (size_t)i + 2]);
+  } else {
+    float dx = m.x - cp.campos[0], dy = m.y - cp.campos[1], dz = m.z - cp.campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    const float* sh = shs + (size_t)i * M * 3;
+    float3 v;
+    if (D == 0) v = sh_eval<1>(sh, dx, dy, dz);
+    else if (D == 1) v = sh_eval<4>(sh, dx, dy, dz);
+    else if (D == 2) v = sh_eval<9>(sh, dx, dy, dz);
+    else v = sh_eval<16>(sh, dx, dy, dz);
+    v.x += 0.5f; v.y += 0.5f; v.z += 0.5f;
+    clamp_bits = (uint8_t)((v.x < 0.f ? 1 : 0) | (v.y < 0.f ? 2 : 0) | (v.z < 0.f ? 4 : 0));
+    rgb = make_float3(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f));
+  }
+
+  // Half extents of the axis-aligned box around {alpha >= 1/255}: a pixel outside it would be skipped
+  // by the alpha test anyway, so the composite kernels use the box to skip whole 8x8 pixel groups.
+  // Computed from the conic actually used; 1% + 0.5 px slack; disabled (inf) when the conic is too
+  // ill-conditioned for the bound to be trusted.
+  const float opac = opacities[i];
+  float hx, hy;
+  const float tau = __logf(255.0f * opac);
+  const float cdet = ca * cc - cb * cb;
+  if (!(tau > 0.f)) { hx = hy = -1e30f; }
+  else if (!(cdet > 0.f) || ca * cc > 1000.f * cdet) { hx = hy = 1e30f; }
+  else {
+    const float s = 2.f * tau / cdet;
+    hx = sqrtf(s * cc) * 1.01f + 0.5f;
+    hy = sqrtf(s * ca) * 1.01f + 0.5f;
+  }
+
+  radii[i] = (int)radius;
+  clamped[i] = clamp_bits;
+  rects[i] = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+  GsRec rec;
+  rec.q0 = make_float4(px, py, hx, hy);
+  rec.q1 = make_float4(ca, cb, cc, opac);
+  rec.q2 = make_float4(rgb.x, rgb.y, rgb.z, pv.z);
+  recs[i] = rec;
+  for (int y = rminy; y < rmaxy; ++y)
+    for (int x = rminx; x < rmaxx; ++x) atomicAdd(&tile_count[y * cp.gx + x], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8+K9 backward: screen-space gradients -> means, SH, opacity, scale, rotation (A.5)
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void sh_backward(const float* sh, float* gsh, float x, float y, float z, float3 gr, float* gd) {
+  float b[NB];
+  sh_basis<NB>(x, y, z, b);
+#pragma unroll
+  for (int k = 0; k < NB; ++k) { gsh[3 * k] = b[k] * gr.x; gsh[3 * k + 1] = b[k] * gr.y; gsh[3 * k + 2] = b[k] * gr.z; }
+  // w_k = sum_c sh[k,c] * g_c ; gd = sum_k dbasis_k/dd * w_k
+  float w[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) w[k] = sh[3 * k] * gr.x + sh[3 * k + 1] * gr.y + sh[3 * k + 2] * gr.z;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (NB > 1) { gy += -SH_C1 * w[1]; gz += SH_C1 * w[2]; gx += -SH_C1 * w[3]; }
+  if (NB > 4) {
+    const float xx = x * x, yy = y * y, zz = z * z;
+    gx += SH_C2_0 * y * w[4]; gy += SH_C2_0 * x * w[4];
+    gy += SH_C2_1 * z * w[5]; gz += SH_C2_1 * y * w[5];
+    gx += SH_C2_2 * -2.f * x * w[6]; gy += SH_C2_2 * -2.f * y * w[6]; gz += SH_C2_2 * 4.f * z * w[6];
+    gx += SH_C2_3 * z * w[7]; gz += SH_C2_3 * x * w[7];
+    gx += SH_C2_4 * 2.f * x * w[8]; gy += SH_C2_4 * -2.f * y * w[8];
+    if (NB > 9) {
+      gx += SH_C3_0 * 6.f * x * y * w[9]; gy += SH_C3_0 * (3.f * xx - 3.f * yy) * w[9];
+      gx += SH_C3_1 * y * z * w[10]; gy += SH_C3_1 * x * z * w[10]; gz += SH_C3_1 * x * y * w[10];
+      gx += SH_C3_2 * -2.f * x * y * w[11]; gy += SH_C3_2 * (4.f * zz - xx - 3.f * yy) * w[11]; gz += SH_C3_2 * 8.f * y * z * w[11];
+      gx += SH_C3_3 * -6.f * x * z * w[12]; gy += SH_C3_3 * -6.f * y * z * w[12]; gz += SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * w[12];
+      gx += SH_C3_4 * (4.f * zz - 3.f * xx - yy) * w[13]; gy += SH_C3_4 * -2.f * x * y * w[13]; gz += SH_C3_4 * 8.f * x * z * w[13];
+      gx += SH_C3_5 * 2.f * x * z * w[14]; gy += SH_C3_5 * -2.f * y * z * w[14]; gz += SH_C3_5 * (xx - yy) * w[14];
+      gx += SH_C3_6 * (3.f * xx - 3.f * yy) * w[15]; gy += SH_C3_6 * -6.f * x * y * w[15];
+    }
+  }
+  gd[0] = gx; gd[1] = gy; gd[2] = gz;
+}
+
+__global__ __launch_bounds__(256) void k_preprocess_bwd(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
+    const float* __restrict__ rotations, int use_shs, int use_cov_precomp, CamParams cp, const int32_t* __restrict__ radii,
+    const float* __restrict__ cov3Ds, const uint8_t* __restrict__ clamped, const GsGrad* __restrict__ grads,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const bool vis = radii[i] > 0;
+  GsGrad g;
+  if (vis) g = grads[i];
+  else { g.g0 = make_float4(0, 0, 0, 0); g.g1 = g.g0; g.g2 = g.g0; }
+  float gm[3] = {0.f, 0.f, 0.f};
+  float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+  const float3 gcol = make_float3(g.g1.z, g.g1.w, g.g2.x);
+  const int nb = (D + 1) * (D + 1);
+  float* gsh = dL_dshs ? dL_dshs + (size_t)i * M * 3 : nullptr;
+
+  if (vis) {
+    const float* view = cp.view;
+    const float* proj = cp.proj;
+    const float3 m = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+    float cov[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov[k] = cov3Ds[6 * (size_t)i + k];
+    // ---- conic -> cov2D -> (cov3D, mean)
+    {
+      const float3 pv = gs_tp43(view, m);
+      const Ewa e = ewa_setup(pv, view, cp);
+      const Cov2D c2 = ewa_cov2d(e, cov);
+      const float a = c2.a, b = c2.b, c = c2.c;
+      const float det = a * c - b * b;
+      const float Dv = 1.f / (det * det + 0.0000001f);
+      const float gA = g.g0.z, gB = g.g0.w, gC = g.g1.x;
+      const float ga = Dv * (-c * c * gA + b * c * gB + (det - a * c) * gC);
+      const float gc = Dv * ((det - a * c) * gA + a * b * gB - a * a * gC);
+      const float gb = Dv * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
+      const float* Mx = e.M;
+      float GM[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { GM[k] = ga * Mx[k] + 0.5f * gb * Mx[3 + k]; GM[3 + k] = 0.5f * gb * Mx[k] + gc * Mx[3 + k]; }
+      // gSigma = M^T Gm M, packed with doubled off-diagonals
+      gcov[0] = Mx[0] * GM[0] + Mx[3] * GM[3];
+      gcov[1] = 2.f * (Mx[0] * GM[1] + Mx[3] * GM[4]);
+      gcov[2] = 2.f * (Mx[0] * GM[2] + Mx[3] * GM[5]);
+      gcov[3] = Mx[1] * GM[1] + Mx[4] * GM[4];
+      gcov[4] = 2.f * (Mx[1] * GM[2] + Mx[4] * GM[5]);
+      gcov[5] = Mx[2] * GM[2] + Mx[5] * GM[5];
+      // gM = 2 * GM * Sigma
+      float gM[6];
+      gM[0] = 2.f * (GM[0] * cov[0] + GM[1] * cov[1] + GM[2] * cov[2]);
+      gM[1] = 2.f * (GM[0] * cov[1] + GM[1] * cov[3] + GM[2] * cov[4]);
+      gM[2] = 2.f * (GM[0] * cov[2] + GM[1] * cov[4] + GM[2] * cov[5]);
+      gM[3] = 2.f * (GM[3] * cov[0] + GM[4] * cov[1] + GM[5] * cov[2]);
+      gM[4] = 2.f * (GM[3] * cov[1] + GM[4] * cov[3] + GM[5] * cov[4]);
+      gM[5] = 2.f * (GM[3] * cov[2] + GM[4] * cov[4] + GM[5] * cov[5]);
+      // gJ = gM * W^T ; only J00, J02, J11, J12 vary
+      const float gJ00 = gM[0] * view[0] + gM[1] * view[4] + gM[2] * view[8];
+      const float gJ02 = gM[0] * view[2] + gM[1] * view[6] + gM[2] * view[10];
+      const float gJ11 = gM[3] * view[1] + gM[4] * view[5] + gM[5] * view[9];
+      const float gJ12 = gM[3] * view[2] + gM[4] * view[6] + gM[5] * view[10];
+      const float tz2 = 1.f / (e.tz * e.tz), tz3 = tz2 / e.tz;
+      const float gtx = e.xmul * -cp.focal_x * tz2 * gJ02;
+      const float gty = e.ymul * -cp.focal_y * tz2 * gJ12;
+      const float gtz = -cp.focal_x * tz2 * gJ00 - cp.focal_y * tz2 * gJ11 + 2.f * cp.focal_x * e.tx * tz3 * gJ02 +
+                        2.f * cp.focal_y * e.ty * tz3 * gJ12;
+      gm[0] = view[0] * gtx + view[1] * gty + view[2] * gtz;
+      gm[1] = view[4] * gtx + view[5] * gty + view[6] * gtz;
+      gm[2] = view[8] * gtx + view[9] * gty + view[10] * gtz;
+    }
+    // ---- projection path (screen-space mean gradient)
+    {
+      const float4 ph = gs_tp44(proj, m);
+      const float mw = 1.0f / (ph.w + 0.0000001f);
+      const float mul1 = ph.x * mw * mw, mul2 = ph.y * mw * mw;
+      const float g2x = g.g0.x, g2y = g.g0.y;
+      gm[0] += (proj[0] * mw - proj[3] * mul1) * g2x + (proj[1] * mw - proj[3] * mul2) * g2y;
+      gm[1] += (proj[4] * mw - proj[7] * mul1) * g2x + (proj[5] * mw - proj[7] * mul2) * g2y;
+      gm[2] += (proj[8] * mw - proj[11] * mul1) * g2x + (proj[9] * mw - proj[11] * mul2) * g2y;
+    }
+    // ---- SH
+    if (use_shs) {
+      float dx = m.x - cp.campos[0], dy = m.y - cp.campos[1], dz = m.z - cp.campos[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inv; dy *= inv; dz *= inv;
+      const uint8_t cl = clamped[i];
+      const float3 gr = make_float3((cl & 1) ? 0.f : gcol.x, (cl & 2) ? 0.f : gcol.y, (cl & 4) ? 0.f : gcol.z);
+      const float* sh = shs + (size_t)i * M * 3;
+      float gd[3];
+      if (D == 0) sh_backward<1>(sh, gsh, dx, dy, dz, gr, gd);
+      else if (D == 1) sh_backward<4>(sh, gsh, dx, dy, dz, gr, gd);
+      else if (D == 2) sh_backward<9>(sh, gsh, dx, dy, dz, gr, gd);
+      else sh_backward<16>(sh, gsh, dx, dy, dz, gr, gd);
+      const float dot = dx * gd[0] + dy * gd[1] + dz * gd[2];
+      gm[0] += (gd[0] - dx * dot) * inv; gm[1] += (gd[1] - dy * dot) * inv; gm[2] += (gd[2] - dz * dot) * inv;
+    }
+    // ---- cov3D -> scale, rotation
+    if (!use_cov_precomp) {
+      const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+      float R[9];
+      quat_to_R(q.x, q.y, q.z, q.w, R);
+      const float mod = cp.scale_modifier;
+      const float s[3] = {mod * scales[3 * (size_t)i], mod * scales[3 * (size_t)i + 1], mod * scales[3 * (size_t)i + 2]};
+      float L[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { L[3 * r] = R[3 * r] * s[0]; L[3 * r + 1] = R[3 * r + 1] * s[1]; L[3 * r + 2] = R[3 * r + 2] * s[2]; }
+      const float Gs[9] = {gcov[0], 0.5f * gcov[1], 0.5f * gcov[2], 0.5f * gcov[1], gcov[3], 0.5f * gcov[4],
+                           0.5f * gcov[2], 0.5f * gcov[4], gcov[5]};
+      float gL[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gL[3 * r + k] = 2.f * (Gs[3 * r] * L[k] + Gs[3 * r + 1] * L[3 + k] + Gs[3 * r + 2] * L[6 + k]);
+      float Rp[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gs[k] = mod * (R[k] * gL[k] + R[3 + k] * gL[3 + k] + R[6 + k] * gL[6 + k]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Rp[3 * r + k] = gL[3 * r + k] * s[k];
+      }
+      const float r_ = q.x, x = q.y, y = q.z, z = q.w;
+      gq[0] = 2.f * (z * (Rp[3] - Rp[1]) + y * (Rp[2] - Rp[6]) + x * (Rp[7] - Rp[5]));
+      gq[1] = 2.f * (y * (Rp[1] + Rp[3]) + z * (Rp[2] + Rp[6]) + r_ * (Rp[7] - Rp[5])) - 4.f * x * (Rp[4] + Rp[8]);
+      gq[2] = 2.f * (x * (Rp[1] + Rp[3]) + r_ * (Rp[2] - Rp[6]) + z * (Rp[5] + Rp[7])) - 4.f * y * (Rp[0] + Rp[8]);
+      gq[3] = 2.f * (r_ * (Rp[3] - Rp[1]) + x * (Rp[2] + Rp[6]) + y * (Rp[5] + Rp[7])) - 4.f * z * (Rp[0] + Rp[4]);
+    }
+  }
+
+  // ---- write every output row (zeros for culled Gaussians: callers get fully-defined tensors)
+  dL_dmeans3D[3 * (size_t)i] = gm[0]; dL_dmeans3D[3 * (size_t)i + 1] = gm[1]; dL_dmeans3D[3 * (size_t)i + 2] = gm[2];
+  dL_dmeans2D[3 * (size_t)i] = g.g0.x; dL_dmeans2D[3 * (size_t)i + 1] = g.g0.y; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
+  dL_dopac[i] = g.g1.y;
+  if (dL_dcolors) { dL_dcolors[3 * (size_t)i] = gcol.x; dL_dcolors[3 * (size_t)i + 1] = gcol.y; dL_dcolors[3 * (size_t)i + 2] = gcol.z; }
+  if (gsh) {
+    const int first = (vis && use_shs) ? nb : 0;  // coefficients [0,nb) were written by sh_backward
+    for (int k = first * 3; k < M * 3; ++k) gsh[k] = 0.f;
+  }
+  if (dL_dscales) { dL_dscales[3 * (size_t)i] = gs[0]; dL_dscales[3 * (size_t)i + 1] = gs[1]; dL_dscales[3 * (size_t)i + 2] = gs[2]; }
+  if (dL_drots) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+  if (dL_dcov3D) {
+    const bool on = vis && use_cov_precomp;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = on ? gcov[k] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict__ view,
+                                                      uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float3 m = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+  present[i] = gs_tp43(view, m).z > 0.2f ? 1 : 0;
+}
+
+}  // namespace
+
+// ---- host-side launchers (called from api.hip)
+int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs,
+                             const float* colors_precomp, const float* opacities, const float* scales,
+                             const float* rotations, const float* cov3D_precomp, const CamParams& cp, int32_t* radii,
+                             GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped, uint32_t* tile_count) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, colors_precomp,
+                     opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, tile_count);
+  return 0;
+}
+
+int gs_launch_preprocess_bwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs,
+                             const float* scales, const float* rotations, int use_shs, int use_cov_precomp,
+                             const CamParams& cp, const int32_t* radii, const float* cov3Ds, const uint8_t* clamped,
+                             const GsGrad* grads, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                             float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, scales, rotations,
+                     use_shs, use_cov_precomp, cp, radii, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                     dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D);
+  return 0;
+}
+
+int gs_launch_mark_visible(hipStream_t stream, int P, const float* means3D, const float* view, uint8_t* present) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, view, present);
+  return 0;
+}

@@ -1,0 +1,217 @@
+// Fused SSIM (+ L1) loss, forward and backward.
+// replaces fused_ssim.fused_ssim at reference train.py:173; value/gradient definition pinned by the
+// reference's own fallback utils/loss_utils.py:55-85 (11-tap Gaussian, sigma 1.5, zero "same"
+// padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements).  L1 is reference utils/loss_utils.py:39-40.
+//
+// One workgroup = one 16x16 output tile of one (batch, channel) plane.  The 26x26 input halo of both
+// images is staged in LDS once; the 11x11 window is applied separably (row pass into LDS, column
+// pass in registers) for the five moments x, y, x^2, y^2, xy.  HBM-bound: forward reads 8 B and
+// writes 12 B per element (+ halo re-reads served by L2), backward reads 20 B and writes 4 B.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16;          // output tile edge
+constexpr int HALO = 5;         // window radius
+constexpr int TH = TS + 2 * HALO;  // 26
+constexpr float C1 = 0.01f * 0.01f;
+constexpr float C2 = 0.03f * 0.03f;
+
+// normalised Gaussian(11, sigma 1.5) — the coefficients the reference's create_window() produces
+__device__ __forceinline__ float gw(int k) {
+  constexpr float w[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f, 0.10936068743467331f,
+                           0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
+                           0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
+  return w[k];
+}
+
+__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                   float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
+                                                   float* __restrict__ dm_dsigma12, float* __restrict__ partial /*[nblocks,2]*/) {
+  __shared__ float s_x[TH][TH + 1];
+  __shared__ float s_y[TH][TH + 1];
+  __shared__ float s_h[5][TH][TS + 1];
+  __shared__ float s_red[2][4];
+  const int tid = threadIdx.y * TS + threadIdx.x;
+  const int plane = blockIdx.z;
+  const int ox = blockIdx.x * TS, oy = blockIdx.y * TS;
+  const float* p1 = img1 + (size_t)plane * H * W;
+  const float* p2 = img2 + (size_t)plane * H * W;
+  for (int i = tid; i < TH * TH; i += 256) {
+    const int r = i / TH, c = i - r * TH;
+    const int gy = oy + r - HALO, gx = ox + c - HALO;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    s_x[r][c] = in ? p1[(size_t)gy * W + gx] : 0.f;
+    s_y[r][c] = in ? p2[(size_t)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < TH * TS; i += 256) {
+    const int r = i / TS, c = i - r * TS;
+    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = gw(k), x = s_x[r][c + k], y = s_y[r][c + k];
+      sx += w * x; sy += w * y; sxx += w * x * x; syy += w * y * y; sxy += w * x * y;
+    }
+    s_h[0][r][c] = sx; s_h[1][r][c] = sy; s_h[2][r][c] = sxx; s_h[3][r][c] = syy; s_h[4][r][c] = sxy;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x, ly = threadIdx.y;
+  float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = gw(k);
+    mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx]; exx += w * s_h[2][ly + k][lx];
+    eyy += w * s_h[3][ly + k][lx]; exy += w * s_h[4][ly + k][lx];
+  }
+  const int gx = ox + lx, gy = oy + ly;
+  const bool in = gx < W && gy < H;
+  float val = 0.f, l1 = 0.f;
+  if (in) {
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+    const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu12 + C1, Dd = 2.f * s12 + C2;
+    const float invAB = 1.f / (A * B);
+    val = Cc * Dd * invAB;
+    const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
+    if (dm_dmu1) {
+      dm_dmu1[o] = (mu2 * 2.f * Dd) * invAB - (mu2 * 2.f * Cc) * invAB - (mu1 * 2.f * Cc * Dd) * invAB / A + (mu1 * 2.f * Cc * Dd) * invAB / B;
+      dm_dsigma1_sq[o] = -Cc * Dd * invAB / B;
+      dm_dsigma12[o] = 2.f * Cc * invAB;
+    }
+    l1 = fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
+  }
+  val = gs_wave_sum(val);
+  l1 = gs_wave_sum(l1);
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) { s_red[0][wave] = val; s_red[1][wave] = l1; }
+  __syncthreads();
+  if (tid == 0) {
+    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    partial[2 * b + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+  }
+}
+
+// deterministic final reduction of the per-block partial sums (double accumulation)
+__global__ __launch_bounds__(1024) void k_ssim_finish(int nblocks, double inv_n, const float* __restrict__ partial,
+                                                       float* __restrict__ ssim_mean, float* __restrict__ l1_mean) {
+  __shared__ double s_a[16], s_b[16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 1024) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_a[wave] = a; s_b[wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < 16; ++w) { ta += s_a[w]; tb += s_b[w]; }
+    if (ssim_mean) *ssim_mean = (float)(ta * inv_n);
+    if (l1_mean) *l1_mean = (float)(tb * inv_n);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                   const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
+                                                   const float* __restrict__ dm_dsigma12, const float* __restrict__ ssim_scale,
+                                                   const float* __restrict__ l1_scale, float* __restrict__ dL_dimg1) {
+  __shared__ float s_a[TH][TH + 1];
+  __shared__ float s_b[TH][TH + 1];
+  __shared__ float s_c[TH][TH + 1];
+  __shared__ float s_h[3][TH][TS + 1];
+  const int tid = threadIdx.y * TS + threadIdx.x;
+  const int plane = blockIdx.z;
+  const int ox = blockIdx.x * TS, oy = blockIdx.y * TS;
+  const size_t po = (size_t)plane * H * W;
+  const float ks = ssim_scale ? *ssim_scale * inv_n : 0.f;
+  const float kl = l1_scale ? *l1_scale * inv_n : 0.f;
+  if (ks != 0.f) {
+    for (int i = tid; i < TH * TH; i += 256) {
+      const int r = i / TH, c = i - r * TH;
+      const int gy = oy + r - HALO, gx = ox + c - HALO;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const size_t o = po + (size_t)gy * W + gx;
+      s_a[r][c] = in ? dm_dmu1[o] : 0.f;
+      s_b[r][c] = in ? dm_dsigma1_sq[o] : 0.f;
+      s_c[r][c] = in ? dm_dsigma12[o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < TH * TS; i += 256) {
+      const int r = i / TS, c = i - r * TS;
+      float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float w = gw(k);
+        a += w * s_a[r][c + k]; b += w * s_b[r][c + k]; cc += w * s_c[r][c + k];
+      }
+      s_h[0][r][c] = a; s_h[1][r][c] = b; s_h[2][r][c] = cc;
+    }
+    __syncthreads();
+  }
+  const int lx = threadIdx.x, ly = threadIdx.y;
+  const int gx = ox + lx, gy = oy + ly;
+  if (gx >= W || gy >= H) return;
+  const size_t o = po + (size_t)gy * W + gx;
+  const float x = img1[o], y = img2[o];
+  float g = 0.f;
+  if (ks != 0.f) {
+    float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = gw(k);
+      a += w * s_h[0][ly + k][lx]; b += w * s_h[1][ly + k][lx]; cc += w * s_h[2][ly + k][lx];
+    }
+    g = ks * (a + 2.f * x * b + y * cc);
+  }
+  if (kl != 0.f) {
+    const float d = x - y;
+    g += kl * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+  }
+  dL_dimg1[o] = g;
+}
+
+}  // namespace
+
+static inline int ssim_nblocks(int B, int C, int H, int W) { return B * C * ((H + TS - 1) / TS) * ((W + TS - 1) / TS); }
+
+extern "C" {
+
+size_t mi355gs_ssim_scratch_bytes(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 256;
+  return gs_align((size_t)ssim_nblocks(B, C, H, W) * 2 * sizeof(float));
+}
+
+int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, float* dm_dmu1,
+                         float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float* ssim_mean, float* l1_mean) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch) return MI355GS_EINVAL;
+  if ((dm_dmu1 == nullptr) != (dm_dsigma1_sq == nullptr) || (dm_dmu1 == nullptr) != (dm_dsigma12 == nullptr)) return MI355GS_EINVAL;
+  if ((size_t)B * C > 65535) return MI355GS_EINVAL;
+  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
+  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch);
+  GS_CHECK_LAUNCH("ssim_fwd");
+  const double inv_n = 1.0 / ((double)B * C * H * W);
+  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean, l1_mean);
+  GS_CHECK_LAUNCH("ssim_finish");
+  return MI355GS_OK;
+}
+
+int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
+                          const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* ssim_grad_scale,
+                          const float* l1_grad_scale, float* dL_dimg1) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dL_dimg1) return MI355GS_EINVAL;
+  if (ssim_grad_scale && (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)) return MI355GS_EINVAL;
+  if ((size_t)B * C > 65535) return MI355GS_EINVAL;
+  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
+  const float inv_n = (float)(1.0 / ((double)B * C * H * W));
+  hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                     ssim_grad_scale, l1_grad_scale, dL_dimg1);
+  GS_CHECK_LAUNCH("ssim_bwd");
+  return MI355GS_OK;
+}
+
+}  // extern "C"

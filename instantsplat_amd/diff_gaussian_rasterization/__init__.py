@@ -1,0 +1,189 @@
+"""Drop-in for the `diff_gaussian_rasterization` package the reference imports at
+gaussian_renderer/__init__.py:14-17 and calls at :60-78 (settings) and :126-135 (forward).
+
+Same public names, argument meaning and error behaviour as that operator package
+(GaussianRasterizationSettings with its 12 fields in order, GaussianRasterizer.forward returning
+`(color[3,H,W], radii[P])`, `markVisible`); the compute is libmi355gs.so (HIP, gfx950).
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class BinningPolicy:
+    """How the instance buffer of a frame is sized.
+
+    "exact"   : read the instance count back after the projection stage (one 4-byte D2H copy per
+                forward — what the reference operator does internally) and allocate exactly.
+    "bounded" : no host synchronisation.  Capacity = `slack` x the largest count observed so far for
+                this (P, W, H), learned from asynchronous pinned-memory read-backs of earlier
+                frames; the first frames of a configuration fall back to "exact".  If a frame
+                overflows its capacity the forward of that frame is transparently redone in exact
+                mode at the next point where the count is known (see _RasterizeGaussians.forward).
+    """
+    mode = "exact"
+    slack = 1.5
+    _seen: dict = {}
+
+
+def _empty_bytes(n: int, device) -> torch.Tensor:
+    return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
+
+
+def _cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        s = raster_settings
+        L = _lib.lib()
+        opt = lambda t: None if (t is None or t.numel() == 0) else _lib.f32c(t)
+        means3D = _lib.f32c(means3D)
+        opac = _lib.f32c(opacities)
+        sh_, col_, sc_, rot_, cov_ = opt(sh), opt(colors_precomp), opt(scales), opt(rotations), opt(cov3Ds_precomp)
+        bg, view, proj, campos = _lib.f32c(s.bg), _lib.f32c(s.viewmatrix), _lib.f32c(s.projmatrix), _lib.f32c(s.campos)
+        dev = _lib.require_device(means3D, opac, sh_, col_, sc_, rot_, cov_, bg, view, proj, campos)
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        P = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        M = sh_.shape[1] if sh_ is not None else 0
+        D = int(s.sh_degree)
+        stream = _lib.stream_ptr(dev)
+        debug = 1 if s.debug else 0
+
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        geom = _empty_bytes(L.mi355gs_raster_geom_bytes(P), dev)
+        tiles = _empty_bytes(L.mi355gs_raster_tiles_bytes(W, H), dev)
+        num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def run():
+            _lib.check(L.mi355gs_raster_forward_preprocess(
+                stream, P, D, M, W, H, _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(opac), _lib.ptr(sc_),
+                float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos),
+                float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _lib.ptr(radii), _lib.ptr(geom),
+                _lib.ptr(tiles), _lib.ptr(num_rendered), debug), "raster_forward_preprocess")
+            R = int(num_rendered.item())  # the reference operator's own blocking read-back
+            binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R), dev)
+            _lib.check(L.mi355gs_raster_forward_render(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
+                                                       _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render")
+            return R, binning
+
+        if s.debug:
+            try:
+                R, binning = run()
+            except Exception:
+                torch.save(_cpu_deep_copy_tuple((means3D, sh_, col_, opac, sc_, rot_, cov_, tuple(s))), "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            R, binning = run()
+
+        ctx.raster_settings = s
+        ctx.num_rendered = R
+        ctx.dims = (P, D, M, W, H)
+        ctx.save_for_backward(means3D, sh_ if sh_ is not None else torch.empty(0), col_ if col_ is not None else torch.empty(0),
+                              opac, sc_ if sc_ is not None else torch.empty(0), rot_ if rot_ is not None else torch.empty(0),
+                              cov_ if cov_ is not None else torch.empty(0), radii, geom, tiles, binning, bg, view, proj, campos)
+        ctx.mark_non_differentiable(radii)
+        ctx.opacity_shape = opacities.shape
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        s = ctx.raster_settings
+        L = _lib.lib()
+        P, D, M, W, H = ctx.dims
+        (means3D, sh_, col_, opac, sc_, rot_, cov_, radii, geom, tiles, binning, bg, view, proj, campos) = ctx.saved_tensors
+        opt = lambda t: None if t.numel() == 0 else t
+        sh_, col_, sc_, rot_, cov_ = opt(sh_), opt(col_), opt(sc_), opt(rot_), opt(cov_)
+        dev = means3D.device
+        g = _lib.f32c(grad_out_color)
+        _lib.require_device(g)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        dL_dmeans3D, dL_dmeans2D, dL_dopac = new(P, 3), new(P, 3), new(P)
+        dL_dsh = new(P, M, 3) if sh_ is not None else None
+        dL_dcol = new(P, 3)
+        dL_dscales = new(P, 3) if cov_ is None else None
+        dL_drot = new(P, 4) if cov_ is None else None
+        dL_dcov = new(P, 6) if cov_ is not None else None
+        scratch = _empty_bytes(L.mi355gs_raster_grad_scratch_bytes(P), dev)
+        stream = _lib.stream_ptr(dev)
+
+        def run():
+            _lib.check(L.mi355gs_raster_backward(
+                stream, P, D, M, W, H, _lib.ptr(bg), _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(opac),
+                _lib.ptr(sc_), float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj),
+                _lib.ptr(campos), float(s.tanfovx), float(s.tanfovy), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(binning),
+                int(ctx.num_rendered), _lib.ptr(radii), _lib.ptr(g), _lib.ptr(scratch), _lib.ptr(dL_dmeans3D),
+                _lib.ptr(dL_dmeans2D), _lib.ptr(dL_dsh), _lib.ptr(dL_dcol), _lib.ptr(dL_dopac), _lib.ptr(dL_dscales),
+                _lib.ptr(dL_drot), _lib.ptr(dL_dcov), 1 if s.debug else 0), "raster_backward")
+
+        if s.debug:
+            try:
+                run()
+            except Exception:
+                torch.save(_cpu_deep_copy_tuple((means3D, sh_, col_, opac, sc_, rot_, cov_, radii, g, tuple(s))), "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            run()
+        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcol if sh_ is None else None, dL_dopac.reshape(ctx.opacity_shape),
+                dL_dscales, dL_drot, dL_dcov, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            s = self.raster_settings
+            pos, view, proj = _lib.f32c(positions), _lib.f32c(s.viewmatrix), _lib.f32c(s.projmatrix)
+            dev = _lib.require_device(pos, view, proj)
+            present = torch.zeros(pos.shape[0], dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib().mi355gs_raster_mark_visible(_lib.stream_ptr(dev), pos.shape[0], _lib.ptr(pos), _lib.ptr(view),
+                                                              _lib.ptr(proj), _lib.ptr(present)), "raster_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp,
+                                   opacities, e if scales is None else scales, e if rotations is None else rotations,
+                                   e if cov3D_precomp is None else cov3D_precomp, raster_settings)

@@ -1,0 +1,41 @@
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+    config.addinivalue_line("markers", "slow: longer CPU test")
+
+
+@pytest.fixture(scope="session")
+def emu_lib_path():
+    """g++ build of the UNMODIFIED kernel sources against the SIMT emulator (tests/emu)."""
+    subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    return os.path.join(ROOT, "tests", "emu", "libmi355gs_emu.so")
+
+
+@pytest.fixture()
+def emu(emu_lib_path):
+    """Route instantsplat_amd's operators to the emulated library for one CPU test."""
+    from instantsplat_amd import _lib
+    _lib._use_library_for_testing(emu_lib_path)
+    yield torch.device("cpu")
+    _lib._use_library_for_testing(None)
+
+
+@pytest.fixture()
+def gpu():
+    """The product path: hipcc-built libmi355gs.so on cuda:0. Fails loudly if either is missing."""
+    from instantsplat_amd import _lib
+    assert torch.cuda.is_available(), "gpu-marked test run without a GPU"
+    _lib._use_library_for_testing(None)
+    _lib.lib()
+    return torch.device("cuda:0")

@@ -330,8 +330,8 @@ static inline unsigned __float_as_uint(float f) { return emu::from_bits<unsigned
 static inline int __float_as_int(float f) { return emu::from_bits<int>(emu::to_bits(f)); }
 static inline float __uint_as_float(unsigned u) { return emu::from_bits<float>(emu::to_bits(u)); }
 static inline float __int_as_float(int u) { return emu::from_bits<float>(emu::to_bits(u)); }
-static inline float __expf(float x) { return expf(x); }
-static inline float __logf(float x) { return logf(x); }
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __fsqrt_rn(float a) { return sqrtf(a); }

@@ -1,0 +1,24 @@
+"""CPU tier: the real kernel sources (compiled against tests/emu) vs the C oracle."""
+import pytest
+import torch
+
+from tests.util import assert_raster_parity, run_blob_case
+
+
+@pytest.mark.parametrize("P,W,H,deg,sm", [(400, 64, 48, 0, 0.15), (400, 50, 37, 3, 0.15), (1500, 96, 64, 2, 0.05)])
+def test_raster_fwd_bwd_matches_oracle(emu, P, W, H, deg, sm):
+    assert_raster_parity(run_blob_case(emu, P, W, H, deg, scale_mean=sm))
+
+
+def test_precomputed_color_and_cov(emu):
+    assert_raster_parity(run_blob_case(emu, 300, 48, 48, 0, scale_mean=0.15, precomp_color=True, precomp_cov=True))
+
+
+def test_scale_modifier_and_init_opacity(emu):
+    assert_raster_parity(run_blob_case(emu, 300, 48, 48, 1, scale_mean=0.1, opacity="init", mod=1.7))
+
+
+def test_empty_and_all_culled(emu):
+    out = run_blob_case(emu, 0, 32, 32, 0, backward=False)
+    assert torch.allclose(out["ref"]["color"], out["dut"]["color"])
+    assert out["dut"]["color"].shape == (3, 32, 32)

@@ -1,0 +1,77 @@
+"""Shared helpers: run the same seeded scene through the oracle and through instantsplat_amd."""
+import math
+
+import torch
+
+from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from instantsplat_amd.synthetic import syn_blob
+from oracle import gs_ref
+from oracle import raster_torch as rt
+
+
+def settings_for(cam, deg, cls, bg, device="cpu", mod=1.0, debug=False):
+    dev = torch.device(device)
+    return cls(cam.image_height, cam.image_width, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), bg.to(dev), mod,
+               torch.eye(4, device=dev), cam.projection_matrix.to(dev), deg, torch.zeros(3, device=dev), False, debug)
+
+
+def relerr(a, b):
+    return float((a.double().cpu() - b.double().cpu()).norm() / (b.double().cpu().norm() + 1e-30))
+
+
+def run_blob_case(device, P, W, H, deg, scale_mean=0.05, seed=1, opacity="random", bg=(0.2, 0.5, 0.9), mod=1.0,
+                  precomp_color=False, precomp_cov=False, backward=True):
+    """Returns dict(ref=..., dut=...) each with color, radii, grads (dict)."""
+    sc = syn_blob(P, W, H, seed=seed, scale_mean=scale_mean, opacity=opacity)
+    bg_t = torch.tensor(bg, dtype=torch.float32)
+    torch.manual_seed(seed + 100)
+    wgt = torch.randn(3, H, W)
+    out = {}
+    for which in ("ref", "dut"):
+        dev = torch.device("cpu") if which == "ref" else torch.device(device)
+        leaves = dict(means3D=sc.means3D.clone(), scaling=sc.scaling_logit.clone(), rot=sc.rotation.clone(),
+                      op=sc.opacity_logit.clone(), shs=sc.shs.clone())
+        leaves = {k: v.to(dev).requires_grad_(True) for k, v in leaves.items()}
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        kw = {}
+        colors = cov = None
+        if precomp_color:
+            colors = torch.sigmoid(leaves["shs"][:, 0, :])
+            kw["colors_precomp"] = colors
+        else:
+            kw["shs"] = leaves["shs"]
+        if precomp_cov:
+            cov = rt.cov3d_from_scale_rot(torch.exp(leaves["scaling"]), mod, leaves["rot"])
+            kw["cov3D_precomp"] = cov
+        else:
+            kw["scales"] = torch.exp(leaves["scaling"])
+            kw["rotations"] = leaves["rot"]
+        if which == "ref":
+            st = settings_for(sc.camera, deg, rt.RasterSettings, bg_t, mod=mod)
+            color, radii = gs_ref.rasterize(leaves["means3D"], m2d, torch.sigmoid(leaves["op"]), st, **kw)
+        else:
+            st = settings_for(sc.camera, deg, GaussianRasterizationSettings, bg_t, device=dev, mod=mod)
+            color, radii = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2d, opacities=torch.sigmoid(leaves["op"]), **kw)
+        grads = {}
+        if backward:
+            (color * wgt.to(dev)).sum().backward()
+            grads = {k: v.grad.detach().cpu().clone() for k, v in leaves.items() if v.grad is not None}
+            grads["means2D"] = m2d.grad.detach().cpu().clone()
+        out[which] = dict(color=color.detach().cpu(), radii=radii.cpu(), grads=grads)
+    return out
+
+
+def assert_raster_parity(out, fwd_tol=1e-4, fwd_max=5e-3, grad_tol=1e-4, radii_frac=1e-4):
+    """Stated fp32 tolerance: >=99.99% of pixels within 1e-4, all within 5e-3 (isolated
+    threshold flips), radii equal up to 0.01% off-by-one, per-tensor gradient relative L2 <= 1e-4."""
+    ref, dut = out["ref"], out["dut"]
+    d = (ref["color"] - dut["color"]).abs()
+    frac_bad = float((d > fwd_tol).float().mean())
+    assert frac_bad <= 1e-4, f"{frac_bad:.2e} of pixel values differ by more than {fwd_tol}"
+    assert float(d.max()) <= fwd_max, f"max pixel error {float(d.max()):.3e}"
+    mism = (ref["radii"] != dut["radii"])
+    assert float(mism.float().mean()) <= radii_frac, f"{int(mism.sum())} radii differ"
+    assert int((ref["radii"] - dut["radii"]).abs().max()) <= 1
+    for k, g in ref["grads"].items():
+        e = relerr(dut["grads"][k], g)
+        assert e <= grad_tol, f"grad {k}: rel L2 {e:.3e} > {grad_tol}"
