@@ -5,7 +5,8 @@
 
 // launchers implemented next to their kernels
 int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*,
-                             const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*, uint32_t*);
+                             const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*);
+int gs_launch_count_tiles(hipStream_t, int, int, int, const uint2*, uint32_t*);
 int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, int, int,
                              const CamParams&, const int32_t*, const float*, const uint8_t*, const GsGrad*, float*, float*,
                              float*, float*, float*, float*, float*, float*);
@@ -74,9 +75,10 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   if (hipMemsetAsync(t + tl.count, 0, tl.start - tl.count, stream) != hipSuccess) return MI355GS_ELAUNCH;
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
   gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
-                           (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped),
-                           (uint32_t*)(t + tl.count));
+                           (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped));
   GS_CHECK_LAUNCH("preprocess_fwd");
+  gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
+  GS_CHECK_LAUNCH("count_tiles");
   gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered);
   GS_CHECK_LAUNCH("scan_tiles");
   return MI355GS_OK;

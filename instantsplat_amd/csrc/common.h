@@ -98,6 +98,22 @@ __device__ __forceinline__ float gs_wave_sum(float v) {
   return v;
 }
 
+// DPP (data-parallel primitive) lane exchange: one VALU op, no LDS traffic.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float gs_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// wave64 sum in 6 DPP adds; the total lands in lanes 48..63 (the last row of 16). All lanes must be active.
+__device__ __forceinline__ float gs_wave_sum_row3(float v) {
+  v += gs_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += gs_dpp<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += gs_dpp<0x141>(v);       // row_half_mirror
+  v += gs_dpp<0x140>(v);       // row_mirror        -> every lane holds its row's sum
+  v += gs_dpp<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+  v += gs_dpp<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> row 3 holds the wave total
+  return v;
+}
+
 #define GS_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \
     hipError_t e_ = hipGetLastError();                                          \

@@ -79,28 +79,32 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
       bool hit = false;
       if (i < cnt) hit = box_hit(s_q0[i], q);
       unsigned long long mask = __ballot(hit);
-      while (mask) {
-        const int b = __ffsll(mask) - 1;
-        mask &= mask - 1;
-        const int i2 = k + b;
-        const float4 a0 = s_q0[i2], a1 = s_q1[i2], a2 = s_q2[i2];
-        if (!done) {
+      if (mask) {
+        // Software-pipelined walk over the hit mask: the next record's three LDS reads are issued
+        // before the current record's math, so their latency hides behind ~25 VALU ops.  The math
+        // is predicated (no exec-mask branches): `valid`/`blend` select results instead.
+        int i_next = k + __ffsll(mask) - 1;
+        float4 n0 = s_q0[i_next], n1 = s_q1[i_next], n2 = s_q2[i_next];
+        for (;;) {
+          const float4 a0 = n0, a1 = n1, a2 = n2;
+          const int i2 = i_next;
+          mask &= mask - 1;
+          const bool more = mask != 0;
+          if (more) i_next = k + __ffsll(mask) - 1;
+          n0 = s_q0[i_next]; n1 = s_q1[i_next]; n2 = s_q2[i_next];
           const float dx = a0.x - q.fx, dy = a0.y - q.fy;
           const float power = -0.5f * (a1.x * dx * dx + a1.z * dy * dy) - a1.y * dx * dy;
-          if (power <= 0.0f) {
-            const float alpha = fminf(0.99f, a1.w * __expf(power));
-            if (alpha >= ALPHA_MIN) {
-              const float test_T = Tr * (1.0f - alpha);
-              if (test_T < T_MIN) {
-                done = true;
-              } else {
-                const float w = alpha * Tr;
-                C0 += a2.x * w; C1 += a2.y * w; C2 += a2.z * w;
-                Tr = test_T;
-                last = (base - start) + (uint32_t)i2 + 1u;
-              }
-            }
-          }
+          const float alpha = fminf(0.99f, a1.w * __expf(fminf(power, 0.0f)));
+          const bool valid = !done && power <= 0.0f && alpha >= ALPHA_MIN;
+          const float test_T = Tr * (1.0f - alpha);
+          const bool stop = valid && test_T < T_MIN;
+          const bool blend = valid && !stop;
+          const float w = blend ? alpha * Tr : 0.0f;
+          C0 += a2.x * w; C1 += a2.y * w; C2 += a2.z * w;
+          Tr = blend ? test_T : Tr;
+          last = blend ? (base - start) + (uint32_t)i2 + 1u : last;
+          done = done || stop;
+          if (!more) break;
         }
       }
       if (__all(done)) break;
@@ -180,57 +184,61 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
       bool hit = false;
       if (i < cnt && boff + (uint32_t)i < wmax) hit = box_hit(s_q0[i], q);
       unsigned long long mask = __ballot(hit);
-      while (mask) {
-        const int b = 63 - __clzll((long long)mask);
-        mask &= ~(1ull << b);
-        const int i2 = k + b;
-        const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
-        const float4 a0 = s_q0[i2], a1 = s_q1[i2], a2 = s_q2[i2];
-        float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
-        bool contributes = false;
-        if (contributor <= last) {
+      if (mask) {
+        int i_next = k + 63 - __clzll((long long)mask);
+        float4 n0 = s_q0[i_next], n1 = s_q1[i_next], n2 = s_q2[i_next];
+        uint32_t nid = s_id[i_next];
+        for (;;) {
+          const float4 a0 = n0, a1 = n1, a2 = n2;
+          const uint32_t id = nid;
+          const int i2 = i_next;
+          mask &= ~(1ull << (i2 - k));
+          const bool more = mask != 0;
+          if (more) i_next = k + 63 - __clzll((long long)mask);
+          n0 = s_q0[i_next]; n1 = s_q1[i_next]; n2 = s_q2[i_next]; nid = s_id[i_next];
+
+          const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
           const float dx = a0.x - q.fx, dy = a0.y - q.fy;
           const float power = -0.5f * (a1.x * dx * dx + a1.z * dy * dy) - a1.y * dx * dy;
-          if (power <= 0.0f) {
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, a1.w * G);
-            if (alpha >= ALPHA_MIN) {
-              contributes = true;
-              Tr = Tr / (1.f - alpha);
-              const float dchannel = alpha * Tr;
-              acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-              acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-              acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-              lc0 = a2.x; lc1 = a2.y; lc2 = a2.z;
-              float dL_dalpha = (a2.x - acc0) * g0 + (a2.y - acc1) * g1 + (a2.z - acc2) * g2;
-              v_r = dchannel * g0; v_g = dchannel * g1; v_b = dchannel * g2;
-              dL_dalpha *= Tr;
-              last_alpha = alpha;
-              dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-              const float dL_dG = a1.w * dL_dalpha;
-              const float gdx = G * dx, gdy = G * dy;
-              const float dG_ddelx = -gdx * a1.x - gdy * a1.y;
-              const float dG_ddely = -gdy * a1.z - gdx * a1.y;
-              v_mx = dL_dG * dG_ddelx * ddelx_dx;
-              v_my = dL_dG * dG_ddely * ddely_dy;
-              v_ca = -0.5f * gdx * dx * dL_dG;
-              v_cb = -gdx * dy * dL_dG;
-              v_cc = -0.5f * gdy * dy * dL_dG;
-              v_op = G * dL_dalpha;
-            }
+          const float G = __expf(fminf(power, 0.0f));
+          const float alpha = fminf(0.99f, a1.w * G);
+          const bool valid = contributor <= last && power <= 0.0f && alpha >= ALPHA_MIN;
+          if (__any(valid)) {
+            const float one_m = 1.f - alpha;
+            Tr = valid ? Tr / one_m : Tr;
+            const float dchannel = valid ? alpha * Tr : 0.f;
+            const float na0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+            const float na1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+            const float na2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+            acc0 = valid ? na0 : acc0; acc1 = valid ? na1 : acc1; acc2 = valid ? na2 : acc2;
+            lc0 = valid ? a2.x : lc0; lc1 = valid ? a2.y : lc1; lc2 = valid ? a2.z : lc2;
+            float dL_dalpha = (a2.x - acc0) * g0 + (a2.y - acc1) * g1 + (a2.z - acc2) * g2;
+            dL_dalpha = dL_dalpha * Tr + (-T_final / one_m) * bg_dot;
+            dL_dalpha = valid ? dL_dalpha : 0.f;
+            last_alpha = valid ? alpha : last_alpha;
+            const float dL_dG = a1.w * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * a1.x - gdy * a1.y;
+            const float dG_ddely = -gdy * a1.z - gdx * a1.y;
+            // 9 x 6 DPP adds; totals land in lanes 48..63, of which 48..56 each own one component
+            const float v_mx = gs_wave_sum_row3(dL_dG * dG_ddelx * ddelx_dx);
+            const float v_my = gs_wave_sum_row3(dL_dG * dG_ddely * ddely_dy);
+            const float v_ca = gs_wave_sum_row3(-0.5f * gdx * dx * dL_dG);
+            const float v_cb = gs_wave_sum_row3(-gdx * dy * dL_dG);
+            const float v_cc = gs_wave_sum_row3(-0.5f * gdy * dy * dL_dG);
+            const float v_op = gs_wave_sum_row3(G * dL_dalpha);
+            const float v_r = gs_wave_sum_row3(dchannel * g0);
+            const float v_g = gs_wave_sum_row3(dchannel * g1);
+            const float v_b = gs_wave_sum_row3(dchannel * g2);
+            float* dst = reinterpret_cast<float*>(grads + id);
+            const int c = lane - 48;
+            float mine = v_mx;
+            mine = c == 1 ? v_my : mine; mine = c == 2 ? v_ca : mine; mine = c == 3 ? v_cb : mine;
+            mine = c == 4 ? v_cc : mine; mine = c == 5 ? v_op : mine; mine = c == 6 ? v_r : mine;
+            mine = c == 7 ? v_g : mine; mine = c == 8 ? v_b : mine;
+            if (c >= 0 && c < 9) atomicAdd(dst + c, mine);
           }
-        }
-        if (__any(contributes)) {
-          v_mx = gs_wave_sum(v_mx); v_my = gs_wave_sum(v_my); v_ca = gs_wave_sum(v_ca);
-          v_cb = gs_wave_sum(v_cb); v_cc = gs_wave_sum(v_cc); v_op = gs_wave_sum(v_op);
-          v_r = gs_wave_sum(v_r); v_g = gs_wave_sum(v_g); v_b = gs_wave_sum(v_b);
-          float* dst = reinterpret_cast<float*>(grads + s_id[i2]);
-          // lanes 0..8 each own one component
-          float mine = v_mx;
-          mine = lane == 1 ? v_my : mine; mine = lane == 2 ? v_ca : mine; mine = lane == 3 ? v_cb : mine;
-          mine = lane == 4 ? v_cc : mine; mine = lane == 5 ? v_op : mine; mine = lane == 6 ? v_r : mine;
-          mine = lane == 7 ? v_g : mine; mine = lane == 8 ? v_b : mine;
-          if (lane < 9) atomicAdd(dst + lane, mine);
+          if (!more) break;
         }
       }
     }

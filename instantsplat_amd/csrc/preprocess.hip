@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, CamParams cp,
     int32_t* __restrict__ radii, GsRec* __restrict__ recs, float* __restrict__ cov3Ds, uint2* __restrict__ rects,
-    uint8_t* __restrict__ clamped, uint32_t* __restrict__ tile_count) {
+    uint8_t* __restrict__ clamped) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   radii[i] = 0;
@@ -196,14 +196,26 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
 
   radii[i] = (int)radius;
   clamped[i] = clamp_bits;
-  rects[i] = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+  // Tiles this Gaussian is binned to: the reference's 3-sigma rect, intersected with the tiles the
+  // alpha >= 1/255 box can reach.  Dropped tiles hold no pixel that would pass the alpha test, so the
+  // image, radii and gradients are unchanged while the instance count R shrinks.
+  int bminx = rminx, bminy = rminy, bmaxx = rmaxx, bmaxy = rmaxy;
+  if (hx < 1e29f) {
+    if (hx < 0.f) { bmaxx = bminx; bmaxy = bminy; }
+    else {
+      bminx = max(bminx, (int)floorf((px - hx) * (1.0f / GS_TILE)));
+      bminy = max(bminy, (int)floorf((py - hy) * (1.0f / GS_TILE)));
+      bmaxx = min(bmaxx, (int)floorf((px + hx) * (1.0f / GS_TILE)) + 1);
+      bmaxy = min(bmaxy, (int)floorf((py + hy) * (1.0f / GS_TILE)) + 1);
+      if (bmaxx <= bminx || bmaxy <= bminy) { bmaxx = bminx; bmaxy = bminy; }
+    }
+  }
+  rects[i] = make_uint2((uint32_t)bminx | ((uint32_t)bminy << 16), (uint32_t)bmaxx | ((uint32_t)bmaxy << 16));
   GsRec rec;
   rec.q0 = make_float4(px, py, hx, hy);
   rec.q1 = make_float4(ca, cb, cc, opac);
   rec.q2 = make_float4(rgb.x, rgb.y, rgb.z, pv.z);
   recs[i] = rec;
-  for (int y = rminy; y < rmaxy; ++y)
-    for (int x = rminx; x < rmaxx; ++x) atomicAdd(&tile_count[y * cp.gx + x], 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,10 +415,10 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* opacities, const float* scales,
                              const float* rotations, const float* cov3D_precomp, const CamParams& cp, int32_t* radii,
-                             GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped, uint32_t* tile_count) {
+                             GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped) {
   if (P <= 0) return 0;
   hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, colors_precomp,
-                     opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, tile_count);
+                     opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped);
   return 0;
 }
 

@@ -196,9 +196,13 @@ inline void run_block() {
   }
 }
 
+inline std::vector<char>& dyn_shared_buf() { static std::vector<char> b; return b; }
+inline void* dyn_shared() { return dyn_shared_buf().data(); }
+
 template <class F>
-inline void launch(F&& body, dim3 grid, dim3 block) {
+inline void launch(F&& body, dim3 grid, dim3 block, size_t shmem = 0) {
   Ctx& c = ctx();
+  if (dyn_shared_buf().size() < shmem + 16) dyn_shared_buf().resize(shmem + 16);
   c.gridDim = grid;
   c.blockDim = block;
   c.nthreads = block.x * block.y * block.z;
@@ -240,9 +244,11 @@ template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T
 #define warpSize 64
 
 template <class K, class... A>
-inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t /*stream*/, A... args) {
-  emu::launch([=]() { kernel(args...); }, grid, block);
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t /*stream*/, A... args) {
+  emu::launch([=]() { kernel(args...); }, grid, block, shmem);
 }
+// HIP's portable spelling of `extern __shared__ type var[]`
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_shared();
 
 // ---------------------------------------------------------------- device intrinsics
 static inline void __syncthreads() { emu::yield_to_sched(emu::AT_BLOCK_BARRIER); }
@@ -313,6 +319,31 @@ static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add) {
   unsigned l = emu::lane_id();
   unsigned lt = l <= 32 ? 0u : ((1u << (l - 32)) - 1u);
   return add + __builtin_popcount(mask & lt);
+}
+// v_mov_b32_dpp semantics (GFX9 DPP): returns src from the lane selected by dpp_ctrl; lanes whose
+// source is out of range, or whose row/bank is masked off, keep `old` (bound_ctrl: 0 instead).
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  int buf = emu::wave_exchange(emu::to_bits(src), true);
+  const int l = (int)emu::lane_id();
+  const int row = l >> 4, r = l & 15;
+  int sl = -1;  // source lane
+  if (ctrl >= 0x000 && ctrl <= 0x0FF) { sl = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3); }
+  else if (ctrl >= 0x101 && ctrl <= 0x10F) { int n = ctrl & 15; sl = (r + n <= 15) ? l + n : -1; }      // row_shl
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) { int n = ctrl & 15; sl = (r - n >= 0) ? l - n : -1; }       // row_shr
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) { int n = ctrl & 15; sl = (row << 4) | ((r - n) & 15); }     // row_ror
+  else if (ctrl == 0x130) { sl = l + 1 <= 63 ? l + 1 : -1; }                                             // wave_shl:1
+  else if (ctrl == 0x134) { sl = (l + 1) & 63; }                                                         // wave_rol:1
+  else if (ctrl == 0x138) { sl = l - 1 >= 0 ? l - 1 : -1; }                                              // wave_shr:1
+  else if (ctrl == 0x13C) { sl = (l - 1) & 63; }                                                         // wave_ror:1
+  else if (ctrl == 0x140) { sl = (row << 4) | (15 - r); }                                                // row_mirror
+  else if (ctrl == 0x141) { sl = (l & ~7) | (7 - (l & 7)); }                                             // row_half_mirror
+  else if (ctrl == 0x142) { sl = row >= 1 ? ((row - 1) << 4) | 15 : -1; }                                // row_bcast:15
+  else if (ctrl == 0x143) { sl = row >= 2 ? 31 : -1; }                                                   // row_bcast:31
+  else { fprintf(stderr, "[hip_emu] unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+  const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> (r >> 2)) & 1);
+  if (!enabled) return old;
+  if (sl < 0 || !emu::lane_in_op(buf, (unsigned)sl)) return bound_ctrl ? 0 : old;
+  return emu::from_bits<int>(emu::ctx().waves[emu::wave_id()].val[buf][sl]);
 }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}

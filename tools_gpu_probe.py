@@ -7,7 +7,9 @@ from tests.util import settings_for
 
 dev = torch.device('cuda:0')
 print(torch.cuda.get_device_name(0))
-for (P, W, H, deg, op) in [(50000, 512, 512, 3, 'random'), (200000, 512, 512, 0, 'random'), (200000, 512, 512, 0, 'init'), (1000000, 1920, 1080, 0, 'random')]:
+CASES = [(50000, 512, 512, 3, 'random'), (200000, 512, 512, 0, 'random'), (200000, 512, 512, 0, 'init'), (1000000, 1920, 1080, 0, 'random')]
+if len(sys.argv) > 1: CASES = [CASES[int(a)] for a in sys.argv[1:]]
+for (P, W, H, deg, op) in CASES:
     sc = syn_blob(P, W, H, seed=0, opacity=op)
     st = settings_for(sc.camera, deg, GaussianRasterizationSettings, sc.bg, device=dev)
     means = sc.means3D.to(dev).requires_grad_(True); sh = sc.shs.to(dev).requires_grad_(True)
