@@ -106,9 +106,10 @@ int mi355gs_raster_mark_visible(void* stream, int P, const float* means3D, const
  * replaces: fused_ssim.fused_ssim(img1, img2) at reference train.py:173 (same value as the
  *           reference's own fallback utils/loss_utils.py:55-85: 11x11 Gaussian window, sigma 1.5,
  *           zero "same" padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements).
- *   img1,img2 [B,C,H,W]; partial_sums: mi355gs_ssim_partials(B,C,H,W) doubles... see below
- *   ssim_sum / l1_sum: device double[1] each, receive SUM of the SSIM map / SUM |img1-img2|
- *   dm_dmu1, dm_dsigma1_sq, dm_dsigma12 [B,C,H,W]: saved partials for backward (null = inference)
+ *   img1, img2 [B,C,H,W]; scratch: mi355gs_ssim_scratch_bytes() bytes (per-workgroup partial sums,
+ *   reduced in a fixed order so the result is run-to-run deterministic)
+ *   ssim_mean / l1_mean: device float[1] each (either may be null): mean SSIM map, mean |img1-img2|
+ *   dm_dmu1, dm_dsigma1_sq, dm_dsigma12 [B,C,H,W]: saved partials for backward (all null = inference)
  * ---------------------------------------------------------------------------------------------- */
 size_t mi355gs_ssim_scratch_bytes(int B, int C, int H, int W);
 int mi355gs_ssim_forward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,

@@ -1,0 +1,84 @@
+"""Drop-in for the `fused_ssim` package (reference train.py:39-43,173).
+
+    fused_ssim(img1, img2, padding="same", train=True) -> 0-dim tensor, gradient w.r.t. img1 only.
+
+`fused_l1_ssim_loss` additionally folds train.py:171-176 — (1-lambda)*L1 + lambda*(1-SSIM) — into
+the same two kernels (the L1 term costs no extra pass over the images).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+
+def _run_forward(img1, img2, train):
+    L = _lib.lib()
+    a, b = _lib.f32c(img1), _lib.f32c(img2)
+    if a.dim() != 4 or a.shape != b.shape:
+        raise RuntimeError("fused_ssim expects two [B,C,H,W] tensors of equal shape")
+    dev = _lib.require_device(a, b)
+    B, C, H, W = a.shape
+    new = lambda: torch.empty_like(a)
+    dm1, dm2, dm3 = (new(), new(), new()) if train else (None, None, None)
+    scratch = torch.empty(int(L.mi355gs_ssim_scratch_bytes(B, C, H, W)), dtype=torch.uint8, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)  # [ssim_mean, l1_mean]
+    _lib.check(L.mi355gs_ssim_forward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1), _lib.ptr(dm2),
+                                      _lib.ptr(dm3), _lib.ptr(scratch), _lib.ptr(out[0:1]), _lib.ptr(out[1:2])), "ssim_forward")
+    return a, b, dm1, dm2, dm3, out
+
+
+def _run_backward(a, b, dm1, dm2, dm3, ssim_scale, l1_scale):
+    L = _lib.lib()
+    dev = a.device
+    B, C, H, W = a.shape
+    grad = torch.empty_like(a)
+    _lib.check(L.mi355gs_ssim_backward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1), _lib.ptr(dm2),
+                                       _lib.ptr(dm3), _lib.ptr(ssim_scale), _lib.ptr(l1_scale), _lib.ptr(grad)), "ssim_backward")
+    return grad
+
+
+class _FusedSSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2, train):
+        a, b, dm1, dm2, dm3, out = _run_forward(img1, img2, train)
+        if train:
+            ctx.save_for_backward(a, b, dm1, dm2, dm3)
+        ctx.train = train
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.train:
+            raise RuntimeError("fused_ssim was called with train=False; no gradient is available")
+        a, b, dm1, dm2, dm3 = ctx.saved_tensors
+        scale = _lib.f32c(g.reshape(1))
+        return _run_backward(a, b, dm1, dm2, dm3, scale, None), None, None
+
+
+def fused_ssim(img1, img2, padding="same", train=True):
+    if padding != "same":
+        raise NotImplementedError('only padding="same" (the reference\'s use, train.py:173) is implemented')
+    return _FusedSSIM.apply(img1, img2, train)
+
+
+class _FusedL1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2, lambda_dssim):
+        a, b, dm1, dm2, dm3, out = _run_forward(img1, img2, True)
+        ctx.save_for_backward(a, b, dm1, dm2, dm3)
+        ctx.lam = float(lambda_dssim)
+        loss = (1.0 - ctx.lam) * out[1] + ctx.lam * (1.0 - out[0])
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, g, _):
+        a, b, dm1, dm2, dm3 = ctx.saved_tensors
+        g = _lib.f32c(g.reshape(1))
+        return _run_backward(a, b, dm1, dm2, dm3, (-ctx.lam) * g, (1.0 - ctx.lam) * g), None, None
+
+
+def fused_l1_ssim_loss(img1, img2, lambda_dssim=0.2):
+    """Returns (loss, [ssim_mean, l1_mean]); loss = (1-lambda)*L1 + lambda*(1-SSIM) as reference train.py:176."""
+    return _FusedL1SSIM.apply(img1, img2, lambda_dssim)

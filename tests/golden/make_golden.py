@@ -1,0 +1,114 @@
+"""Generates tests/golden/reference_vectors.npz by IMPORTING the reference's own pure-PyTorch helpers
+from /root/reference (possible only in the build container; the GPU box has no /root/reference, so the
+vectors are committed).  These pin the oracle / product restatements of every hot-path piece that
+exists in the reference tree as Python:
+
+  ssim(), l1_loss()            reference utils/loss_utils.py:39-85   (== fused_ssim's definition)
+  eval_sh(), RGB2SH            reference utils/sh_utils.py:57-117
+  build_covariance...          reference utils/general_utils.py:64-110 (+ scene/gaussian_model.py:32-36)
+  getProjectionMatrix          reference utils/graphics_utils.py:71-91
+  get_expon_lr_func            reference utils/general_utils.py:29-62
+  get_camera_from_tensor, quadmultiply, get_tensor_from_camera   reference utils/pose_utils.py:10-215
+  PerPointAdam.step            reference scene/per_point_adam.py:34-100
+  psnr                         reference utils/image_utils.py:17-19
+
+Run:  python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.npz")
+
+from utils import general_utils, graphics_utils, image_utils, loss_utils, pose_utils, sh_utils  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("ref_ppa", os.path.join(REF, "scene", "per_point_adam.py"))
+ppa = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ppa)
+
+g = torch.Generator().manual_seed(20260923)
+rn = lambda *s: torch.randn(*s, generator=g)
+ru = lambda *s: torch.rand(*s, generator=g)
+out = {}
+
+# ---- SSIM / L1 (value and gradient w.r.t. img1)
+for name, (H, W) in {"a": (40, 36), "b": (17, 53)}.items():
+    x = ru(1, 3, H, W).requires_grad_(True)
+    y = (x.detach() + 0.1 * rn(1, 3, H, W)).clamp(0, 1)
+    v = loss_utils.ssim(x, y)
+    v.backward()
+    out[f"ssim_{name}_x"], out[f"ssim_{name}_y"] = x.detach().numpy(), y.numpy()
+    out[f"ssim_{name}_val"], out[f"ssim_{name}_grad"] = v.detach().numpy(), x.grad.numpy().copy()
+    x.grad = None
+    l1 = loss_utils.l1_loss(x, y)
+    l1.backward()
+    out[f"l1_{name}_val"], out[f"l1_{name}_grad"] = l1.detach().numpy(), x.grad.numpy().copy()
+
+# ---- SH
+sh = rn(50, 3, 16)
+d = rn(50, 3)
+d = d / d.norm(dim=1, keepdim=True)
+out["sh_coeffs"], out["sh_dirs"] = sh.numpy(), d.numpy()
+for deg in range(4):
+    out[f"sh_eval_deg{deg}"] = sh_utils.eval_sh(deg, sh, d).numpy()
+out["rgb2sh"] = sh_utils.RGB2SH(torch.tensor([0.0, 0.25, 1.0])).numpy()
+
+# ---- covariance from scaling / rotation (the reference hard-codes device="cuda": strip it for the CPU)
+_zeros = torch.zeros
+torch.zeros = lambda *a, **k: _zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+try:
+    s = torch.exp(0.3 * rn(40, 3))
+    q = rn(40, 4)
+    L = general_utils.build_scaling_rotation(1.7 * s, q)
+    cov = general_utils.strip_symmetric(L @ L.transpose(1, 2))
+finally:
+    torch.zeros = _zeros
+out["cov_scales"], out["cov_rots"], out["cov_mod"], out["cov_packed"] = s.numpy(), q.numpy(), np.float32(1.7), cov.numpy()
+
+# ---- projection
+out["proj_args"] = np.array([0.01, 100.0, 1.1, 0.7])
+out["proj_matrix"] = graphics_utils.getProjectionMatrix(0.01, 100.0, 1.1, 0.7).numpy()
+
+# ---- LR schedule
+f = general_utils.get_expon_lr_func(lr_init=1.6e-4 * 3.0, lr_final=1.6e-6 * 3.0, lr_delay_mult=0.01, max_steps=30000)
+steps = np.array([0, 1, 10, 500, 1000, 29999, 30000, 40000])
+out["lr_steps"], out["lr_values"] = steps, np.array([f(int(t)) for t in steps])
+
+# ---- pose algebra
+pose = torch.cat([rn(4), rn(3)])
+out["pose7"] = pose.numpy()
+w2c = pose_utils.get_camera_from_tensor(pose)
+out["pose_w2c"] = w2c.numpy()
+out["pose_back"] = pose_utils.get_tensor_from_camera(w2c).numpy()
+q1, q2 = rn(4), rn(30, 4)
+out["qm_q1"], out["qm_q2"], out["qm_out"] = q1.numpy(), q2.numpy(), pose_utils.quadmultiply(q1, q2).numpy()
+
+# ---- PerPointAdam trajectory (xyz-like tensor with per-point multiplier, plus a plain tensor, plus a zero-grad step)
+p1 = rn(25, 3).requires_grad_(True)
+p2 = rn(25, 1, 3).requires_grad_(True)
+pplr = 1.0 + 99.0 * ru(25, 1)
+opt = ppa.PerPointAdam([{"params": [p1], "per_point_lr": pplr, "lr": 1.6e-4, "name": "xyz"},
+                        {"params": [p2], "lr": 2.5e-2, "name": "f_dc"}], lr=0, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.0)
+out["adam_p1_0"], out["adam_p2_0"], out["adam_pplr"] = p1.detach().numpy().copy(), p2.detach().numpy().copy(), pplr.numpy()
+grads1, grads2 = [], []
+for t in range(4):
+    g1 = rn(25, 3) if t != 2 else torch.zeros(25, 3)  # step 2: all-zero gradient -> moments frozen, update still applied
+    g2 = rn(25, 1, 3)
+    p1.grad, p2.grad = g1.clone(), g2.clone()
+    opt.step()
+    grads1.append(g1.numpy())
+    grads2.append(g2.numpy())
+    out[f"adam_p1_{t + 1}"], out[f"adam_p2_{t + 1}"] = p1.detach().numpy().copy(), p2.detach().numpy().copy()
+out["adam_g1"], out["adam_g2"] = np.stack(grads1), np.stack(grads2)
+
+# ---- psnr
+a, b = ru(3, 8, 9), ru(3, 8, 9)
+out["psnr_a"], out["psnr_b"], out["psnr_val"] = a.numpy(), b.numpy(), image_utils.psnr(a, b).numpy()
+
+np.savez_compressed(OUT, **out)
+print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(out), "arrays")

@@ -1,0 +1,37 @@
+"""GPU tier: SSIM / kNN / Adam kernels and the training loop through the C ABI on cuda:0."""
+import pytest
+import torch
+
+from tests import ops_util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ssim_matches_reference_golden(gpu):
+    ops_util.check_ssim_golden(gpu)
+
+
+@pytest.mark.parametrize("H,W", [(7, 5), (33, 17), (512, 512), (1080, 1920)])
+def test_ssim_sizes(gpu, H, W):
+    ops_util.check_ssim_random(gpu, H, W)
+
+
+@pytest.mark.parametrize("n,dup", [(1, False), (3, False), (300, False), (5000, True), (60000, False)])
+def test_knn_matches_kdtree(gpu, n, dup):
+    ops_util.check_knn(gpu, n, duplicates=dup)
+
+
+def test_adam_matches_reference_trajectory(gpu):
+    ops_util.check_adam_golden(gpu)
+
+
+def test_train_iterations_match_cpu_oracle(gpu):
+    ops_util.check_train_matches_cpu_oracle(gpu, iters=5, Wm=48, W=96)
+
+
+def test_training_improves_psnr(gpu):
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import training
+    r = training(syn_pointmap(3, 64, 64, 128, 128, seed=0), gpu, iterations=150)
+    assert r["last_loss"] < r["first_loss"]
+    assert r["psnr_after"] > r["psnr_before"] + 0.5
