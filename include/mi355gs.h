@@ -101,6 +101,20 @@ int mi355gs_raster_backward(
 int mi355gs_raster_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
                                 const float* projmatrix, uint8_t* present);
 
+/* Frame statistics for roofline accounting (bench.py): stats[0] = R, the number of (tile, Gaussian)
+ * instances of the last forward that used `tiles`; stats[1] = R_eff = sum over tiles of the largest
+ * per-pixel contributor count, i.e. the instances the composite kernels actually had to consume
+ * (SURVEY.md 8d).  stats: device int64[2]. */
+int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, int64_t* stats);
+
+/* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that
+ * cannot see the kernels (they are enqueued inside this library) can still attribute time to them.
+ * kind: 0 = composite forward, 1 = composite backward.  profile_read synchronises the recorded events
+ * and returns the summed milliseconds and launch count since profile_begin. */
+int mi355gs_profile_begin(void);
+int mi355gs_profile_read(int kind, double* total_ms, int* launches);
+int mi355gs_profile_end(void);
+
 /* ------------------------------------------------------------------------------------------------
  * fused SSIM (+ optional L1) loss
  * replaces: fused_ssim.fused_ssim(img1, img2) at reference train.py:173 (same value as the

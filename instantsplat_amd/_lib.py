@@ -32,6 +32,10 @@ _SIGNATURES = {
                                         _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                         c_int]),
     "mi355gs_raster_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
+    "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),
+    "mi355gs_profile_begin": (c_int, []),
+    "mi355gs_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    "mi355gs_profile_end": (c_int, []),
     "mi355gs_ssim_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mi355gs_ssim_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_ssim_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

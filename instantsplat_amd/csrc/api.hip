@@ -18,6 +18,35 @@ int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uin
 int gs_launch_composite_bwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*);
 
+int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
+
+// ---- optional per-kernel timing (HIP events on the launch stream)
+namespace {
+constexpr int PROF_KINDS = 2, PROF_MAX = 8192;
+struct ProfState {
+  bool on = false;
+  hipEvent_t ev[PROF_KINDS][PROF_MAX][2];
+  int created[PROF_KINDS] = {0, 0};
+  int used[PROF_KINDS] = {0, 0};
+} g_prof;
+struct ProfScope {
+  hipStream_t s; hipEvent_t stop; bool active = false;
+  ProfScope(int kind, hipStream_t stream) : s(stream) {
+    if (!g_prof.on || g_prof.used[kind] >= PROF_MAX) return;
+    const int i = g_prof.used[kind];
+    if (i >= g_prof.created[kind]) {
+      if (hipEventCreate(&g_prof.ev[kind][i][0]) != hipSuccess || hipEventCreate(&g_prof.ev[kind][i][1]) != hipSuccess) return;
+      g_prof.created[kind] = i + 1;
+    }
+    (void)hipEventRecord(g_prof.ev[kind][i][0], s);
+    stop = g_prof.ev[kind][i][1];
+    g_prof.used[kind] = i + 1;
+    active = true;
+  }
+  ~ProfScope() { if (active) (void)hipEventRecord(stop, s); }
+};
+}  // namespace
+
 void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
 
 static CamParams make_cam(const float* view, const float* proj, const float* campos, float tanfovx, float tanfovy,
@@ -100,8 +129,11 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
                     (const uint32_t*)(t + tl.start), (uint32_t*)(t + tl.cursor), (uint64_t*)(b + bl.keys),
                     (uint32_t*)(b + bl.list), cap);
   GS_CHECK_LAUNCH("binning");
-  gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
-                          (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib));
+  {
+    ProfScope prof(0, stream);
+    gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
+                            (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib));
+  }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;
 }
@@ -136,9 +168,12 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   GsGrad* grads = (GsGrad*)grad_scratch;
   if (hipMemsetAsync(grads, 0, (size_t)P * sizeof(GsGrad), stream) != hipSuccess) return MI355GS_ELAUNCH;
   if (cap > 0) {
-    gs_launch_composite_bwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
-                            (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
-                            dL_dpix, grads);
+    {
+      ProfScope prof(1, stream);
+      gs_launch_composite_bwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
+                              (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
+                              dL_dpix, grads);
+    }
     GS_CHECK_LAUNCH("composite_bwd");
   }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
@@ -146,6 +181,43 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                            (const float*)(g + gl.cov3D), (const uint8_t*)(g + gl.clamped), grads, dL_dmeans3D, dL_dmeans2D,
                            dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D);
   GS_CHECK_LAUNCH("preprocess_bwd");
+  return MI355GS_OK;
+}
+
+int mi355gs_raster_frame_stats(void* stream_, int W, int H, const void* tiles, int64_t* stats) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (W <= 0 || H <= 0 || !tiles || !stats) return MI355GS_EINVAL;
+  const TilesLayout tl(W, H);
+  const char* t = (const char*)tiles;
+  if (hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  gs_launch_frame_stats(stream, tl.T, tl.gx, W, H, (const uint32_t*)(t + tl.start), (const uint32_t*)(t + tl.n_contrib), stats);
+  GS_CHECK_LAUNCH("frame_stats");
+  return MI355GS_OK;
+}
+
+int mi355gs_profile_begin(void) {
+  g_prof.on = true;
+  g_prof.used[0] = g_prof.used[1] = 0;
+  return MI355GS_OK;
+}
+
+int mi355gs_profile_read(int kind, double* total_ms, int* launches) {
+  if (kind < 0 || kind >= PROF_KINDS || !total_ms || !launches) return MI355GS_EINVAL;
+  double tot = 0.0;
+  for (int i = 0; i < g_prof.used[kind]; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.ev[kind][i][1]) != hipSuccess) return MI355GS_ELAUNCH;
+    if (hipEventElapsedTime(&ms, g_prof.ev[kind][i][0], g_prof.ev[kind][i][1]) != hipSuccess) return MI355GS_ELAUNCH;
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = g_prof.used[kind];
+  return MI355GS_OK;
+}
+
+int mi355gs_profile_end(void) {
+  g_prof.on = false;
   return MI355GS_OK;
 }
 

@@ -245,7 +245,32 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
   }
 }
 
+// per-tile max of n_contrib -> R_eff (roofline accounting only)
+__global__ __launch_bounds__(256) void k_frame_stats(int T, int gx, int W, int H, const uint32_t* __restrict__ tile_start,
+                                                      const uint32_t* __restrict__ n_contrib, int64_t* __restrict__ stats) {
+  __shared__ uint32_t s_max[4];
+  const int tile = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Quad q = make_quad(tile, gx, W, H);
+  uint32_t v = q.inside ? n_contrib[(size_t)q.py * W + q.px] : 0u;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+  if (lane == 0) s_max[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    atomicAdd(reinterpret_cast<unsigned long long*>(stats + 1), (unsigned long long)m);
+    if (tile == 0) stats[0] = (int64_t)tile_start[T];
+  }
+}
+
 }  // namespace
+
+int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const uint32_t* tile_start, const uint32_t* n_contrib,
+                          int64_t* stats) {
+  hipLaunchKernelGGL(k_frame_stats, dim3(T), dim3(256), 0, stream, T, gx, W, H, tile_start, n_contrib, stats);
+  return 0;
+}
 
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,

@@ -30,20 +30,29 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-class BinningPolicy:
-    """How the instance buffer of a frame is sized.
+# Roofline accounting hook (bench.py): when enabled, the scratch of the most recent forward is kept
+# reachable so mi355gs_raster_frame_stats can be asked for its instance counts.
+_KEEP_LAST_FRAME = False
+_LAST_FRAME = {}
 
-    "exact"   : read the instance count back after the projection stage (one 4-byte D2H copy per
-                forward — what the reference operator does internally) and allocate exactly.
-    "bounded" : no host synchronisation.  Capacity = `slack` x the largest count observed so far for
-                this (P, W, H), learned from asynchronous pinned-memory read-backs of earlier
-                frames; the first frames of a configuration fall back to "exact".  If a frame
-                overflows its capacity the forward of that frame is transparently redone in exact
-                mode at the next point where the count is known (see _RasterizeGaussians.forward).
-    """
-    mode = "exact"
-    slack = 1.5
-    _seen: dict = {}
+
+def keep_last_frame(flag: bool):
+    global _KEEP_LAST_FRAME
+    _KEEP_LAST_FRAME = bool(flag)
+    if not flag:
+        _LAST_FRAME.clear()
+
+
+def last_frame_stats():
+    """(R, R_eff) of the most recent forward: instances binned / instances the composite kernels consumed."""
+    if not _LAST_FRAME:
+        raise RuntimeError("keep_last_frame(True) was not set before the forward")
+    tiles, W, H = _LAST_FRAME["tiles"], _LAST_FRAME["W"], _LAST_FRAME["H"]
+    stats = torch.zeros(2, dtype=torch.int64, device=tiles.device)
+    _lib.check(_lib.lib().mi355gs_raster_frame_stats(_lib.stream_ptr(tiles.device), W, H, _lib.ptr(tiles), _lib.ptr(stats)),
+               "raster_frame_stats")
+    r, reff = stats.tolist()
+    return int(r), int(reff)
 
 
 def _empty_bytes(n: int, device) -> torch.Tensor:
@@ -102,6 +111,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             R, binning = run()
 
+        if _KEEP_LAST_FRAME:
+            _LAST_FRAME.update(tiles=tiles, W=W, H=H)
         ctx.raster_settings = s
         ctx.num_rendered = R
         ctx.dims = (P, D, M, W, H)

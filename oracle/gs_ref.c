@@ -312,10 +312,11 @@ void SUF(gsref_backward)(void* c_, const real* means3D, const real* shs, const r
   int nthreads = 1;
 #ifdef _OPENMP
   nthreads = omp_get_max_threads();
+  if (nthreads > 16) nthreads = 16; /* per-thread accumulators: bound memory (16 x P x 9 reals) and the fixed-order reduction */
 #endif
   /* per-thread accumulators: [mean2D.x, mean2D.y, conic a, b(full), c, opacity, r, g, b] */
   real* acc = (real*)calloc((size_t)nthreads * Pn * 9, sizeof(real));
-#pragma omp parallel
+#pragma omp parallel num_threads(nthreads)
   {
     int tid = 0;
 #ifdef _OPENMP
@@ -500,6 +501,18 @@ void SUF(gsref_backward)(void* c_, const real* means3D, const real* shs, const r
   }
   free(acc);
 }
+
+#if !GSREF_DOUBLE
+/* thread count used by both precisions (bench.py's cpu_baseline reports it as `cores`) */
+int gsref_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n; return 1;
+#endif
+}
+#endif
 
 /* introspection for tests */
 void SUF(gsref_get_aux)(void* c_, real* final_T, int32_t* n_contrib, int64_t* tile_start, int32_t* list) {
