@@ -154,6 +154,32 @@ int mi355gs_adam_step(void* stream, int64_t n, int row, float* param, const floa
                       float* exp_avg_sq, const float* per_point_lr, const float* grad_sumsq,
                       float lr, float beta1, float beta2, float eps, int step);
 
+/* All parameter tensors of one optimizer step in two launches (<= 8 tensors per call).  The arrays are
+ * HOST arrays of length ntensors holding device pointers / per-tensor scalars; per_point_lr[t] may be null;
+ * step[t] is the 1-based step count of tensor t; scratch: device float[8].  The whole-tensor gradient gate
+ * of the reference (per_point_adam.py:62-69) is evaluated on the device from the summed squares. */
+int mi355gs_adam_multi_step(void* stream, int ntensors, const int64_t* numel, const int32_t* row, float* const* params,
+                            const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                            const float* const* per_point_lr, const float* lr, float beta1, float beta2, float eps,
+                            const int32_t* step, float* scratch);
+
+/* ------------------------------------------------------------------------------------------------
+ * InstantSplat camera-frame transform fused with the Gaussian activations
+ * replaces: the PyTorch ops of reference gaussian_renderer/__init__.py:81-103 —
+ *   rel_w2c = get_camera_from_tensor(pose) (utils/pose_utils.py:57-84, quaternion normalised),
+ *   means_cam = rel_w2c @ [xyz,1], rot_cam = quadmultiply(pose[:4], rotation) (raw quaternions),
+ *   opacity = sigmoid(_opacity), scales = exp(_scaling) (scene/gaussian_model.py:101-124) — and their
+ *   autograd backward, including the reduction over all Gaussians to dL/dpose[7].
+ *   pose[7] = (qw,qx,qy,qz,tx,ty,tz) on the device; scratch16: device float[16].
+ * ---------------------------------------------------------------------------------------------- */
+int mi355gs_pose_forward(void* stream, int P, const float* xyz, const float* rot, const float* scaling,
+                         const float* opacity_logit, const float* pose, float* means_cam, float* rot_cam, float* scales,
+                         float* opac);
+int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* rot, const float* scales, const float* opac,
+                          const float* pose, const float* g_means, const float* g_rot, const float* g_scales,
+                          const float* g_opac, float* d_xyz, float* d_rot, float* d_scaling, float* d_opacity_logit,
+                          float* d_pose, float* scratch16);
+
 #ifdef __cplusplus
 }
 #endif

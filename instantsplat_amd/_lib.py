@@ -42,6 +42,9 @@ _SIGNATURES = {
     "mi355gs_knn_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_knn_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "mi355gs_adam_step": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int]),
+    "mi355gs_adam_multi_step": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P]),
+    "mi355gs_pose_forward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi355gs_pose_backward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -34,6 +34,117 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, int row, float* __restr
 
 }  // namespace
 
+// ---- multi-tensor variant: all parameter groups of one optimizer step in two launches
+// (sum of squared gradients per tensor for the reference's whole-tensor gate, then the update).
+namespace {
+
+constexpr int MT_MAX = 8;
+constexpr int MT_CHUNK = 4096;  // elements per workgroup
+
+struct MultiAdamArgs {
+  int n;
+  int first_block[MT_MAX + 1];  // workgroup index ranges per tensor
+  long long numel[MT_MAX];
+  int row[MT_MAX];
+  float* param[MT_MAX];
+  const float* grad[MT_MAX];
+  float* m[MT_MAX];
+  float* v[MT_MAX];
+  const float* pplr[MT_MAX];
+  float step_size[MT_MAX];
+};
+
+__device__ __forceinline__ int mt_find(const MultiAdamArgs& a, int b) {
+  int t = 0;
+#pragma unroll
+  for (int k = 1; k < MT_MAX; ++k) t += (k < a.n && b >= a.first_block[k]) ? 1 : 0;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_adam_sumsq(MultiAdamArgs a, float* __restrict__ sumsq) {
+  __shared__ float s_red[4];
+  const int t = mt_find(a, blockIdx.x);
+  const long long lo = (long long)(blockIdx.x - a.first_block[t]) * MT_CHUNK;
+  const long long hi = min(a.numel[t], lo + MT_CHUNK);
+  const float* g = a.grad[t];
+  float acc = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) { const float x = g[i]; acc += x * x; }
+  acc = gs_wave_sum_row3(acc);
+  if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (tot > 0.f) atomicAdd(&sumsq[t], tot);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float* __restrict__ sumsq, float beta1, float beta2,
+                                                     float eps) {
+  const int t = mt_find(a, blockIdx.x);
+  const long long lo = (long long)(blockIdx.x - a.first_block[t]) * MT_CHUNK;
+  const long long hi = min(a.numel[t], lo + MT_CHUNK);
+  const bool update = sumsq[t] > 0.f;
+  float* __restrict__ p = a.param[t];
+  const float* __restrict__ g = a.grad[t];
+  float* __restrict__ mm = a.m[t];
+  float* __restrict__ vv = a.v[t];
+  const float* __restrict__ pplr = a.pplr[t];
+  const int row = a.row[t];
+  const float step_size = a.step_size[t];
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    float m = mm[i], v = vv[i];
+    if (update) {
+      const float gi = g[i];
+      m = m * beta1 + gi * (1.f - beta1);
+      v = v * beta2 + gi * gi * (1.f - beta2);
+      mm[i] = m;
+      vv[i] = v;
+    }
+    const float denom = sqrtf(v) + eps;
+    const float s = pplr ? step_size * pplr[i / row] : step_size;
+    p[i] = p[i] - s * (m / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_t* numel, const int32_t* row, float* const* params,
+                                       const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                       const float* const* per_point_lr, const float* lr, float beta1, float beta2, float eps,
+                                       const int32_t* step, float* scratch) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (ntensors < 0 || ntensors > MT_MAX || !scratch) return MI355GS_EINVAL;
+  if (ntensors == 0) return MI355GS_OK;
+  if (!numel || !row || !params || !grads || !exp_avg || !exp_avg_sq || !per_point_lr || !lr || !step) return MI355GS_EINVAL;
+  MultiAdamArgs a;
+  a.n = ntensors;
+  int blocks = 0;
+  for (int t = 0; t < MT_MAX; ++t) {
+    a.first_block[t] = blocks;
+    if (t < ntensors) {
+      if (numel[t] < 0 || row[t] <= 0 || step[t] <= 0 || (numel[t] > 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t])))
+        return MI355GS_EINVAL;
+      a.numel[t] = numel[t]; a.row[t] = row[t];
+      a.param[t] = params[t]; a.grad[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.pplr[t] = per_point_lr[t];
+      const double bc1 = 1.0 - pow((double)beta1, (double)step[t]), bc2 = 1.0 - pow((double)beta2, (double)step[t]);
+      a.step_size[t] = (float)((double)lr[t] * (sqrt(bc2) / bc1));
+      blocks += (int)((numel[t] + MT_CHUNK - 1) / MT_CHUNK);
+    } else {
+      a.numel[t] = 0; a.row[t] = 1; a.param[t] = nullptr; a.grad[t] = nullptr; a.m[t] = nullptr; a.v[t] = nullptr; a.pplr[t] = nullptr;
+      a.step_size[t] = 0.f;
+    }
+  }
+  a.first_block[MT_MAX] = blocks;
+  if (blocks == 0) return MI355GS_OK;
+  if (hipMemsetAsync(scratch, 0, MT_MAX * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  hipLaunchKernelGGL(k_adam_sumsq, dim3(blocks), dim3(256), 0, stream, a, scratch);
+  GS_CHECK_LAUNCH("adam_sumsq");
+  hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, stream, a, (const float*)scratch, beta1, beta2, eps);
+  GS_CHECK_LAUNCH("adam_multi");
+  return MI355GS_OK;
+}
+
 extern "C" int mi355gs_adam_step(void* stream_, int64_t n, int row, float* param, const float* grad, float* exp_avg,
                                  float* exp_avg_sq, const float* per_point_lr, const float* grad_sumsq, float lr, float beta1,
                                  float beta2, float eps, int step) {

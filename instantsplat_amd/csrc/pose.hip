@@ -1,0 +1,179 @@
+// InstantSplat's camera-frame transform, fused with the Gaussian activations.
+//
+// replaces, per render call, the ~60 eager PyTorch kernels of reference
+// gaussian_renderer/__init__.py:81-103 (get_camera_from_tensor -> [R|t], xyz_cam = R xyz + t,
+// rot_cam = pose_quat (x) rotation, opacity = sigmoid, scales = exp; helpers at
+// utils/pose_utils.py:10-104, scene/gaussian_model.py:101-124) and, in backward, their autograd
+// graph plus the P-long reduction to the 7 pose gradients — one launch each way.
+// Semantics kept: the pose quaternion is NORMALISED for the rotation of the means but used RAW in
+// the Hamilton product with the (raw) Gaussian quaternions.
+// HBM-bound: 44 B read + 44 B written per Gaussian forward; 88 B read + 44 B written backward.
+#include "common.h"
+
+namespace {
+
+struct PoseMat {
+  float R[9];   // rotation from the normalised quaternion, row-major
+  float t[3];
+  float q[4];   // raw pose quaternion (w,x,y,z)
+  float qn[4];  // normalised
+  float inv_norm;
+};
+
+__device__ __forceinline__ PoseMat load_pose(const float* __restrict__ pose) {
+  PoseMat m;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m.q[k] = pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) m.t[k] = pose[4 + k];
+  const float n = sqrtf(m.q[0] * m.q[0] + m.q[1] * m.q[1] + m.q[2] * m.q[2] + m.q[3] * m.q[3]);
+  m.inv_norm = 1.0f / n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m.qn[k] = m.q[k] / n;
+  const float r = m.qn[0], x = m.qn[1], y = m.qn[2], z = m.qn[3];
+  m.R[0] = 1.f - 2.f * (y * y + z * z); m.R[1] = 2.f * (x * y - r * z); m.R[2] = 2.f * (x * z + r * y);
+  m.R[3] = 2.f * (x * y + r * z); m.R[4] = 1.f - 2.f * (x * x + z * z); m.R[5] = 2.f * (y * z - r * x);
+  m.R[6] = 2.f * (x * z - r * y); m.R[7] = 2.f * (y * z + r * x); m.R[8] = 1.f - 2.f * (x * x + y * y);
+  return m;
+}
+
+__global__ __launch_bounds__(256) void k_pose_fwd(int P, const float* __restrict__ xyz, const float* __restrict__ rot,
+                                                   const float* __restrict__ scaling, const float* __restrict__ opacity_logit,
+                                                   const float* __restrict__ pose, float* __restrict__ means_cam,
+                                                   float* __restrict__ rot_cam, float* __restrict__ scales, float* __restrict__ opac) {
+  const PoseMat m = load_pose(pose);
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    means_cam[3 * (size_t)i] = m.R[0] * x + m.R[1] * y + m.R[2] * z + m.t[0];
+    means_cam[3 * (size_t)i + 1] = m.R[3] * x + m.R[4] * y + m.R[5] * z + m.t[1];
+    means_cam[3 * (size_t)i + 2] = m.R[6] * x + m.R[7] * y + m.R[8] * z + m.t[2];
+    const float4 g = *reinterpret_cast<const float4*>(rot + 4 * (size_t)i);  // (w2,x2,y2,z2)
+    const float w1 = m.q[0], x1 = m.q[1], y1 = m.q[2], z1 = m.q[3];
+    float4 o;
+    o.x = w1 * g.x - x1 * g.y - y1 * g.z - z1 * g.w;
+    o.y = w1 * g.y + x1 * g.x + y1 * g.w - z1 * g.z;
+    o.z = w1 * g.z - x1 * g.w + y1 * g.x + z1 * g.y;
+    o.w = w1 * g.w + x1 * g.z - y1 * g.y + z1 * g.x;
+    *reinterpret_cast<float4*>(rot_cam + 4 * (size_t)i) = o;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) scales[3 * (size_t)i + k] = expf(scaling[3 * (size_t)i + k]);
+    opac[i] = 1.0f / (1.0f + expf(-opacity_logit[i]));
+  }
+}
+
+// acc[0..2] = dL/dt, acc[3..11] = dL/dR (row-major, sum of g_m (x) xyz), acc[12..15] = dL/dq_raw via the Hamilton product
+__global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict__ xyz, const float* __restrict__ rot,
+                                                   const float* __restrict__ scales, const float* __restrict__ opac,
+                                                   const float* __restrict__ pose, const float* __restrict__ g_means,
+                                                   const float* __restrict__ g_rot, const float* __restrict__ g_scales,
+                                                   const float* __restrict__ g_opac, float* __restrict__ d_xyz,
+                                                   float* __restrict__ d_rot, float* __restrict__ d_scaling,
+                                                   float* __restrict__ d_opacity_logit, float* __restrict__ acc) {
+  __shared__ float s_red[4][16];
+  const PoseMat m = load_pose(pose);
+  float a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = 0.f;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    const float gx = g_means[3 * (size_t)i], gy = g_means[3 * (size_t)i + 1], gz = g_means[3 * (size_t)i + 2];
+    d_xyz[3 * (size_t)i] = m.R[0] * gx + m.R[3] * gy + m.R[6] * gz;
+    d_xyz[3 * (size_t)i + 1] = m.R[1] * gx + m.R[4] * gy + m.R[7] * gz;
+    d_xyz[3 * (size_t)i + 2] = m.R[2] * gx + m.R[5] * gy + m.R[8] * gz;
+    a[0] += gx; a[1] += gy; a[2] += gz;
+    a[3] += gx * x; a[4] += gx * y; a[5] += gx * z;
+    a[6] += gy * x; a[7] += gy * y; a[8] += gy * z;
+    a[9] += gz * x; a[10] += gz * y; a[11] += gz * z;
+    const float4 q2 = *reinterpret_cast<const float4*>(rot + 4 * (size_t)i);
+    const float4 gr = *reinterpret_cast<const float4*>(g_rot + 4 * (size_t)i);  // grads of (rw, rx, ry, rz)
+    const float w1 = m.q[0], x1 = m.q[1], y1 = m.q[2], z1 = m.q[3];
+    float4 d2;
+    d2.x = w1 * gr.x + x1 * gr.y + y1 * gr.z + z1 * gr.w;
+    d2.y = -x1 * gr.x + w1 * gr.y - z1 * gr.z + y1 * gr.w;
+    d2.z = -y1 * gr.x + z1 * gr.y + w1 * gr.z - x1 * gr.w;
+    d2.w = -z1 * gr.x - y1 * gr.y + x1 * gr.z + w1 * gr.w;
+    *reinterpret_cast<float4*>(d_rot + 4 * (size_t)i) = d2;
+    a[12] += q2.x * gr.x + q2.y * gr.y + q2.z * gr.z + q2.w * gr.w;
+    a[13] += -q2.y * gr.x + q2.x * gr.y + q2.w * gr.z - q2.z * gr.w;
+    a[14] += -q2.z * gr.x - q2.w * gr.y + q2.x * gr.z + q2.y * gr.w;
+    a[15] += -q2.w * gr.x + q2.z * gr.y - q2.y * gr.z + q2.x * gr.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d_scaling[3 * (size_t)i + k] = g_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
+    const float o = opac[i];
+    d_opacity_logit[i] = g_opac[i] * o * (1.f - o);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float v = gs_wave_sum_row3(a[k]);
+    if (lane == 63) s_red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int k = threadIdx.x;
+    atomicAdd(&acc[k], (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]));
+  }
+}
+
+__global__ void k_pose_finish(const float* __restrict__ pose, const float* __restrict__ acc, float* __restrict__ d_pose) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const PoseMat m = load_pose(pose);
+  const float* Rp = acc + 3;  // dL/dR, row-major: Rp[3*i+j]
+  const float r = m.qn[0], x = m.qn[1], y = m.qn[2], z = m.qn[3];
+  float gq[4];
+  gq[0] = 2.f * (z * (Rp[3] - Rp[1]) + y * (Rp[2] - Rp[6]) + x * (Rp[7] - Rp[5]));
+  gq[1] = 2.f * (y * (Rp[1] + Rp[3]) + z * (Rp[2] + Rp[6]) + r * (Rp[7] - Rp[5])) - 4.f * x * (Rp[4] + Rp[8]);
+  gq[2] = 2.f * (x * (Rp[1] + Rp[3]) + r * (Rp[2] - Rp[6]) + z * (Rp[5] + Rp[7])) - 4.f * y * (Rp[0] + Rp[8]);
+  gq[3] = 2.f * (r * (Rp[3] - Rp[1]) + x * (Rp[2] + Rp[6]) + y * (Rp[5] + Rp[7])) - 4.f * z * (Rp[0] + Rp[4]);
+  // through q_hat = q / |q|
+  const float dot = m.qn[0] * gq[0] + m.qn[1] * gq[1] + m.qn[2] * gq[2] + m.qn[3] * gq[3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d_pose[k] = (gq[k] - m.qn[k] * dot) * m.inv_norm + acc[12 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d_pose[4 + k] = acc[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355gs_pose_forward(void* stream_, int P, const float* xyz, const float* rot, const float* scaling,
+                         const float* opacity_logit, const float* pose, float* means_cam, float* rot_cam, float* scales,
+                         float* opac) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (P < 0 || !pose) return MI355GS_EINVAL;
+  if (P == 0) return MI355GS_OK;
+  if (!xyz || !rot || !scaling || !opacity_logit || !means_cam || !rot_cam || !scales || !opac) return MI355GS_EINVAL;
+  const int blocks = min((P + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_pose_fwd, dim3(blocks), dim3(256), 0, stream, P, xyz, rot, scaling, opacity_logit, pose, means_cam, rot_cam,
+                     scales, opac);
+  GS_CHECK_LAUNCH("pose_fwd");
+  return MI355GS_OK;
+}
+
+int mi355gs_pose_backward(void* stream_, int P, const float* xyz, const float* rot, const float* scales, const float* opac,
+                          const float* pose, const float* g_means, const float* g_rot, const float* g_scales,
+                          const float* g_opac, float* d_xyz, float* d_rot, float* d_scaling, float* d_opacity_logit,
+                          float* d_pose, float* scratch16) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (P < 0 || !pose || !d_pose || !scratch16) return MI355GS_EINVAL;
+  if (hipMemsetAsync(scratch16, 0, 16 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if (P > 0) {
+    if (!xyz || !rot || !scales || !opac || !g_means || !g_rot || !g_scales || !g_opac || !d_xyz || !d_rot || !d_scaling ||
+        !d_opacity_logit)
+      return MI355GS_EINVAL;
+    const int blocks = min((P + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_pose_bwd, dim3(blocks), dim3(256), 0, stream, P, xyz, rot, scales, opac, pose, g_means, g_rot, g_scales,
+                       g_opac, d_xyz, d_rot, d_scaling, d_opacity_logit, scratch16);
+    GS_CHECK_LAUNCH("pose_bwd");
+  }
+  hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, (const float*)scratch16, d_pose);
+  GS_CHECK_LAUNCH("pose_finish");
+  return MI355GS_OK;
+}
+
+}  // extern "C"

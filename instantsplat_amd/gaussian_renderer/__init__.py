@@ -12,8 +12,13 @@ import math
 import torch
 
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from ..fused import pose_activations, sh_features
 from ..pose_utils import get_camera_from_tensor, quadmultiply
 from ..sh_utils import eval_sh
+
+
+# False = always take the op-by-op PyTorch glue below (kept for A/B tests against the fused path)
+FUSED_GLUE = True
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, camera_pose=None):
@@ -36,11 +41,19 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         projmatrix=projmatrix, sh_degree=pc.active_sh_degree, campos=camera_pos, prefiltered=False, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
+    means2D = screenspace_points
+    fused = (not pipe.compute_cov3D_python) and (not pipe.convert_SHs_python) and override_color is None and FUSED_GLUE
+    if fused:
+        # one HIP launch each way for the pose transform + activations (and the pose-gradient reduction)
+        means3D, rot_cam, scales_act, opacity = pose_activations(pc._xyz, pc._rotation, pc._scaling, pc._opacity, camera_pose)
+        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=sh_features(pc), colors_precomp=None,
+                                           opacities=opacity, scales=scales_act, rotations=rot_cam, cov3D_precomp=None)
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
     rel_w2c = get_camera_from_tensor(camera_pose)
     xyz = pc._xyz
     means3D = xyz @ rel_w2c[:3, :3].t() + rel_w2c[:3, 3]
     rot_cam = quadmultiply(camera_pose[:4], pc._rotation)
-    means2D = screenspace_points
     opacity = pc.get_opacity
 
     scales = rotations = cov3D_precomp = None

@@ -10,6 +10,7 @@ Semantics kept on purpose:
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import torch
@@ -44,8 +45,11 @@ class PerPointAdam(Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        """All parameter tensors in two launches (mi355gs_adam_multi_step): per-tensor sum of squared gradients
+        for the whole-tensor gate, then the fused update."""
         loss = closure() if closure is not None else None
         L = _lib.lib()
+        items = []
         for group in self.param_groups:
             per_point_lr = group.get("per_point_lr")
             beta1, beta2 = group["betas"]
@@ -64,9 +68,7 @@ class PerPointAdam(Optimizer):
                 if group["weight_decay"] != 0:
                     grad = grad.add(p, alpha=group["weight_decay"])
                 grad = _lib.f32c(grad)
-                dev = _lib.require_device(p, grad, state["exp_avg"], state["exp_avg_sq"])
-                pplr = None
-                row = 1
+                pplr, row = None, 1
                 if per_point_lr is not None:
                     if not isinstance(per_point_lr, torch.Tensor):
                         raise TypeError("per_point_lr must be a torch.Tensor")
@@ -77,9 +79,21 @@ class PerPointAdam(Optimizer):
                         raise ValueError(f"Invalid per_point_lr shape. Expected {expected_shape}, got {per_point_lr.shape}")
                     pplr = _lib.f32c(per_point_lr)
                     row = p.numel() // p.shape[0]
-                sumsq = (grad * grad).sum().reshape(1)  # device scalar: the reference's whole-tensor gate
-                _lib.check(L.mi355gs_adam_step(_lib.stream_ptr(dev), p.numel(), row, _lib.ptr(p), _lib.ptr(grad),
-                                               _lib.ptr(state["exp_avg"]), _lib.ptr(state["exp_avg_sq"]), _lib.ptr(pplr),
-                                               _lib.ptr(sumsq), float(group["lr"]), float(beta1), float(beta2),
-                                               float(group["eps"]), int(state["step"])), "adam_step")
+                items.append((p, grad, state, pplr, row, float(group["lr"]), float(beta1), float(beta2), float(group["eps"])))
+        # one call per (betas, eps) combination, at most 8 tensors each
+        while items:
+            b1, b2, eps = items[0][6:9]
+            batch = [it for it in items if it[6:9] == (b1, b2, eps)][:8]
+            items = [it for it in items if not any(it is b for b in batch)]
+            n = len(batch)
+            dev = _lib.require_device(*[t for it in batch for t in (it[0], it[1], it[2]["exp_avg"], it[2]["exp_avg_sq"], it[3])])
+            I64, I32, PTR, F32 = ctypes.c_int64 * n, ctypes.c_int32 * n, ctypes.c_void_p * n, ctypes.c_float * n
+            addr = lambda t: 0 if t is None else t.data_ptr()
+            scratch = torch.empty(8, dtype=torch.float32, device=dev)
+            _lib.check(L.mi355gs_adam_multi_step(
+                _lib.stream_ptr(dev), n, I64(*[it[0].numel() for it in batch]), I32(*[it[4] for it in batch]),
+                PTR(*[addr(it[0]) for it in batch]), PTR(*[addr(it[1]) for it in batch]),
+                PTR(*[addr(it[2]["exp_avg"]) for it in batch]), PTR(*[addr(it[2]["exp_avg_sq"]) for it in batch]),
+                PTR(*[addr(it[3]) for it in batch]), F32(*[it[5] for it in batch]), b1, b2, eps,
+                I32(*[it[2]["step"] for it in batch]), _lib.ptr(scratch)), "adam_multi_step")
         return loss

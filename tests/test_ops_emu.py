@@ -25,6 +25,14 @@ def test_knn_matches_kdtree(emu, n, dup):
     ops_util.check_knn(emu, n, duplicates=dup)
 
 
+def test_pose_activations_match_autograd(emu):
+    ops_util.check_pose_activations(emu)
+
+
+def test_fused_render_equals_unfused(emu):
+    ops_util.check_fused_render_equals_unfused(emu)
+
+
 def test_adam_matches_reference_trajectory(emu):
     ops_util.check_adam_golden(emu)
 

@@ -21,6 +21,14 @@ def test_knn_matches_kdtree(gpu, n, dup):
     ops_util.check_knn(gpu, n, duplicates=dup)
 
 
+def test_pose_activations_match_autograd(gpu):
+    ops_util.check_pose_activations(gpu)
+
+
+def test_fused_render_equals_unfused(gpu):
+    ops_util.check_fused_render_equals_unfused(gpu)
+
+
 def test_adam_matches_reference_trajectory(gpu):
     ops_util.check_adam_golden(gpu)
 
