@@ -91,14 +91,14 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
     const float w1 = m.q[0], x1 = m.q[1], y1 = m.q[2], z1 = m.q[3];
     float4 d2;
     d2.x = w1 * gr.x + x1 * gr.y + y1 * gr.z + z1 * gr.w;
-    d2.y = -x1 * gr.x + w1 * gr.y - z1 * gr.z + y1 * gr.w;
-    d2.z = -y1 * gr.x + z1 * gr.y + w1 * gr.z - x1 * gr.w;
-    d2.w = -z1 * gr.x - y1 * gr.y + x1 * gr.z + w1 * gr.w;
+    d2.y = -x1 * gr.x + w1 * gr.y + z1 * gr.z - y1 * gr.w;
+    d2.z = -y1 * gr.x - z1 * gr.y + w1 * gr.z + x1 * gr.w;
+    d2.w = -z1 * gr.x + y1 * gr.y - x1 * gr.z + w1 * gr.w;
     *reinterpret_cast<float4*>(d_rot + 4 * (size_t)i) = d2;
     a[12] += q2.x * gr.x + q2.y * gr.y + q2.z * gr.z + q2.w * gr.w;
-    a[13] += -q2.y * gr.x + q2.x * gr.y + q2.w * gr.z - q2.z * gr.w;
-    a[14] += -q2.z * gr.x - q2.w * gr.y + q2.x * gr.z + q2.y * gr.w;
-    a[15] += -q2.w * gr.x + q2.z * gr.y - q2.y * gr.z + q2.x * gr.w;
+    a[13] += -q2.y * gr.x + q2.x * gr.y - q2.w * gr.z + q2.z * gr.w;
+    a[14] += -q2.z * gr.x + q2.w * gr.y + q2.x * gr.z - q2.y * gr.w;
+    a[15] += -q2.w * gr.x - q2.z * gr.y + q2.y * gr.z + q2.x * gr.w;
 #pragma unroll
     for (int k = 0; k < 3; ++k) d_scaling[3 * (size_t)i + k] = g_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
     const float o = opac[i];
