@@ -1,0 +1,60 @@
+"""Scene-per-GPU launcher.
+
+The reference's "multi-GPU" is a bash loop that polls nvidia-smi and starts one OS process per scene
+(reference scripts/run_infer.sh:22-27,104-117); there is no communication on the train path.  Here:
+one rank per GPU (torchrun / torch.distributed.run), rank i trains scene i, and ONE all_reduce
+(RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests) combines the final metrics.
+The message is 40 bytes, so the collective is latency-bound and link bandwidth is irrelevant.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m instantsplat_amd.launch --iterations 1000
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def reduce_scene_metrics(psnr: float, n_images: int, iterations: int, seconds: float, device) -> dict:
+    """SUM-reduce [psnr*n_images, n_images, iterations, 1] and MAX-reduce [seconds] over all ranks."""
+    s = torch.tensor([psnr * n_images, float(n_images), float(iterations), 1.0], dtype=torch.float64, device=device)
+    mx = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    s, mx = s.cpu(), mx.cpu()
+    return dict(scenes=int(s[3]), mean_psnr=float(s[0] / s[1]), iterations=int(s[2]), max_seconds=float(mx[0]),
+                aggregate_iters_per_sec=float(s[2] / mx[0]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=1000)
+    ap.add_argument("--pointmap", type=int, default=256)
+    ap.add_argument("--res", type=int, default=512)
+    args = ap.parse_args()
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from .synthetic import syn_pointmap
+    from .train import training
+    scene = syn_pointmap(3, args.pointmap, args.pointmap, args.res, args.res, seed=rank)  # scene i -> rank i
+    if world > 1:
+        dist.barrier()
+    r = training(scene, dev, iterations=args.iterations)
+    m = reduce_scene_metrics(r["psnr_after"], len(scene.cameras), args.iterations, r["seconds"], dev)
+    if rank == 0:
+        print(json.dumps(m))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
