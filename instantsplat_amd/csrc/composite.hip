@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
   const uint32_t tile_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
   if (tile_max == 0) return;
 
+  const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
+  const int r16 = lane & 15;
   float Tr = T_final;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
 
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
           const bool valid = contributor <= last && power <= 0.0f && alpha >= ALPHA_MIN;
           if (__any(valid)) {
             const float one_m = 1.f - alpha;
-            Tr = valid ? Tr / one_m : Tr;
+            const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // v_rcp_f32 (1 ulp) instead of two IEEE divisions
+            Tr = valid ? Tr * inv_one_m : Tr;
             const float dchannel = valid ? alpha * Tr : 0.f;
             const float na0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
             const float na1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
@@ -213,30 +216,36 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
             acc0 = valid ? na0 : acc0; acc1 = valid ? na1 : acc1; acc2 = valid ? na2 : acc2;
             lc0 = valid ? a2.x : lc0; lc1 = valid ? a2.y : lc1; lc2 = valid ? a2.z : lc2;
             float dL_dalpha = (a2.x - acc0) * g0 + (a2.y - acc1) * g1 + (a2.z - acc2) * g2;
-            dL_dalpha = dL_dalpha * Tr + (-T_final / one_m) * bg_dot;
+            dL_dalpha = dL_dalpha * Tr - T_final * inv_one_m * bg_dot;
             dL_dalpha = valid ? dL_dalpha : 0.f;
             last_alpha = valid ? alpha : last_alpha;
             const float dL_dG = a1.w * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
             const float dG_ddelx = -gdx * a1.x - gdy * a1.y;
             const float dG_ddely = -gdy * a1.z - gdx * a1.y;
-            // 9 x 6 DPP adds; totals land in lanes 48..63, of which 48..56 each own one component
-            const float v_mx = gs_wave_sum_row3(dL_dG * dG_ddelx * ddelx_dx);
-            const float v_my = gs_wave_sum_row3(dL_dG * dG_ddely * ddely_dy);
-            const float v_ca = gs_wave_sum_row3(-0.5f * gdx * dx * dL_dG);
-            const float v_cb = gs_wave_sum_row3(-gdx * dy * dL_dG);
-            const float v_cc = gs_wave_sum_row3(-0.5f * gdy * dy * dL_dG);
-            const float v_op = gs_wave_sum_row3(G * dL_dalpha);
-            const float v_r = gs_wave_sum_row3(dchannel * g0);
-            const float v_g = gs_wave_sum_row3(dchannel * g1);
-            const float v_b = gs_wave_sum_row3(dchannel * g2);
-            float* dst = reinterpret_cast<float*>(grads + id);
-            const int c = lane - 48;
-            float mine = v_mx;
-            mine = c == 1 ? v_my : mine; mine = c == 2 ? v_ca : mine; mine = c == 3 ? v_cb : mine;
-            mine = c == 4 ? v_cc : mine; mine = c == 5 ? v_op : mine; mine = c == 6 ? v_r : mine;
-            mine = c == 7 ? v_g : mine; mine = c == 8 ? v_b : mine;
-            if (c >= 0 && c < 9) atomicAdd(dst + c, mine);
+            // nine terms -> one per lane: component c of this Gaussian ends up in lanes with (lane & 15) == c
+            const float t0 = dL_dG * dG_ddelx * ddelx_dx;   // dL/dmean2D.x
+            const float t1 = dL_dG * dG_ddely * ddely_dy;   // dL/dmean2D.y
+            const float t2 = -0.5f * gdx * dx * dL_dG;      // dL/dconic a
+            const float t3 = -gdx * dy * dL_dG;             // dL/dconic b
+            const float t4 = -0.5f * gdy * dy * dL_dG;      // dL/dconic c
+            const float t5 = G * dL_dalpha;                 // dL/dopacity
+            const float t6 = dchannel * g0, t7 = dchannel * g1, t8 = dchannel * g2;  // dL/drgb
+            // lanes differing in bit 0 (quad_perm [1,0,3,2]) then bit 1 (quad_perm [2,3,0,1])
+            const float w0 = gs_pair_reduce<0xB1>(bit0, t0, t1), w1 = gs_pair_reduce<0xB1>(bit0, t2, t3);
+            const float w2 = gs_pair_reduce<0xB1>(bit0, t4, t5), w3 = gs_pair_reduce<0xB1>(bit0, t6, t7);
+            const float w4 = t8 + gs_dpp<0xB1>(t8);
+            float x0 = gs_pair_reduce<0x4E>(bit1, w0, w1);  // component 2*bit1 + bit0, summed over the quad
+            float x1 = gs_pair_reduce<0x4E>(bit1, w2, w3);  // component 4 + 2*bit1 + bit0
+            float x2 = w4 + gs_dpp<0x4E>(w4);               // component 8
+            // the four quads of each 16-lane row (row_ror:4, row_ror:8 keep the low two lane bits)
+            x0 += gs_dpp<0x124>(x0); x1 += gs_dpp<0x124>(x1); x2 += gs_dpp<0x124>(x2);
+            x0 += gs_dpp<0x128>(x0); x1 += gs_dpp<0x128>(x1); x2 += gs_dpp<0x128>(x2);
+            float mine = r16 < 4 ? x0 : (r16 < 8 ? x1 : x2);
+            // the four rows
+            mine += __shfl_xor(mine, 16);
+            mine += __shfl_xor(mine, 32);
+            if (lane < 9) atomicAdd(reinterpret_cast<float*>(grads + id) + lane, mine);
           }
           if (!more) break;
         }
