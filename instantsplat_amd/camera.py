@@ -52,3 +52,11 @@ class Camera:
         self.full_proj_transform = self.world_view_transform @ self.projection_matrix
         self.camera_center = torch.linalg.inv(self.world_view_transform)[3, :3]
         self.original_image = None if image is None else image.clamp(0.0, 1.0).to(device)
+
+    def to(self, device):
+        """Move the per-view constants to `device` (the reference keeps them on the GPU: scene/cameras.py:54-57)."""
+        for name in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center", "original_image"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t.to(device))
+        return self

@@ -55,6 +55,63 @@ def last_frame_stats():
     return int(r), int(reff)
 
 
+class BinningPolicy:
+    """How a frame's instance buffer is sized.
+
+    mode "exact" (default): read the instance count R back after the projection stage — one blocking 4-byte
+        D2H copy per forward, exactly what the reference operator does internally — and allocate exactly.
+    mode "bounded": no host synchronisation.  For a frame rendered under `binning_hint(key)` whose key has a
+        known count, capacity = slack * R_known + pad; R of the new frame is copied to pinned memory
+        asynchronously and examined later by `poll()`, which refreshes R_known and reports every frame whose R
+        exceeded its capacity (those frames dropped instances and everything computed from them is invalid —
+        instantsplat_amd.train rolls back to its last verified snapshot and replays them in exact mode).
+        Frames without a hint, or with an unknown key, use the exact path.
+    """
+    mode = "exact"
+    slack = 1.5
+    pad = 16384
+    known = {}       # key -> last verified R
+    pending = []     # (event, pinned int32[1], capacity, key, tag)
+    current_key = None
+    current_tag = None
+
+    @classmethod
+    def reset(cls, mode="exact"):
+        cls.mode, cls.known, cls.pending, cls.current_key, cls.current_tag = mode, {}, [], None, None
+
+    @classmethod
+    def poll(cls, block: bool = False):
+        """Process finished read-backs; returns the tags of frames that overflowed their capacity."""
+        bad, keep = [], []
+        for ev, pinned, cap, key, tag in cls.pending:
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((ev, pinned, cap, key, tag))
+                continue
+            r = int(pinned[0])
+            cls.known[key] = r
+            if r > cap:
+                bad.append(tag)
+        cls.pending = keep
+        return bad
+
+
+class binning_hint:
+    """with binning_hint(key, tag): frames rendered inside may reuse the instance count last seen for `key`
+    (e.g. the camera uid) when BinningPolicy.mode == "bounded"; `tag` (e.g. the iteration) labels overflow reports."""
+
+    def __init__(self, key, tag=None):
+        self.key, self.tag = key, tag
+
+    def __enter__(self):
+        self.prev = (BinningPolicy.current_key, BinningPolicy.current_tag)
+        BinningPolicy.current_key, BinningPolicy.current_tag = self.key, self.tag
+
+    def __exit__(self, *a):
+        BinningPolicy.current_key, BinningPolicy.current_tag = self.prev
+
+
 def _empty_bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
 
@@ -95,7 +152,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                 float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos),
                 float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _lib.ptr(radii), _lib.ptr(geom),
                 _lib.ptr(tiles), _lib.ptr(num_rendered), debug), "raster_forward_preprocess")
-            R = int(num_rendered.item())  # the reference operator's own blocking read-back
+            key = BinningPolicy.current_key
+            if BinningPolicy.mode == "bounded" and key is not None and key in BinningPolicy.known and dev.type == "cuda":
+                R = int(BinningPolicy.slack * BinningPolicy.known[key]) + BinningPolicy.pad  # capacity, no host sync
+                pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                pinned.copy_(num_rendered, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                BinningPolicy.pending.append((ev, pinned, R, key, BinningPolicy.current_tag))
+            else:
+                R = int(num_rendered.item())  # the reference operator's own blocking read-back
+                if key is not None:
+                    BinningPolicy.known[key] = R
             binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R), dev)
             _lib.check(L.mi355gs_raster_forward_render(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
                                                        _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render")

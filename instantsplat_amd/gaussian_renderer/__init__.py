@@ -17,6 +17,15 @@ from ..pose_utils import get_camera_from_tensor, quadmultiply
 from ..sh_utils import eval_sh
 
 
+_IDENTITY = {}
+
+
+def _identity_view(dev):
+    if dev not in _IDENTITY:
+        _IDENTITY[dev] = (torch.eye(4, device=dev), torch.zeros(3, device=dev))
+    return _IDENTITY[dev]
+
+
 # False = always take the op-by-op PyTorch glue below (kept for A/B tests against the fused path)
 FUSED_GLUE = True
 
@@ -32,9 +41,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
 
-    w2c = torch.eye(4, device=dev)
-    projmatrix = w2c @ viewpoint_camera.projection_matrix.to(dev)
-    camera_pos = torch.zeros(3, device=dev)  # inverse(identity)[3, :3]
+    w2c, camera_pos = _identity_view(dev)  # identity view matrix, camera at the origin (reference :55-59)
+    projmatrix = viewpoint_camera.projection_matrix  # identity @ projection
+    if projmatrix.device != dev:
+        projmatrix = projmatrix.to(dev)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=w2c,

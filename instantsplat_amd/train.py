@@ -16,6 +16,7 @@ import torch
 
 from .arguments import ModelParams, OptimizationParams, PipelineParams
 from .fused_ssim import fused_l1_ssim_loss, fused_ssim
+from .diff_gaussian_rasterization import BinningPolicy, binning_hint
 from .gaussian_renderer import render
 from .pose_utils import get_tensor_from_camera, quadmultiply
 from .scene import GaussianModel, confidence_to_lr_modifiers
@@ -81,11 +82,13 @@ def setup_training(scene: PointmapScene, device, opt: OptimizationParams | None 
         student.training_setup_pp(opt, conf_lr)
     else:
         student.training_setup(opt)
-    return TrainState(student, list(scene.cameras), gts, bg, opt, pipe)
+    import copy
+    cams = [copy.copy(c).to(dev) for c in scene.cameras]  # per-view constants live on the device, as in the reference
+    return TrainState(student, cams, gts, bg, opt, pipe)
 
 
-def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = True):
-    """One pass of reference train.py:140-211. Returns the loss (python float if sync_loss)."""
+def _forward_backward_step(st: TrainState, fused_loss: bool):
+    """Body of reference train.py:140-211 without the host read-back of the loss."""
     st.iteration += 1
     it, g, opt = st.iteration, st.gaussians, st.opt
     g.update_learning_rate(it)
@@ -98,7 +101,8 @@ def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = T
     cam = st.viewpoint_stack.pop(st.rng.randint(0, len(st.viewpoint_stack) - 1))
     pose = g.get_RT(cam.uid)
     bg = torch.rand(3, device=st.background.device) if opt.random_background else st.background
-    pkg = render(cam, g, st.pipe, bg, camera_pose=pose)
+    with binning_hint(("train", cam.uid), tag=it):
+        pkg = render(cam, g, st.pipe, bg, camera_pose=pose)
     image = pkg["render"]
     gt = st.gt_images[cam.uid]
     if fused_loss:
@@ -107,13 +111,112 @@ def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = T
         Ll1 = l1_loss(image, gt)
         loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - fused_ssim(image.unsqueeze(0), gt.unsqueeze(0)))
     loss.backward()
-    out = loss.item() if sync_loss else loss.detach()
+    return loss.detach()
+
+
+def _optimizer_step(st: TrainState):
     with torch.no_grad():
-        if it < opt.iterations:
-            g.optimizer.step()
-            g.optimizer.zero_grad(set_to_none=True)
+        if st.iteration < st.opt.iterations:
+            st.gaussians.optimizer.step()
+            st.gaussians.optimizer.zero_grad(set_to_none=True)
+
+
+def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = True):
+    """One pass of reference train.py:140-211, with the reference's per-iteration `loss.item()` (sync_loss=True)."""
+    loss = _forward_backward_step(st, fused_loss)
+    out = loss.item() if sync_loss else loss
+    _optimizer_step(st)
     st.last_loss = out
     return out
+
+
+# ---- run-ahead variant: same arithmetic, no host synchronisation inside the iteration ------------------------
+class RunAhead:
+    """Drives `train_iteration` without per-iteration host syncs and with results identical to the synchronous loop.
+
+    * The reference reads `loss.item()` every iteration only to maintain an EMA it displays every 10 iterations
+      (train.py:188-191).  Here each loss is written to a device ring buffer and the EMA is evaluated from it when
+      the window is read back (same values, one D2H copy per `window` iterations).
+    * The rasterizer's instance buffers are sized from the last verified count of the same view ("bounded"
+      BinningPolicy).  At each window boundary all counts of the window are verified; if any frame overflowed, the
+      parameters, optimizer state, RNG and view stack are restored from the snapshot taken at the previous boundary
+      and the window is replayed with exact sizing — so an overflow costs time, never correctness.
+    """
+
+    def __init__(self, st: TrainState, window: int = 10, fused_loss: bool = True):
+        self.st, self.window, self.fused = st, window, fused_loss
+        dev = st.background.device
+        self.ring = torch.zeros(window, dtype=torch.float32, device=dev)
+        self.ema = 0.0
+        self.n_in_window = 0
+        self.replays = 0
+        BinningPolicy.reset("bounded")
+        self._snapshot()
+
+    def _tensors(self):
+        g = self.st.gaussians
+        return [g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation, g.P]
+
+    def _snapshot(self):
+        st, g = self.st, self.st.gaussians
+        opt_state = []
+        for p in self._tensors():
+            s = g.optimizer.state.get(p, {})
+            opt_state.append(None if not s else (s["step"], s["exp_avg"].clone(), s["exp_avg_sq"].clone()))
+        self.snap = dict(params=[p.detach().clone() for p in self._tensors()], opt=opt_state, iteration=st.iteration,
+                         stack=list(st.viewpoint_stack), rng=st.rng.getstate(), sh=g.active_sh_degree, ema=self.ema,
+                         lrs=[grp["lr"] for grp in g.optimizer.param_groups])
+
+    def _restore(self):
+        st, g, sn = self.st, self.st.gaussians, self.snap
+        with torch.no_grad():
+            for p, v, o in zip(self._tensors(), sn["params"], sn["opt"]):
+                p.copy_(v)
+                p.grad = None
+                if o is None:
+                    g.optimizer.state.pop(p, None)
+                else:
+                    s = g.optimizer.state[p]
+                    s["step"] = o[0]
+                    s["exp_avg"].copy_(o[1])
+                    s["exp_avg_sq"].copy_(o[2])
+        st.iteration, st.viewpoint_stack, g.active_sh_degree, self.ema = sn["iteration"], list(sn["stack"]), sn["sh"], sn["ema"]
+        st.rng.setstate(sn["rng"])
+        for grp, lr in zip(g.optimizer.param_groups, sn["lrs"]):
+            grp["lr"] = lr
+
+    def step(self):
+        """One training iteration; returns the EMA loss at window boundaries (like the reference's progress bar), else None."""
+        loss = _forward_backward_step(self.st, self.fused)
+        self.ring[self.n_in_window] = loss
+        _optimizer_step(self.st)
+        self.n_in_window += 1
+        if self.n_in_window == self.window:
+            return self.flush()
+        return None
+
+    def flush(self):
+        """Verify the window (replaying it with exact sizing if a frame overflowed), fold its losses into the EMA."""
+        n = self.n_in_window
+        if n == 0:
+            return self.ema
+        losses = self.ring[:n].tolist()           # the only blocking read-back of the window
+        if BinningPolicy.poll(block=True):
+            self.replays += 1
+            self._restore()
+            BinningPolicy.mode = "exact"
+            losses = []
+            for _ in range(n):
+                l = _forward_backward_step(self.st, self.fused)
+                losses.append(float(l.item()))
+                _optimizer_step(self.st)
+            BinningPolicy.mode = "bounded"
+        for l in losses:
+            self.ema = 0.4 * l + 0.6 * self.ema   # reference train.py:188
+        self.st.last_loss = losses[-1]
+        self.n_in_window = 0
+        self._snapshot()
+        return self.ema
 
 
 @torch.no_grad()
@@ -125,20 +228,37 @@ def evaluate_psnr(st: TrainState) -> float:
     return float(torch.stack(vals).mean())
 
 
-def training(scene: PointmapScene, device, iterations: int = 1000, log_every: int = 0, **kw) -> dict:
+def training(scene: PointmapScene, device, iterations: int = 1000, log_every: int = 0, run_ahead: bool = True,
+             fused_loss: bool = True) -> dict:
+    """Train one scene. run_ahead=True uses the sync-free driver (identical results, see RunAhead);
+    run_ahead=False reproduces the reference's per-iteration host read-backs."""
     opt = OptimizationParams(iterations=iterations, pp_optimizer=True, optim_pose=True)
     st = setup_training(scene, device, opt=opt)
     psnr0 = evaluate_psnr(st)
-    if torch.device(device).type == "cuda":
+    is_cuda = torch.device(device).type == "cuda"
+    if is_cuda:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    losses = []
-    for i in range(iterations):
-        losses.append(train_iteration(st, **kw))
-        if log_every and (i + 1) % log_every == 0:
-            print(f"[iter {i + 1}] loss {losses[-1]:.6f}")
-    if torch.device(device).type == "cuda":
+    first = last = None
+    if run_ahead:
+        ra = RunAhead(st, fused_loss=fused_loss)
+        for i in range(iterations):
+            ema = ra.step()
+            if first is None and ema is not None:
+                first = st.last_loss
+            if log_every and ema is not None and (i + 1) % log_every == 0:
+                print(f"[iter {i + 1}] ema loss {ema:.6f}")
+        ra.flush()
+        last = st.last_loss
+        BinningPolicy.reset("exact")
+    else:
+        for i in range(iterations):
+            last = train_iteration(st, fused_loss=fused_loss)
+            first = last if first is None else first
+            if log_every and (i + 1) % log_every == 0:
+                print(f"[iter {i + 1}] loss {last:.6f}")
+    if is_cuda:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dict(seconds=dt, iters_per_sec=iterations / dt, first_loss=losses[0], last_loss=losses[-1], psnr_before=psnr0,
+    return dict(seconds=dt, iters_per_sec=iterations / dt, first_loss=first, last_loss=last, psnr_before=psnr0,
                 psnr_after=evaluate_psnr(st), state=st)

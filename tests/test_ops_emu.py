@@ -33,6 +33,10 @@ def test_fused_render_equals_unfused(emu):
     ops_util.check_fused_render_equals_unfused(emu)
 
 
+def test_run_ahead_equals_sync_loop(emu):
+    ops_util.check_run_ahead_equals_sync_loop(emu, iters=7)
+
+
 def test_adam_matches_reference_trajectory(emu):
     ops_util.check_adam_golden(emu)
 

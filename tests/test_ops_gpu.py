@@ -29,6 +29,14 @@ def test_fused_render_equals_unfused(gpu):
     ops_util.check_fused_render_equals_unfused(gpu)
 
 
+def test_run_ahead_equals_sync_loop(gpu):
+    ops_util.check_run_ahead_equals_sync_loop(gpu, iters=23)
+
+
+def test_run_ahead_overflow_is_replayed_exactly(gpu):
+    ops_util.check_run_ahead_equals_sync_loop(gpu, iters=23, force_overflow=True)
+
+
 def test_adam_matches_reference_trajectory(gpu):
     ops_util.check_adam_golden(gpu)
 
