@@ -84,7 +84,9 @@ class BinningPolicy:
         """Process finished read-backs; returns the tags of frames that overflowed their capacity."""
         bad, keep = [], []
         for ev, pinned, cap, key, tag in cls.pending:
-            if block:
+            if ev is None:
+                pass
+            elif block:
                 ev.synchronize()
             elif not ev.query():
                 keep.append((ev, pinned, cap, key, tag))
@@ -153,12 +155,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _lib.ptr(radii), _lib.ptr(geom),
                 _lib.ptr(tiles), _lib.ptr(num_rendered), debug), "raster_forward_preprocess")
             key = BinningPolicy.current_key
-            if BinningPolicy.mode == "bounded" and key is not None and key in BinningPolicy.known and dev.type == "cuda":
+            if BinningPolicy.mode == "bounded" and key is not None and key in BinningPolicy.known:
                 R = int(BinningPolicy.slack * BinningPolicy.known[key]) + BinningPolicy.pad  # capacity, no host sync
-                pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                pinned.copy_(num_rendered, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
+                if dev.type == "cuda":
+                    pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    pinned.copy_(num_rendered, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                else:  # emulated kernels on CPU tensors (tests): the count is already there
+                    pinned, ev = num_rendered, None
                 BinningPolicy.pending.append((ev, pinned, R, key, BinningPolicy.current_tag))
             else:
                 R = int(num_rendered.item())  # the reference operator's own blocking read-back

@@ -34,7 +34,11 @@ def test_fused_render_equals_unfused(emu):
 
 
 def test_run_ahead_equals_sync_loop(emu):
-    ops_util.check_run_ahead_equals_sync_loop(emu, iters=7)
+    ops_util.check_run_ahead_equals_sync_loop(emu, iters=7, Wm=12, W=32)
+
+
+def test_run_ahead_overflow_is_replayed_exactly(emu):
+    ops_util.check_run_ahead_equals_sync_loop(emu, iters=7, force_overflow=True, Wm=12, W=32)
 
 
 def test_adam_matches_reference_trajectory(emu):
