@@ -112,3 +112,24 @@ out["psnr_a"], out["psnr_b"], out["psnr_val"] = a.numpy(), b.numpy(), image_util
 
 np.savez_compressed(OUT, **out)
 print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(out), "arrays")
+
+# ---- COLMAP text readers (reference scene/colmap_loader.py, loaded by path: scene/__init__ needs plyfile)
+spec2 = importlib.util.spec_from_file_location("ref_colmap", os.path.join(REF, "scene", "colmap_loader.py"))
+cl = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(cl)
+HERE = os.path.dirname(os.path.abspath(__file__))
+cams = cl.read_intrinsics_text(os.path.join(HERE, "colmap_cameras.txt"))
+imgs = cl.read_extrinsics_text(os.path.join(HERE, "colmap_images.txt"))
+ids = sorted(cams)
+out2 = dict(np.load(OUT))
+out2["colmap_cam_ids"] = np.array(ids)
+out2["colmap_cam_wh"] = np.array([[cams[i].width, cams[i].height] for i in ids])
+out2["colmap_cam_params"] = np.stack([cams[i].params for i in ids])
+iid = sorted(imgs)
+out2["colmap_img_ids"] = np.array(iid)
+out2["colmap_img_qvec"] = np.stack([imgs[i].qvec for i in iid])
+out2["colmap_img_tvec"] = np.stack([imgs[i].tvec for i in iid])
+out2["colmap_img_camid"] = np.array([imgs[i].camera_id for i in iid])
+out2["colmap_img_R"] = np.stack([cl.qvec2rotmat(imgs[i].qvec) for i in iid])
+np.savez_compressed(OUT, **out2)
+print("added COLMAP vectors:", len(out2), "arrays")

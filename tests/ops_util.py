@@ -225,3 +225,27 @@ def check_run_ahead_equals_sync_loop(dev, iters=23, force_overflow=False, Wm=20,
     finally:
         BinningPolicy.slack, BinningPolicy.pad = 1.5, 16384
         BinningPolicy.reset("exact")
+
+
+def check_pose_tracking(dev, num_iter, Wm=16, W=40, min_gain=0.0):
+    """render_set_optimize (reference render.py:99-170): Gaussians frozen, a perturbed view pose is pulled back
+    towards the pose that explains the image (masked L1)."""
+    from instantsplat_amd.pose_tracking import measure_fps, render_set_optimize
+    from instantsplat_amd.pose_utils import get_tensor_from_camera
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=11)
+    st = setup_training(sc, dev)
+    g = st.gaussians
+    view = st.cameras[1]
+    view.original_image = st.gt_images[1]
+    true_pose = get_tensor_from_camera(view.world_view_transform.transpose(0, 1).cpu())
+    init = true_pose.clone()
+    init[4:] += torch.tensor([0.03, -0.02, 0.04])
+    res = render_set_optimize([view], g, st.pipe, st.background, num_iter=num_iter, init_poses=[init])[0]
+    assert all(not t.requires_grad for t in (g._xyz, g._features_dc, g._opacity))
+    assert res["best_loss"] <= res["initial_loss"] * (1.0 - min_gain), (res["initial_loss"], res["best_loss"])
+    assert res["render"].shape == (3, W, W)
+    fps = measure_fps(view, g, st.pipe, st.background, res["pose"], frames=5)
+    assert fps["fps"] > 0
+    return res

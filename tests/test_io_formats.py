@@ -1,0 +1,69 @@
+"""CPU tier: on-disk formats. COLMAP text parsing is checked against vectors produced by the
+reference's own loader (tests/golden/make_golden.py); PLY and pose files by round trip + header layout."""
+import os
+
+import numpy as np
+import torch
+
+from instantsplat_amd import io_formats as io
+
+HERE = os.path.dirname(__file__)
+G = np.load(os.path.join(HERE, "golden", "reference_vectors.npz"))
+
+
+def test_colmap_text_matches_reference_loader(tmp_path):
+    cams = io.read_cameras_text(os.path.join(HERE, "golden", "colmap_cameras.txt"))
+    imgs = io.read_images_text(os.path.join(HERE, "golden", "colmap_images.txt"))
+    ids = sorted(cams)
+    assert ids == list(G["colmap_cam_ids"])
+    assert np.array_equal(np.array([[cams[i].width, cams[i].height] for i in ids]), G["colmap_cam_wh"])
+    assert np.allclose(np.stack([cams[i].params for i in ids]), G["colmap_cam_params"], rtol=0, atol=0)
+    iid = sorted(imgs)
+    assert iid == list(G["colmap_img_ids"])
+    assert np.array_equal(np.stack([imgs[i].qvec for i in iid]), G["colmap_img_qvec"])
+    assert np.array_equal(np.stack([imgs[i].tvec for i in iid]), G["colmap_img_tvec"])
+    assert np.array_equal(np.array([imgs[i].camera_id for i in iid]), G["colmap_img_camid"])
+    assert np.allclose(np.stack([io.qvec2rotmat(imgs[i].qvec) for i in iid]), G["colmap_img_R"], atol=1e-15)
+    # writer -> reader round trip
+    io.write_cameras_text(tmp_path / "c.txt", cams)
+    io.write_images_text(tmp_path / "i.txt", imgs)
+    cams2, imgs2 = io.read_cameras_text(tmp_path / "c.txt"), io.read_images_text(tmp_path / "i.txt")
+    assert all(np.array_equal(cams[i].params, cams2[i].params) for i in ids)
+    assert all(np.array_equal(imgs[i].qvec, imgs2[i].qvec) and imgs[i].name == imgs2[i].name for i in iid)
+    fx, fy = io.camera_fovs(cams[1])
+    assert abs(fx - 2 * np.arctan(1280 / (2 * 1108.5125))) < 1e-12
+
+
+def test_point_cloud_ply_round_trip(tmp_path):
+    g = torch.Generator().manual_seed(0)
+    xyz, rgb = torch.randn(100, 3, generator=g), torch.randint(0, 256, (100, 3), generator=g).float() / 255.0
+    io.write_point_cloud_ply(tmp_path / "points3D.ply", xyz, rgb)
+    xyz2, rgb2 = io.read_point_cloud_ply(tmp_path / "points3D.ply")
+    assert torch.equal(xyz, xyz2) and torch.allclose(rgb, rgb2, atol=1e-7)
+    hdr = open(tmp_path / "points3D.ply", "rb").read(400).decode("ascii", "replace")
+    assert "property float nx" in hdr and "property uchar red" in hdr and "element vertex 100" in hdr
+
+
+def test_gaussian_ply_layout_and_round_trip(tmp_path):
+    class GM:
+        pass
+    g = torch.Generator().manual_seed(1)
+    m = GM()
+    m._xyz, m._features_dc, m._features_rest = torch.randn(50, 3, generator=g), torch.randn(50, 1, 3, generator=g), torch.randn(50, 15, 3, generator=g)
+    m._opacity, m._scaling, m._rotation = torch.randn(50, 1, generator=g), torch.randn(50, 3, generator=g), torch.randn(50, 4, generator=g)
+    io.save_gaussian_ply(tmp_path / "point_cloud.ply", m)
+    v = io.read_ply_vertices(tmp_path / "point_cloud.ply")
+    # attribute order of reference scene/gaussian_model.py:247-260
+    assert list(v.dtype.names) == io.gaussian_ply_attributes() and len(v.dtype.names) == 62
+    # f_rest is stored channel-major (transpose(1,2) before flatten, reference :267)
+    assert np.allclose(v["f_rest_0"], m._features_rest[:, 0, 0].numpy()) and np.allclose(v["f_rest_15"], m._features_rest[:, 0, 1].numpy())
+    d = io.load_gaussian_ply(tmp_path / "point_cloud.ply")
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(d[k], getattr(m, k)), k
+
+
+def test_save_pose_orders_by_colmap_id(tmp_path):
+    poses = torch.tensor([[1.0, 0, 0, 0, 1, 2, 3], [0.0, 1, 0, 0, 4, 5, 6]])
+    io.save_pose(tmp_path / "pose_optimized.npy", poses, colmap_ids=[2, 1])
+    a = np.load(tmp_path / "pose_optimized.npy")
+    assert a.shape == (2, 4, 4) and np.allclose(a[0, :3, 3], [4, 5, 6]) and np.allclose(a[1, :3, 3], [1, 2, 3])

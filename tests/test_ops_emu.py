@@ -41,6 +41,10 @@ def test_run_ahead_overflow_is_replayed_exactly(emu):
     ops_util.check_run_ahead_equals_sync_loop(emu, iters=7, force_overflow=True, Wm=12, W=32)
 
 
+def test_pose_tracking_reduces_masked_l1(emu):
+    ops_util.check_pose_tracking(emu, num_iter=3, min_gain=0.0)
+
+
 def test_adam_matches_reference_trajectory(emu):
     ops_util.check_adam_golden(emu)
 

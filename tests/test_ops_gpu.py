@@ -37,6 +37,10 @@ def test_run_ahead_overflow_is_replayed_exactly(gpu):
     ops_util.check_run_ahead_equals_sync_loop(gpu, iters=23, force_overflow=True)
 
 
+def test_pose_tracking_reduces_masked_l1(gpu):
+    ops_util.check_pose_tracking(gpu, num_iter=120, min_gain=0.3, Wm=64, W=128)
+
+
 def test_adam_matches_reference_trajectory(gpu):
     ops_util.check_adam_golden(gpu)
 
