@@ -180,6 +180,28 @@ int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* ro
                           const float* g_opac, float* d_xyz, float* d_rot, float* d_scaling, float* d_opacity_logit,
                           float* d_pose, float* scratch16);
 
+/* ------------------------------------------------------------------------------------------------
+ * Whole train iteration in one call
+ * replaces: the body of the loop at reference train.py:140-211 — render(camera_pose=P[view]) -> (1-l)*L1 +
+ *   l*(1-SSIM) -> backward -> PerPointAdam.step() — for the configuration the reference's scripts run: SH degree 0
+ *   (first 1000 iterations), scale/rotation covariance, --pp_optimizer --optim_pose.  17 launches, no host sync.
+ *   Parameter tensors use the reference's GaussianModel layouts (scene/gaussian_model.py:166-171): xyz[P,3],
+ *   f_dc[P,1,3], f_rest[P,15,3], opacity[P,1], scaling[P,3], rotation[P,4], poses[V,7]; exp_avg/exp_avg_sq: host
+ *   arrays of 7 device pointers in the optimizer's group order (xyz, f_dc, f_rest, opacity, scaling, rotation, pose).
+ *   workspace: mi355gs_trainer_workspace_bytes() bytes, owned by the caller, must outlive the handle.
+ *   capacity: instance capacity of the binning buffers; *num_rendered (device) receives the true count of every
+ *   step — a step with num_rendered > capacity dropped instances and must be discarded by the caller.
+ *   lr[7], step[7] (1-based Adam step of each group): host arrays.  loss_out: device float[1].
+ * ---------------------------------------------------------------------------------------------- */
+size_t mi355gs_trainer_workspace_bytes(int P, int W, int H, int V, int64_t capacity);
+void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float* xyz, float* f_dc, float* f_rest, float* opacity,
+                             float* scaling, float* rotation, float* poses, float* const* exp_avg, float* const* exp_avg_sq,
+                             const float* per_point_lr, void* workspace);
+int mi355gs_trainer_step(void* trainer, void* stream, int view, const float* gt_image, const float* projmatrix, float tanfovx,
+                         float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
+                         float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out);
+void mi355gs_trainer_destroy(void* trainer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __r
 
 // deterministic final reduction of the per-block partial sums (double accumulation)
 __global__ __launch_bounds__(1024) void k_ssim_finish(int nblocks, double inv_n, const float* __restrict__ partial,
-                                                       float* __restrict__ ssim_mean, float* __restrict__ l1_mean) {
+                                                       float* __restrict__ ssim_mean, float* __restrict__ l1_mean,
+                                                       float* __restrict__ loss, float lambda_dssim) {
   __shared__ double s_a[16], s_b[16];
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 1024) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
@@ -107,15 +108,18 @@ __global__ __launch_bounds__(1024) void k_ssim_finish(int nblocks, double inv_n,
   if (threadIdx.x == 0) {
     double ta = 0.0, tb = 0.0;
     for (int w = 0; w < 16; ++w) { ta += s_a[w]; tb += s_b[w]; }
-    if (ssim_mean) *ssim_mean = (float)(ta * inv_n);
-    if (l1_mean) *l1_mean = (float)(tb * inv_n);
+    const float sm = (float)(ta * inv_n), lm = (float)(tb * inv_n);
+    if (ssim_mean) *ssim_mean = sm;
+    if (l1_mean) *l1_mean = lm;
+    if (loss) *loss = (1.0f - lambda_dssim) * lm + lambda_dssim * (1.0f - sm);  // reference train.py:176
   }
 }
 
 __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, const float* __restrict__ img1, const float* __restrict__ img2,
                                                    const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
                                                    const float* __restrict__ dm_dsigma12, const float* __restrict__ ssim_scale,
-                                                   const float* __restrict__ l1_scale, float* __restrict__ dL_dimg1) {
+                                                   const float* __restrict__ l1_scale, float ssim_scale_host, float l1_scale_host,
+                                                   float* __restrict__ dL_dimg1) {
   __shared__ float s_a[TH][TH + 1];
   __shared__ float s_b[TH][TH + 1];
   __shared__ float s_c[TH][TH + 1];
@@ -124,8 +128,9 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
   const int plane = blockIdx.z;
   const int ox = blockIdx.x * TS, oy = blockIdx.y * TS;
   const size_t po = (size_t)plane * H * W;
-  const float ks = ssim_scale ? *ssim_scale * inv_n : 0.f;
-  const float kl = l1_scale ? *l1_scale * inv_n : 0.f;
+  // scale = (device scalar, if given) x (host scalar)
+  const float ks = (ssim_scale ? *ssim_scale : 1.f) * ssim_scale_host * inv_n;
+  const float kl = (l1_scale ? *l1_scale : 1.f) * l1_scale_host * inv_n;
   if (ks != 0.f) {
     for (int i = tid; i < TH * TH; i += 256) {
       const int r = i / TH, c = i - r * TH;
@@ -193,7 +198,8 @@ int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float*
   hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch);
   GS_CHECK_LAUNCH("ssim_fwd");
   const double inv_n = 1.0 / ((double)B * C * H * W);
-  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean, l1_mean);
+  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
+                     l1_mean, (float*)nullptr, 0.f);
   GS_CHECK_LAUNCH("ssim_finish");
   return MI355GS_OK;
 }
@@ -209,9 +215,34 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
   const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
   const float inv_n = (float)(1.0 / ((double)B * C * H * W));
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
-                     ssim_grad_scale, l1_grad_scale, dL_dimg1);
+                     ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1);
   GS_CHECK_LAUNCH("ssim_bwd");
   return MI355GS_OK;
 }
 
 }  // extern "C"
+
+// internal entry for the fused train step: loss = (1-l)*L1 + l*(1-SSIM) forward, its gradient backward (d loss = 1)
+int gs_loss_forward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, float* dm1, float* dm2, float* dm3,
+                    void* scratch, float lambda_dssim, float* loss) {
+  const int debug = 0;
+  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
+  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm1, dm2, dm3, (float*)scratch);
+  GS_CHECK_LAUNCH("ssim_fwd");
+  const double inv_n = 1.0 / ((double)C * H * W);
+  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(1, C, H, W), inv_n, (const float*)scratch,
+                     (float*)nullptr, (float*)nullptr, loss, lambda_dssim);
+  GS_CHECK_LAUNCH("ssim_finish");
+  return MI355GS_OK;
+}
+
+int gs_loss_backward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, const float* dm1,
+                     const float* dm2, const float* dm3, float lambda_dssim, float* dL_dimg1) {
+  const int debug = 0;
+  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
+  const float inv_n = (float)(1.0 / ((double)C * H * W));
+  hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm1, dm2, dm3, (const float*)nullptr,
+                     (const float*)nullptr, -lambda_dssim, 1.0f - lambda_dssim, dL_dimg1);
+  GS_CHECK_LAUNCH("ssim_bwd");
+  return MI355GS_OK;
+}

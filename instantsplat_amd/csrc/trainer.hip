@@ -1,0 +1,168 @@
+// One full InstantSplat train iteration behind ONE library call (whole-iteration enqueue once
+// the host read-backs are gone).  Body of reference train.py:140-211 for the configuration the reference's
+// scripts run (SH degree 0 during the first 1000 iterations, --pp_optimizer --optim_pose, scale/rotation
+// covariance, SH colours):
+//
+//   pose transform + activations -> projection -> tile binning -> composite
+//   -> (1-l)*L1 + l*(1-SSIM) -> SSIM/L1 backward -> composite backward -> projection backward
+//   -> pose/activation backward (incl. the 7 pose gradients) -> PerPointAdam over all 7 parameter groups
+//
+// 17 kernel launches, no host synchronisation, no temporary allocation: every buffer lives in one caller-provided
+// workspace that the trainer carves up once.  The same kernels (and launch helpers) as the op-by-op path are used,
+// so results are identical up to the order of float atomics.  The instance buffers have a fixed capacity; the
+// true count is written to *num_rendered every step so the caller can verify it asynchronously.
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+int gs_loss_forward(hipStream_t, int, int, int, const float*, const float*, float*, float*, float*, void*, float, float*);
+int gs_loss_backward(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, float, float*);
+
+namespace {
+
+struct Trainer {
+  int P, W, H, V;
+  int64_t capacity;
+  // parameters, optimizer state (caller-owned)
+  float *xyz, *f_dc, *f_rest, *opacity, *scaling, *rotation, *poses;
+  float* m[7];
+  float* v[7];
+  const float* pplr;
+  // workspace slices
+  char *geom, *tiles, *binning, *grad_scratch, *ssim_scratch;
+  float *image, *dm1, *dm2, *dm3, *dL_dimg;
+  float *means_cam, *rot_cam, *scales, *opac;
+  int32_t* radii;
+  float *g_means3D, *g_means2D, *g_opac, *g_scales, *g_rot_cam, *g_colors;
+  float *g_xyz, *g_rot, *g_scaling, *g_opacity, *g_fdc, *g_frest, *g_poses;
+  float *pose_scratch, *adam_scratch, *consts;  // consts: identity view [16], campos [3]
+  bool consts_ready;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <class T> T* take(size_t n) {
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += gs_align(n * sizeof(T));
+    return p;
+  }
+};
+
+size_t carve(Trainer& t, void* workspace) {
+  Carver c{(char*)workspace};
+  const size_t P = (size_t)(t.P > 0 ? t.P : 1), npix = (size_t)t.W * t.H;
+  t.geom = c.take<char>(mi355gs_raster_geom_bytes(t.P));
+  t.tiles = c.take<char>(mi355gs_raster_tiles_bytes(t.W, t.H));
+  t.binning = c.take<char>(mi355gs_raster_binning_bytes(t.capacity));
+  t.grad_scratch = c.take<char>(mi355gs_raster_grad_scratch_bytes(t.P));
+  t.ssim_scratch = c.take<char>(mi355gs_ssim_scratch_bytes(1, 3, t.H, t.W));
+  t.image = c.take<float>(3 * npix); t.dm1 = c.take<float>(3 * npix); t.dm2 = c.take<float>(3 * npix);
+  t.dm3 = c.take<float>(3 * npix); t.dL_dimg = c.take<float>(3 * npix);
+  t.means_cam = c.take<float>(3 * P); t.rot_cam = c.take<float>(4 * P); t.scales = c.take<float>(3 * P); t.opac = c.take<float>(P);
+  t.radii = c.take<int32_t>(P);
+  t.g_means3D = c.take<float>(3 * P); t.g_means2D = c.take<float>(3 * P); t.g_opac = c.take<float>(P);
+  t.g_scales = c.take<float>(3 * P); t.g_rot_cam = c.take<float>(4 * P); t.g_colors = c.take<float>(3 * P);
+  t.g_xyz = c.take<float>(3 * P); t.g_rot = c.take<float>(4 * P); t.g_scaling = c.take<float>(3 * P); t.g_opacity = c.take<float>(P);
+  t.g_fdc = c.take<float>(3 * P); t.g_frest = c.take<float>(45 * P); t.g_poses = c.take<float>(7 * (size_t)t.V);
+  t.pose_scratch = c.take<float>(16); t.adam_scratch = c.take<float>(8); t.consts = c.take<float>(32);
+  return c.off;
+}
+
+__global__ void k_trainer_consts(float* consts) {
+  const int i = threadIdx.x;
+  if (i < 16) consts[i] = (i % 5 == 0) ? 1.f : 0.f;  // identity view matrix
+  else if (i < 19) consts[i] = 0.f;                   // camera position
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi355gs_trainer_workspace_bytes(int P, int W, int H, int V, int64_t capacity) {
+  if (P < 0 || W <= 0 || H <= 0 || V <= 0 || capacity < 0) return 0;
+  Trainer t;
+  memset(&t, 0, sizeof(t));
+  t.P = P; t.W = W; t.H = H; t.V = V; t.capacity = capacity;
+  return carve(t, nullptr);
+}
+
+void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float* xyz, float* f_dc, float* f_rest, float* opacity,
+                             float* scaling, float* rotation, float* poses, float* const* exp_avg, float* const* exp_avg_sq,
+                             const float* per_point_lr, void* workspace) {
+  if (P <= 0 || W <= 0 || H <= 0 || V <= 0 || capacity <= 0 || !workspace || !exp_avg || !exp_avg_sq) return nullptr;
+  if (!xyz || !f_dc || !f_rest || !opacity || !scaling || !rotation || !poses) return nullptr;
+  Trainer* t = (Trainer*)calloc(1, sizeof(Trainer));
+  if (!t) return nullptr;
+  t->P = P; t->W = W; t->H = H; t->V = V; t->capacity = capacity;
+  t->xyz = xyz; t->f_dc = f_dc; t->f_rest = f_rest; t->opacity = opacity; t->scaling = scaling; t->rotation = rotation; t->poses = poses;
+  for (int k = 0; k < 7; ++k) {
+    if (!exp_avg[k] || !exp_avg_sq[k]) { free(t); return nullptr; }
+    t->m[k] = exp_avg[k]; t->v[k] = exp_avg_sq[k];
+  }
+  t->pplr = per_point_lr;
+  carve(*t, workspace);
+  t->consts_ready = false;
+  return t;
+}
+
+void mi355gs_trainer_destroy(void* handle) { free(handle); }
+
+int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_image, const float* projmatrix, float tanfovx,
+                         float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
+                         float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out) {
+  Trainer* t = (Trainer*)handle;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (!t || view < 0 || view >= t->V || !gt_image || !projmatrix || !bg || !lr || !step || !loss_out || !num_rendered_out)
+    return MI355GS_EINVAL;
+  const int P = t->P, W = t->W, H = t->H;
+  if (!t->consts_ready) {
+    hipLaunchKernelGGL(k_trainer_consts, dim3(1), dim3(64), 0, stream, t->consts);
+    GS_CHECK_LAUNCH("trainer_consts");
+    // f_rest never receives a gradient at SH degree 0: its (all-zero) gradient buffer is written once
+    if (hipMemsetAsync(t->g_frest, 0, (size_t)P * 45 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+    t->consts_ready = true;
+  }
+  const float* view_m = t->consts;
+  const float* campos = t->consts + 16;
+  const float* pose = t->poses + 7 * (size_t)view;
+  int rc;
+  // ---- forward
+  if ((rc = mi355gs_pose_forward(stream, P, t->xyz, t->rotation, t->scaling, t->opacity, pose, t->means_cam, t->rot_cam, t->scales,
+                                 t->opac)))
+    return rc;
+  if ((rc = mi355gs_raster_forward_preprocess(stream, P, 0, 1, W, H, t->means_cam, t->f_dc, nullptr, t->opac, t->scales, 1.0f,
+                                              t->rot_cam, nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, 0, t->radii,
+                                              t->geom, t->tiles, num_rendered_out, 0)))
+    return rc;
+  if ((rc = mi355gs_raster_forward_render(stream, P, W, H, t->capacity, bg, t->geom, t->tiles, t->binning, t->image, 0))) return rc;
+  if ((rc = gs_loss_forward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, t->ssim_scratch, lambda_dssim, loss_out)))
+    return rc;
+  // ---- backward
+  if ((rc = gs_loss_backward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, lambda_dssim, t->dL_dimg))) return rc;
+  if ((rc = mi355gs_raster_backward(stream, P, 0, 1, W, H, bg, t->means_cam, t->f_dc, nullptr, t->opac, t->scales, 1.0f, t->rot_cam,
+                                    nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, t->geom, t->tiles, t->binning,
+                                    t->capacity, t->radii, t->dL_dimg, t->grad_scratch, t->g_means3D, t->g_means2D, t->g_fdc,
+                                    t->g_colors, t->g_opac, t->g_scales, t->g_rot_cam, nullptr, 0)))
+    return rc;
+  if (hipMemsetAsync(t->g_poses, 0, (size_t)t->V * 7 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if ((rc = mi355gs_pose_backward(stream, P, t->xyz, t->rotation, t->scales, t->opac, pose, t->g_means3D, t->g_rot_cam, t->g_scales,
+                                  t->g_opac, t->g_xyz, t->g_rot, t->g_scaling, t->g_opacity, t->g_poses + 7 * (size_t)view,
+                                  t->pose_scratch)))
+    return rc;
+  // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
+  if (do_optimizer_step) {
+    const int64_t numel[7] = {3LL * P, 3LL * P, 45LL * P, (int64_t)P, 3LL * P, 4LL * P, 7LL * t->V};
+    const int32_t row[7] = {3, 1, 1, 1, 1, 1, 1};
+    float* params[7] = {t->xyz, t->f_dc, t->f_rest, t->opacity, t->scaling, t->rotation, t->poses};
+    const float* grads[7] = {t->g_xyz, t->g_fdc, t->g_frest, t->g_opacity, t->g_scaling, t->g_rot, t->g_poses};
+    const float* pplr[7] = {t->pplr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if ((rc = mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step,
+                                      t->adam_scratch)))
+      return rc;
+  }
+  return MI355GS_OK;
+}
+
+}  // extern "C"

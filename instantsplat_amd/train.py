@@ -7,6 +7,8 @@ optimizer.step() unless it is the last iteration -> zero_grad(set_to_none=True).
 """
 from __future__ import annotations
 
+import ctypes
+import math
 import random
 import time
 from dataclasses import dataclass, field
@@ -14,7 +16,9 @@ from typing import List, Optional
 
 import torch
 
+from . import _lib
 from .arguments import ModelParams, OptimizationParams, PipelineParams
+from .optim import PerPointAdam
 from .fused_ssim import fused_l1_ssim_loss, fused_ssim
 from .diff_gaussian_rasterization import BinningPolicy, binning_hint
 from .gaussian_renderer import render
@@ -87,6 +91,13 @@ def setup_training(scene: PointmapScene, device, opt: OptimizationParams | None 
     return TrainState(student, cams, gts, bg, opt, pipe)
 
 
+def _pick_camera(st: TrainState):
+    """reference train.py:152-157: pop a random view from the stack, refilling it when empty."""
+    if not st.viewpoint_stack:
+        st.viewpoint_stack = list(st.cameras)
+    return st.viewpoint_stack.pop(st.rng.randint(0, len(st.viewpoint_stack) - 1))
+
+
 def _forward_backward_step(st: TrainState, fused_loss: bool):
     """Body of reference train.py:140-211 without the host read-back of the loss."""
     st.iteration += 1
@@ -96,9 +107,7 @@ def _forward_backward_step(st: TrainState, fused_loss: bool):
         g.P.requires_grad_(False)
     if it % 1000 == 0:
         g.oneupSHdegree()
-    if not st.viewpoint_stack:
-        st.viewpoint_stack = list(st.cameras)
-    cam = st.viewpoint_stack.pop(st.rng.randint(0, len(st.viewpoint_stack) - 1))
+    cam = _pick_camera(st)
     pose = g.get_RT(cam.uid)
     bg = torch.rand(3, device=st.background.device) if opt.random_background else st.background
     with binning_hint(("train", cam.uid), tag=it):
@@ -130,6 +139,93 @@ def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = T
     return out
 
 
+class FusedTrainer:
+    """Whole iteration in one library call (mi355gs_trainer_step): same kernels as the op-by-op path, no autograd
+    graph, no temporaries, ~17 launches.  Used by RunAhead whenever the configuration is the one the reference's
+    scripts run (SH degree 0, scale/rotation covariance, SH colours, PerPointAdam with pose optimisation)."""
+
+    ORDER = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
+
+    @staticmethod
+    def supported(st: TrainState) -> bool:
+        g, o, p = st.gaussians, st.opt, st.pipe
+        if g.active_sh_degree != 0 or g.max_sh_degree != 3 or not o.optim_pose or p.debug or p.compute_cov3D_python or p.convert_SHs_python:
+            return False
+        if not isinstance(g.optimizer, PerPointAdam) or len(g.optimizer.param_groups) != 7:
+            return False
+        grp = g.optimizer.param_groups
+        if any(x["weight_decay"] != 0 or x["betas"] != grp[0]["betas"] or x["eps"] != grp[0]["eps"] for x in grp):
+            return False
+        return [x["name"] for x in grp] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "pose"]
+
+    def __init__(self, st: TrainState, capacity: int):
+        self.st, self.capacity = st, int(capacity)
+        g = st.gaussians
+        L = _lib.lib()
+        self.params = [getattr(g, n) for n in self.ORDER]
+        dev = _lib.require_device(*[p.data for p in self.params])
+        self.dev = dev
+        for p in self.params:  # same lazy state creation as PerPointAdam.step
+            s = g.optimizer.state[p]
+            if len(s) == 0:
+                s["step"], s["exp_avg"], s["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+        P, V = g._xyz.shape[0], g.P.shape[0]
+        cam = st.cameras[0]
+        self.W, self.H = int(cam.image_width), int(cam.image_height)
+        nbytes = L.mi355gs_trainer_workspace_bytes(P, self.W, self.H, V, self.capacity)
+        self.workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        PTR = ctypes.c_void_p * 7
+        m = PTR(*[g.optimizer.state[p]["exp_avg"].data_ptr() for p in self.params])
+        v = PTR(*[g.optimizer.state[p]["exp_avg_sq"].data_ptr() for p in self.params])
+        pplr = g.optimizer.param_groups[0].get("per_point_lr")
+        self._keep = (m, v, pplr)
+        self.handle = L.mi355gs_trainer_create(P, self.W, self.H, V, self.capacity, *[_lib.ptr(p.data) for p in self.params], m, v,
+                                               _lib.ptr(pplr), _lib.ptr(self.workspace))
+        if not self.handle:
+            raise RuntimeError("mi355gs_trainer_create failed")
+        self.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().mi355gs_trainer_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+
+    __del__ = close
+
+    def step(self, loss_slot: torch.Tensor):
+        """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1])."""
+        st = self.st
+        st.iteration += 1
+        it, g, opt = st.iteration, st.gaussians, st.opt
+        g.update_learning_rate(it)
+        cam = _pick_camera(st)
+        bg = torch.rand(3, device=self.dev) if opt.random_background else st.background
+        do_opt = it < opt.iterations
+        grp = g.optimizer.param_groups
+        steps = []
+        for p in self.params:
+            s = g.optimizer.state[p]
+            if do_opt:
+                s["step"] += 1
+            steps.append(max(s["step"], 1))
+        b1, b2 = grp[0]["betas"]
+        F7, I7 = ctypes.c_float * 7, ctypes.c_int32 * 7
+        _lib.check(_lib.lib().mi355gs_trainer_step(
+            ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), _lib.ptr(st.gt_images[cam.uid]),
+            _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(bg),
+            F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"]), float(opt.lambda_dssim),
+            1 if do_opt else 0, _lib.ptr(loss_slot), _lib.ptr(self.num_rendered)), "trainer_step")
+        # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy)
+        if self.dev.type == "cuda":
+            pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(self.num_rendered, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+        else:
+            pinned, ev = self.num_rendered.clone(), None
+        BinningPolicy.pending.append((ev, pinned, self.capacity, ("train", cam.uid), it))
+
+
 # ---- run-ahead variant: same arithmetic, no host synchronisation inside the iteration ------------------------
 class RunAhead:
     """Drives `train_iteration` without per-iteration host syncs and with results identical to the synchronous loop.
@@ -143,8 +239,9 @@ class RunAhead:
       and the window is replayed with exact sizing — so an overflow costs time, never correctness.
     """
 
-    def __init__(self, st: TrainState, window: int = 10, fused_loss: bool = True):
+    def __init__(self, st: TrainState, window: int = 10, fused_loss: bool = True, fused_step: bool = True):
         self.st, self.window, self.fused = st, window, fused_loss
+        self.fused_step, self.trainer = fused_step, None
         dev = st.background.device
         self.ring = torch.zeros(window, dtype=torch.float32, device=dev)
         self.ema = 0.0
@@ -152,6 +249,23 @@ class RunAhead:
         self.replays = 0
         BinningPolicy.reset("bounded")
         self._snapshot()
+        if fused_step and FusedTrainer.supported(st):
+            self._make_trainer()
+
+    def _make_trainer(self):
+        """Instance capacity from an exact count of every training view (one un-timed forward each)."""
+        st = self.st
+        with torch.no_grad():
+            for cam in st.cameras:
+                if ("train", cam.uid) not in BinningPolicy.known:
+                    mode, BinningPolicy.mode = BinningPolicy.mode, "exact"
+                    with binning_hint(("train", cam.uid)):
+                        render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
+                    BinningPolicy.mode = mode
+        need = max(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
+        if self.trainer is not None:
+            self.trainer.close()
+        self.trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
 
     def _tensors(self):
         g = self.st.gaussians
@@ -187,9 +301,13 @@ class RunAhead:
 
     def step(self):
         """One training iteration; returns the EMA loss at window boundaries (like the reference's progress bar), else None."""
-        loss = _forward_backward_step(self.st, self.fused)
-        self.ring[self.n_in_window] = loss
-        _optimizer_step(self.st)
+        nxt = self.st.iteration + 1
+        if self.trainer is not None and nxt % 1000 != 0 and FusedTrainer.supported(self.st):
+            self.trainer.step(self.ring[self.n_in_window:self.n_in_window + 1])
+        else:
+            loss = _forward_backward_step(self.st, self.fused)
+            self.ring[self.n_in_window] = loss
+            _optimizer_step(self.st)
         self.n_in_window += 1
         if self.n_in_window == self.window:
             return self.flush()
@@ -215,6 +333,10 @@ class RunAhead:
             self.ema = 0.4 * l + 0.6 * self.ema   # reference train.py:188
         self.st.last_loss = losses[-1]
         self.n_in_window = 0
+        if self.trainer is not None:  # grow the fixed-capacity buffers before the scene outgrows them
+            need = max(BinningPolicy.known.get(("train", c.uid), 0) for c in self.st.cameras)
+            if need * 1.2 + 1024 > self.trainer.capacity:
+                self._make_trainer()
         self._snapshot()
         return self.ema
 

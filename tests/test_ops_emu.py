@@ -45,6 +45,10 @@ def test_pose_tracking_reduces_masked_l1(emu):
     ops_util.check_pose_tracking(emu, num_iter=3, min_gain=0.0)
 
 
+def test_fused_train_step_equals_autograd_path(emu):
+    ops_util.check_fused_train_step_equals_autograd_path(emu)
+
+
 def test_adam_matches_reference_trajectory(emu):
     ops_util.check_adam_golden(emu)
 

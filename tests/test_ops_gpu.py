@@ -41,6 +41,10 @@ def test_pose_tracking_reduces_masked_l1(gpu):
     ops_util.check_pose_tracking(gpu, num_iter=120, min_gain=0.3, Wm=64, W=128)
 
 
+def test_fused_train_step_equals_autograd_path(gpu):
+    ops_util.check_fused_train_step_equals_autograd_path(gpu, iters=12, Wm=48, W=96)
+
+
 def test_adam_matches_reference_trajectory(gpu):
     ops_util.check_adam_golden(gpu)
 
