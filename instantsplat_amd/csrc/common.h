@@ -124,6 +124,17 @@ __device__ __forceinline__ float gs_pair_reduce(bool bit, float a, float b) {
   return keep + gs_dpp<CTRL>(send);
 }
 
+// Sum over the four 16-lane rows, lane-wise (every lane ends with the sum of the lanes l, l^16, l^32, l^48), with
+// gfx950's VALU row swaps — no LDS round trip (ds_bpermute) on the critical path.
+__device__ __forceinline__ float gs_sum_rows(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned w = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 #define GS_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \
     hipError_t e_ = hipGetLastError();                                          \

@@ -241,19 +241,22 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
           const float alpha = fminf(0.99f, a1.w * G);
           const bool valid = contributor <= last && power <= 0.0f && alpha >= ALPHA_MIN;
           if (__any(valid)) {
-            const float one_m = 1.f - alpha;
+            // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T, accum_rec, last_alpha and
+            // last_color then evolve exactly as if it had been skipped (acc' = 0*lc + 1*acc), so the replay state needs no
+            // per-field selects; only alpha itself and dL/dalpha are masked.
+            const float al = valid ? alpha : 0.f;
+            const float one_m = 1.f - al;
             const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // v_rcp_f32 (1 ulp) instead of two IEEE divisions
-            Tr = valid ? Tr * inv_one_m : Tr;
-            const float dchannel = valid ? alpha * Tr : 0.f;
-            const float na0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-            const float na1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-            const float na2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-            acc0 = valid ? na0 : acc0; acc1 = valid ? na1 : acc1; acc2 = valid ? na2 : acc2;
-            lc0 = valid ? a2.x : lc0; lc1 = valid ? a2.y : lc1; lc2 = valid ? a2.z : lc2;
+            Tr = Tr * inv_one_m;
+            const float dchannel = al * Tr;
+            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+            lc0 = a2.x; lc1 = a2.y; lc2 = a2.z;
             float dL_dalpha = (a2.x - acc0) * g0 + (a2.y - acc1) * g1 + (a2.z - acc2) * g2;
             dL_dalpha = dL_dalpha * Tr - T_final * inv_one_m * bg_dot;
             dL_dalpha = valid ? dL_dalpha : 0.f;
-            last_alpha = valid ? alpha : last_alpha;
+            last_alpha = al;
             const float dL_dG = a1.w * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
             const float dG_ddelx = -gdx * a1.x - gdy * a1.y;
@@ -277,9 +280,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
             x0 += gs_dpp<0x124>(x0); x1 += gs_dpp<0x124>(x1); x2 += gs_dpp<0x124>(x2);
             x0 += gs_dpp<0x128>(x0); x1 += gs_dpp<0x128>(x1); x2 += gs_dpp<0x128>(x2);
             float mine = r16 < 4 ? x0 : (r16 < 8 ? x1 : x2);
-            // the four rows
-            mine += __shfl_xor(mine, 16);
-            mine += __shfl_xor(mine, 32);
+            mine = gs_sum_rows(mine);  // the four rows
             if (lane < 9) atomicAdd(reinterpret_cast<float*>(grads + id) + lane, mine);
           }
           if (!more) break;

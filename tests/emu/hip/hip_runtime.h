@@ -351,6 +351,32 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
   if (sl < 0 || !emu::lane_in_op(buf, (unsigned)sl)) return bound_ctrl ? 0 : old;
   return emu::from_bits<int>(emu::ctx().waves[emu::wave_id()].val[buf][sl]);
 }
+// gfx950 row swaps: returns {new first operand, new second operand}
+struct emu_uint2v { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+// v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second
+static inline emu_uint2v __builtin_amdgcn_permlane16_swap(unsigned old, unsigned src, bool, bool) {
+  int buf = emu::wave_exchange(((uint64_t)src << 32) | old, true);
+  auto& ws = emu::ctx().waves[emu::wave_id()];
+  const unsigned l = emu::lane_id(), row = l >> 4;
+  auto D = [&](unsigned lane) { return (unsigned)(ws.val[buf][lane] & 0xffffffffu); };
+  auto S = [&](unsigned lane) { return (unsigned)(ws.val[buf][lane] >> 32); };
+  emu_uint2v r;
+  r.v[0] = (row & 1) ? S(l - 16) : D(l);   // vdst: odd rows receive the second operand's preceding even row
+  r.v[1] = (row & 1) ? S(l) : D(l + 16);   // src : even rows receive the first operand's following odd row
+  return r;
+}
+// v_permlane32_swap: upper 32 lanes of the first operand <-> lower 32 lanes of the second
+static inline emu_uint2v __builtin_amdgcn_permlane32_swap(unsigned old, unsigned src, bool, bool) {
+  int buf = emu::wave_exchange(((uint64_t)src << 32) | old, true);
+  auto& ws = emu::ctx().waves[emu::wave_id()];
+  const unsigned l = emu::lane_id();
+  auto D = [&](unsigned lane) { return (unsigned)(ws.val[buf][lane] & 0xffffffffu); };
+  auto S = [&](unsigned lane) { return (unsigned)(ws.val[buf][lane] >> 32); };
+  emu_uint2v r;
+  r.v[0] = l >= 32 ? S(l - 32) : D(l);
+  r.v[1] = l >= 32 ? S(l) : D(l + 32);
+  return r;
+}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
