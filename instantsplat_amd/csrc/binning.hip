@@ -4,8 +4,8 @@
 // (tile | depth) key and runs a device-wide radix sort over all R instances (6 passes of
 // 8-bit digits at 512^2, ~152 B of HBM traffic per instance).  Here the tile part of the key is
 // resolved by a counting scatter (count -> scan -> scatter, LDS-privatised), and only the
-// depth order inside each tile is sorted — by one workgroup per tile, entirely in LDS (64 KiB of
-// the CU's 160 KiB holds 8192 instances).  HBM traffic drops to ~28 B per instance
+// depth order inside each tile is sorted — by one workgroup per tile, in registers + wave shuffles with
+// only the cross-wave stages in LDS (64 KiB of the CU's 160 KiB covers 8192 instances).  HBM traffic drops to ~28 B per instance
 // (8 B key write, 8 B key read, 4 B list write, + counters) and the whole stage is 3 launches.
 // Result is identical: per tile, ascending (depth bits, Gaussian index).
 //
@@ -16,8 +16,9 @@
 namespace {
 
 constexpr int SCAN_THREADS = 1024;
-constexpr int SORT_THREADS = 512;
-constexpr int SORT_LDS_CAP = 8192;  // 8192 x 8 B = 64 KiB static LDS
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_SMALL_CAP = 2048;  // small kernel: <= 8 keys per thread, 16 KiB LDS, ~40 VGPRs -> 8 workgroups per CU
+constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64 KiB LDS
 
 // ---- K2: exclusive scan of per-tile counts (T <= ~10^5 fits one workgroup comfortably)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* __restrict__ count,
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
 // serialise at the L2.  The scatter kernel turns each private count into a reserved range of its
 // tile's segment (one returning global atomic), then hands out slots with returning LDS atomics.
 // Order inside a tile is arbitrary here; K4's sort makes it deterministic.
-constexpr int BIN_CHUNK = 2048;
+constexpr int BIN_CHUNK = 512;   // Gaussians per workgroup: 384 workgroups at 196k Gaussians (2048 left 160 of 256 CUs idle)
 constexpr int BIN_MAX_LDS_TILES = 16384;  // 64 KiB of LDS; larger grids use the direct-atomic kernels
 
 __device__ __forceinline__ bool unpack_rect(uint2 r, int& x0, int& y0, int& x1, int& y1) {
@@ -182,23 +183,109 @@ __device__ __forceinline__ void bitonic_sort_any(KeyPtr a, int n, int tid, int n
   }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles(int T, const uint32_t* __restrict__ start, uint64_t* __restrict__ keys,
-                                                              uint32_t* __restrict__ list, uint32_t capacity) {
+// Register/wave/LDS bitonic sort of one tile's keys: thread t owns E keys; key index
+//   i = wave * (64*E) + lane * E + e          (e = low bits, lane = middle 6 bits, wave = top 2 bits)
+// so compare-exchange partners at distance < E sit in the same thread, at distance < 64*E in the same wave
+// (one 64-bit lane shuffle, no barrier) and only the last two distance bits (across the 4 waves) go through
+// LDS: 3 barrier stages in total instead of one per network stage (55 for 1024 keys).
+// Slots >= n hold 0xFFFF... (sorts last, never written back).
+template <int E>
+__device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
+                                               uint32_t s, int n) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = wave * (64 * E) + lane * E;
+  uint64_t k[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) k[e] = (base + e < n) ? keys[s + base + e] : ~0ull;
+  constexpr int NP2 = SORT_THREADS * E;
+  for (int kk = 2; kk <= NP2; kk <<= 1) {
+    // ---- flip stage: partner = i ^ (kk-1); the lower index keeps the minimum
+    {
+      const int m = kk - 1;
+      if (kk <= E) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int pe = e ^ (m & (E - 1));
+          if (e < pe) { const uint64_t a = k[e], b = k[pe]; if (a > b) { k[e] = b; k[pe] = a; } }
+        }
+      } else if (kk <= 64 * E) {
+        const int lm = (m / E) & 63;  // lane bits of the mask
+        uint64_t other[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) other[e] = __shfl_xor(k[E - 1 - e], lm);
+        const bool lower = ((base) & (kk >> 1)) == 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = other[e]; k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+      } else {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) s_keys[base + e] = k[e];
+        __syncthreads();
+        const bool lower = (base & (kk >> 1)) == 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ m]; k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+      }
+    }
+    // ---- disperse stages: partner = i ^ d
+    for (int d = kk >> 2; d >= 1; d >>= 1) {
+      if (d < E) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int pe = e ^ d;
+          if (e < pe) { const uint64_t a = k[e], b = k[pe]; if (a > b) { k[e] = b; k[pe] = a; } }
+        }
+      } else if (d < 64 * E) {
+        const int lm = d / E;
+        const bool lower = (base & d) == 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = __shfl_xor(a, lm); k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+      } else {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) s_keys[base + e] = k[e];
+        __syncthreads();
+        const bool lower = (base & d) == 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ d]; k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if (base + e < n) list[s + base + e] = (uint32_t)k[e];
+}
+
+// Two launches per frame: the small-tile kernel keeps its register and LDS footprint low so 8 workgroups fit a CU
+// (a single kernel with the 32-keys-per-thread path compiled in needs 134 VGPRs and ran one workgroup per CU);
+// the large-tile kernel exits at once for every tile the small one handled.
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_small(int T, const uint32_t* __restrict__ start,
+                                                                    const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
+                                                                    uint32_t capacity) {
+  __shared__ uint64_t s_keys[SORT_SMALL_CAP];
+  const int tile = gs_tile_of_block(blockIdx.x, T);
+  if (tile >= T) return;
+  const uint32_t s = min(start[tile], capacity), e = min(start[tile + 1], capacity);
+  const int n = (int)(e - s);
+  if (n <= 0 || n > SORT_SMALL_CAP) return;
+  if (n <= SORT_THREADS) sort_tile_regs<1>(s_keys, keys, list, s, n);
+  else if (n <= SORT_THREADS * 2) sort_tile_regs<2>(s_keys, keys, list, s, n);
+  else if (n <= SORT_THREADS * 4) sort_tile_regs<4>(s_keys, keys, list, s, n);
+  else sort_tile_regs<8>(s_keys, keys, list, s, n);
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_large(int T, const uint32_t* __restrict__ start, uint64_t* __restrict__ keys,
+                                                                    uint32_t* __restrict__ list, uint32_t capacity) {
   __shared__ uint64_t s_keys[SORT_LDS_CAP];
   const int tile = gs_tile_of_block(blockIdx.x, T);
   if (tile >= T) return;
   const uint32_t s = min(start[tile], capacity), e = min(start[tile + 1], capacity);
   const int n = (int)(e - s);
-  if (n <= 0) return;
+  if (n <= SORT_SMALL_CAP) return;
   const int tid = threadIdx.x;
-  if (n <= SORT_LDS_CAP) {
-    for (int i = tid; i < n; i += SORT_THREADS) s_keys[i] = keys[s + i];
-    __syncthreads();
-    bitonic_sort_any(s_keys, n, tid, SORT_THREADS);
-    for (int i = tid; i < n; i += SORT_THREADS) list[s + i] = (uint32_t)s_keys[i];
-  } else {
+  if (n <= SORT_THREADS * 16) sort_tile_regs<16>(s_keys, keys, list, s, n);
+  else if (n <= SORT_THREADS * 32) sort_tile_regs<32>(s_keys, keys, list, s, n);
+  else {
     uint64_t* seg = keys + s;
-    __syncthreads();
     bitonic_sort_any(seg, n, tid, SORT_THREADS);
     for (int i = tid; i < n; i += SORT_THREADS) list[s + i] = (uint32_t)seg[i];
   }
@@ -228,6 +315,7 @@ int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const GsRec* rec
                        start, cursor, keys, capacity);
   else
     hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, recs, rects, start, cursor, keys, capacity);
-  hipLaunchKernelGGL(k_sort_tiles, dim3(gs_grid_for_tiles(T)), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity);
+  hipLaunchKernelGGL(k_sort_tiles_small, dim3(gs_grid_for_tiles(T)), dim3(SORT_THREADS), 0, stream, T, start, (const uint64_t*)keys, list, capacity);
+  hipLaunchKernelGGL(k_sort_tiles_large, dim3(gs_grid_for_tiles(T)), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity);
   return 0;
 }

@@ -22,3 +22,10 @@ def test_empty_and_all_culled(emu):
     out = run_blob_case(emu, 0, 32, 32, 0, backward=False)
     assert torch.allclose(out["ref"]["color"], out["dut"]["color"])
     assert out["dut"]["color"].shape == (3, 32, 32)
+
+
+@pytest.mark.parametrize("P,W,H,sm", [(700, 32, 32, 0.3), (2600, 32, 16, 0.4), (9000, 16, 16, 0.5)])
+def test_long_tile_lists_all_sort_paths(emu, P, W, H, sm):
+    """Tiles with ~600 / ~2500 / >8192 instances: register sort with 2 and 8 keys per thread, and the global-memory fallback."""
+    out = run_blob_case(emu, P, W, H, 0, scale_mean=sm, backward=False)
+    assert_raster_parity(out)
