@@ -137,9 +137,13 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
   }
   a.first_block[MT_MAX] = blocks;
   if (blocks == 0) return MI355GS_OK;
-  if (hipMemsetAsync(scratch, 0, MT_MAX * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
-  hipLaunchKernelGGL(k_adam_sumsq, dim3(blocks), dim3(256), 0, stream, a, scratch);
-  GS_CHECK_LAUNCH("adam_sumsq");
+  if (g_fused.gate == scratch) {
+    // fused train step: the gate flags were written by the kernels that produced the gradients
+  } else {
+    if (hipMemsetAsync(scratch, 0, MT_MAX * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+    hipLaunchKernelGGL(k_adam_sumsq, dim3(blocks), dim3(256), 0, stream, a, scratch);
+    GS_CHECK_LAUNCH("adam_sumsq");
+  }
   hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, stream, a, (const float*)scratch, beta1, beta2, eps);
   GS_CHECK_LAUNCH("adam_multi");
   return MI355GS_OK;

@@ -9,7 +9,7 @@ int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const flo
 int gs_launch_count_tiles(hipStream_t, int, int, int, const uint2*, uint32_t*);
 int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, int, int,
                              const CamParams&, const int32_t*, const float*, const uint8_t*, const GsGrad*, float*, float*,
-                             float*, float*, float*, float*, float*, float*);
+                             float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
 int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*);
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t);
@@ -46,6 +46,8 @@ struct ProfScope {
   ~ProfScope() { if (active) (void)hipEventRecord(stop, s); }
 };
 }  // namespace
+
+thread_local GsFusedStepHooks g_fused;
 
 void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
 
@@ -101,7 +103,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   char* g = (char*)geom;
   char* t = (char*)tiles;
   // count + cursor are adjacent
-  if (hipMemsetAsync(t + tl.count, 0, tl.start - tl.count, stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if (!g_fused.skip_memsets && hipMemsetAsync(t + tl.count, 0, tl.start - tl.count, stream) != hipSuccess) return MI355GS_ELAUNCH;
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
   gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
                            (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped));
@@ -166,7 +168,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   const char* t = (const char*)tiles;
   const char* b = (const char*)binning;
   GsGrad* grads = (GsGrad*)grad_scratch;
-  if (hipMemsetAsync(grads, 0, (size_t)P * sizeof(GsGrad), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if (!g_fused.skip_memsets && hipMemsetAsync(grads, 0, (size_t)P * sizeof(GsGrad), stream) != hipSuccess) return MI355GS_ELAUNCH;
   if (cap > 0) {
     {
       ProfScope prof(1, stream);
@@ -179,7 +181,8 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
   gs_launch_preprocess_bwd(stream, P, D, M, means3D, shs, scales, rotations, use_shs, use_cov, cp, radii,
                            (const float*)(g + gl.cov3D), (const uint8_t*)(g + gl.clamped), grads, dL_dmeans3D, dL_dmeans2D,
-                           dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D);
+                           dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D,
+                           (g_fused.gate && g_fused.gate_sh >= 0) ? g_fused.gate + g_fused.gate_sh : nullptr);
   GS_CHECK_LAUNCH("preprocess_bwd");
   return MI355GS_OK;
 }

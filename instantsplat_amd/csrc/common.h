@@ -146,3 +146,15 @@ __device__ __forceinline__ float gs_sum_rows(float v) {
   } while (0)
 
 void gs_log_error(const char* where, const char* what);
+
+// Set by the fused train step (trainer.hip) around its calls into the per-operator entry points: the trainer zeroes
+// every counter / accumulator of the iteration in ONE prologue launch and asks the operators to skip their own memsets,
+// and it collects the "gradient tensor has a non-zero" gate flags for PerPointAdam from the kernels that write the
+// gradients (gate[k] > 0  <=>  tensor k of the optimizer's group order has a non-zero gradient) instead of a
+// separate pass over all gradients.
+struct GsFusedStepHooks {
+  bool skip_memsets = false;
+  float* gate = nullptr;   // device float[8] or null
+  int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_pose = -1;
+};
+extern thread_local GsFusedStepHooks g_fused;

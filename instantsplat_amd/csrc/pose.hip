@@ -69,19 +69,22 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
                                                    const float* __restrict__ g_rot, const float* __restrict__ g_scales,
                                                    const float* __restrict__ g_opac, float* __restrict__ d_xyz,
                                                    float* __restrict__ d_rot, float* __restrict__ d_scaling,
-                                                   float* __restrict__ d_opacity_logit, float* __restrict__ acc) {
+                                                   float* __restrict__ d_opacity_logit, float* __restrict__ acc,
+                                                   float* __restrict__ gate, int gi_xyz, int gi_rot, int gi_scaling, int gi_opacity) {
   __shared__ float s_red[4][16];
   const PoseMat m = load_pose(pose);
   float a[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
+  bool nz_xyz = false, nz_rot = false, nz_sc = false, nz_op = false;
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
     const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     const float gx = g_means[3 * (size_t)i], gy = g_means[3 * (size_t)i + 1], gz = g_means[3 * (size_t)i + 2];
-    d_xyz[3 * (size_t)i] = m.R[0] * gx + m.R[3] * gy + m.R[6] * gz;
-    d_xyz[3 * (size_t)i + 1] = m.R[1] * gx + m.R[4] * gy + m.R[7] * gz;
-    d_xyz[3 * (size_t)i + 2] = m.R[2] * gx + m.R[5] * gy + m.R[8] * gz;
+    const float dx0 = m.R[0] * gx + m.R[3] * gy + m.R[6] * gz, dx1 = m.R[1] * gx + m.R[4] * gy + m.R[7] * gz,
+                dx2 = m.R[2] * gx + m.R[5] * gy + m.R[8] * gz;
+    d_xyz[3 * (size_t)i] = dx0; d_xyz[3 * (size_t)i + 1] = dx1; d_xyz[3 * (size_t)i + 2] = dx2;
+    nz_xyz = nz_xyz || dx0 != 0.f || dx1 != 0.f || dx2 != 0.f;
     a[0] += gx; a[1] += gy; a[2] += gz;
     a[3] += gx * x; a[4] += gx * y; a[5] += gx * z;
     a[6] += gy * x; a[7] += gy * y; a[8] += gy * z;
@@ -95,14 +98,21 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
     d2.z = -y1 * gr.x - z1 * gr.y + w1 * gr.z + x1 * gr.w;
     d2.w = -z1 * gr.x + y1 * gr.y - x1 * gr.z + w1 * gr.w;
     *reinterpret_cast<float4*>(d_rot + 4 * (size_t)i) = d2;
+    nz_rot = nz_rot || d2.x != 0.f || d2.y != 0.f || d2.z != 0.f || d2.w != 0.f;
     a[12] += q2.x * gr.x + q2.y * gr.y + q2.z * gr.z + q2.w * gr.w;
     a[13] += -q2.y * gr.x + q2.x * gr.y - q2.w * gr.z + q2.z * gr.w;
     a[14] += -q2.z * gr.x + q2.w * gr.y + q2.x * gr.z - q2.y * gr.w;
     a[15] += -q2.w * gr.x - q2.z * gr.y + q2.y * gr.z + q2.x * gr.w;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) d_scaling[3 * (size_t)i + k] = g_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
+    for (int k = 0; k < 3; ++k) {
+      const float v = g_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
+      d_scaling[3 * (size_t)i + k] = v;
+      nz_sc = nz_sc || v != 0.f;
+    }
     const float o = opac[i];
-    d_opacity_logit[i] = g_opac[i] * o * (1.f - o);
+    const float dol = g_opac[i] * o * (1.f - o);
+    d_opacity_logit[i] = dol;
+    nz_op = nz_op || dol != 0.f;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -115,9 +125,16 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
     const int k = threadIdx.x;
     atomicAdd(&acc[k], (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]));
   }
+  if (gate) {  // PerPointAdam's whole-tensor gate: any non-zero gradient element (benign same-value store race)
+    if (gi_xyz >= 0 && nz_xyz) gate[gi_xyz] = 1.0f;
+    if (gi_rot >= 0 && nz_rot) gate[gi_rot] = 1.0f;
+    if (gi_scaling >= 0 && nz_sc) gate[gi_scaling] = 1.0f;
+    if (gi_opacity >= 0 && nz_op) gate[gi_opacity] = 1.0f;
+  }
 }
 
-__global__ void k_pose_finish(const float* __restrict__ pose, const float* __restrict__ acc, float* __restrict__ d_pose) {
+__global__ void k_pose_finish(const float* __restrict__ pose, const float* __restrict__ acc, float* __restrict__ d_pose,
+                              float* __restrict__ pose_gate) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const PoseMat m = load_pose(pose);
   const float* Rp = acc + 3;  // dL/dR, row-major: Rp[3*i+j]
@@ -133,6 +150,11 @@ __global__ void k_pose_finish(const float* __restrict__ pose, const float* __res
   for (int k = 0; k < 4; ++k) d_pose[k] = (gq[k] - m.qn[k] * dot) * m.inv_norm + acc[12 + k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) d_pose[4 + k] = acc[k];
+  if (pose_gate) {
+    bool nz = false;
+    for (int k = 0; k < 7; ++k) nz = nz || d_pose[k] != 0.f;
+    if (nz) *pose_gate = 1.0f;
+  }
 }
 
 }  // namespace
@@ -161,17 +183,19 @@ int mi355gs_pose_backward(void* stream_, int P, const float* xyz, const float* r
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (P < 0 || !pose || !d_pose || !scratch16) return MI355GS_EINVAL;
-  if (hipMemsetAsync(scratch16, 0, 16 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if (!g_fused.skip_memsets && hipMemsetAsync(scratch16, 0, 16 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
   if (P > 0) {
     if (!xyz || !rot || !scales || !opac || !g_means || !g_rot || !g_scales || !g_opac || !d_xyz || !d_rot || !d_scaling ||
         !d_opacity_logit)
       return MI355GS_EINVAL;
     const int blocks = min((P + 255) / 256, 1024);
     hipLaunchKernelGGL(k_pose_bwd, dim3(blocks), dim3(256), 0, stream, P, xyz, rot, scales, opac, pose, g_means, g_rot, g_scales,
-                       g_opac, d_xyz, d_rot, d_scaling, d_opacity_logit, scratch16);
+                       g_opac, d_xyz, d_rot, d_scaling, d_opacity_logit, scratch16, g_fused.gate, g_fused.gate_xyz, g_fused.gate_rot,
+                       g_fused.gate_scaling, g_fused.gate_opacity);
     GS_CHECK_LAUNCH("pose_bwd");
   }
-  hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, (const float*)scratch16, d_pose);
+  hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, (const float*)scratch16, d_pose,
+                     (g_fused.gate && g_fused.gate_pose >= 0) ? g_fused.gate + g_fused.gate_pose : nullptr);
   GS_CHECK_LAUNCH("pose_finish");
   return MI355GS_OK;
 }

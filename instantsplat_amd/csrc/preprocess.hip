@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float* __restrict__ cov3Ds, const uint8_t* __restrict__ clamped, const GsGrad* __restrict__ grads,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ sh_gate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const bool vis = radii[i] > 0;
@@ -391,6 +391,11 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   if (gsh) {
     const int first = (vis && use_shs) ? nb : 0;  // coefficients [0,nb) were written by sh_backward
     for (int k = first * 3; k < M * 3; ++k) gsh[k] = 0.f;
+    if (sh_gate && first) {  // benign race: every writer stores the same value
+      bool nz = false;
+      for (int k = 0; k < first * 3; ++k) nz = nz || gsh[k] != 0.f;
+      if (nz) *sh_gate = 1.0f;
+    }
   }
   if (dL_dscales) { dL_dscales[3 * (size_t)i] = gs[0]; dL_dscales[3 * (size_t)i + 1] = gs[1]; dL_dscales[3 * (size_t)i + 2] = gs[2]; }
   if (dL_drots) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
@@ -426,11 +431,11 @@ int gs_launch_preprocess_bwd(hipStream_t stream, int P, int D, int M, const floa
                              const float* scales, const float* rotations, int use_shs, int use_cov_precomp,
                              const CamParams& cp, const int32_t* radii, const float* cov3Ds, const uint8_t* clamped,
                              const GsGrad* grads, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
-                             float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D) {
+                             float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D, float* sh_gate) {
   if (P <= 0) return 0;
   hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, scales, rotations,
                      use_shs, use_cov_precomp, cp, radii, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
-                     dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D);
+                     dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate);
   return 0;
 }
 

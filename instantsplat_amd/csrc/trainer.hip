@@ -69,6 +69,19 @@ size_t carve(Trainer& t, void* workspace) {
   return c.off;
 }
 
+// one launch zeroes every counter / accumulator of the iteration (grid-stride over the 48-byte gradient records)
+__global__ __launch_bounds__(256) void k_trainer_prologue(float4* __restrict__ grad_records, size_t n_vec, uint32_t* __restrict__ tile_counters,
+                                                          int n_counters, float* __restrict__ g_poses, int n_pose, float* __restrict__ pose_scratch,
+                                                          float* __restrict__ adam_scratch) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = gid; i < n_vec; i += stride) grad_records[i] = z;
+  for (size_t i = gid; i < (size_t)n_counters; i += stride) tile_counters[i] = 0u;
+  if (gid < (size_t)n_pose) g_poses[gid] = 0.f;
+  if (gid < 16) pose_scratch[gid] = 0.f;
+  if (gid < 8) adam_scratch[gid] = 0.f;
+}
+
 __global__ void k_trainer_consts(float* consts) {
   const int i = threadIdx.x;
   if (i < 16) consts[i] = (i % 5 == 0) ? 1.f : 0.f;  // identity view matrix
@@ -124,6 +137,20 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_
     if (hipMemsetAsync(t->g_frest, 0, (size_t)P * 45 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
     t->consts_ready = true;
   }
+  {
+    const TilesLayout tl(W, H);
+    hipLaunchKernelGGL(k_trainer_prologue, dim3(1024), dim3(256), 0, stream, (float4*)t->grad_scratch, (size_t)P * 3,
+                       (uint32_t*)(t->tiles + tl.count), (int)((tl.start - tl.count) / 4), t->g_poses, 7 * t->V, t->pose_scratch,
+                       t->adam_scratch);
+    GS_CHECK_LAUNCH("trainer_prologue");
+  }
+  struct HookScope {
+    HookScope(float* gate) {
+      g_fused.skip_memsets = true; g_fused.gate = gate;
+      g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5; g_fused.gate_pose = 6;
+    }
+    ~HookScope() { g_fused = GsFusedStepHooks(); }
+  } hook_scope(t->adam_scratch);
   const float* view_m = t->consts;
   const float* campos = t->consts + 16;
   const float* pose = t->poses + 7 * (size_t)view;
@@ -146,7 +173,6 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_
                                     t->capacity, t->radii, t->dL_dimg, t->grad_scratch, t->g_means3D, t->g_means2D, t->g_fdc,
                                     t->g_colors, t->g_opac, t->g_scales, t->g_rot_cam, nullptr, 0)))
     return rc;
-  if (hipMemsetAsync(t->g_poses, 0, (size_t)t->V * 7 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
   if ((rc = mi355gs_pose_backward(stream, P, t->xyz, t->rotation, t->scales, t->opac, pose, t->g_means3D, t->g_rot_cam, t->g_scales,
                                   t->g_opac, t->g_xyz, t->g_rot, t->g_scaling, t->g_opacity, t->g_poses + 7 * (size_t)view,
                                   t->pose_scratch)))
