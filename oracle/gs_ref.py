@@ -47,9 +47,12 @@ class RefContext:
         self.handle, self.suf = handle, suf
 
     def __del__(self):
-        if self.handle:
-            getattr(lib(), f"gsref_free_{self.suf}")(ctypes.c_void_p(self.handle))
-            self.handle = None
+        try:
+            if self.handle:
+                getattr(lib(), f"gsref_free_{self.suf}")(ctypes.c_void_p(self.handle))
+                self.handle = None
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     @property
     def num_rendered(self):
