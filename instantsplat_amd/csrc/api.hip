@@ -8,7 +8,7 @@ int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const flo
                              const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*);
 int gs_launch_count_tiles(hipStream_t, int, int, int, const uint2*, uint32_t*);
 int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, int, int,
-                             const CamParams&, const int32_t*, const float*, const uint8_t*, const GsGrad*, float*, float*,
+                             const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
                              float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
 int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*);
@@ -180,7 +180,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
   gs_launch_preprocess_bwd(stream, P, D, M, means3D, shs, scales, rotations, use_shs, use_cov, cp, radii,
-                           (const float*)(g + gl.cov3D), (const uint8_t*)(g + gl.clamped), grads, dL_dmeans3D, dL_dmeans2D,
+                           (const GsRec*)(g + gl.rec), (const float*)(g + gl.cov3D), (const uint8_t*)(g + gl.clamped), grads, dL_dmeans3D, dL_dmeans2D,
                            dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D,
                            (g_fused.gate && g_fused.gate_sh >= 0) ? g_fused.gate + g_fused.gate_sh : nullptr);
   GS_CHECK_LAUNCH("preprocess_bwd");

@@ -19,10 +19,12 @@ struct alignas(16) GsRec {
   float4 q2;  // r, g, b, depth
 };
 
-// Per-Gaussian screen-space gradient accumulator filled by composite backward (float atomics).
+// Per-Gaussian accumulator filled by composite backward (float atomics): moments of w = G * dL/dG over all
+// pixels the Gaussian touched, plus the colour gradient.  k_preprocess_bwd turns the moments into
+// dL/dmean2D, dL/dconic and dL/dopacity with the Gaussian's own conic and opacity.
 struct alignas(16) GsGrad {
-  float4 g0;  // dL/dmean2D.x, .y (NDC-scaled, as the reference reports them), dL/dconic a, dL/dconic b (full)
-  float4 g1;  // dL/dconic c, dL/dopacity, dL/dr, dL/dg
+  float4 g0;  // sum w dx, sum w dy, sum w dx^2, sum w dx dy
+  float4 g1;  // sum w dy^2, sum w, dL/dr, dL/dg
   float4 g2;  // dL/db, unused x3
 };
 

@@ -185,7 +185,6 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
   if (q.inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[plane + pix]; g2 = dL_dpix[2 * plane + pix]; }
   const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
   // the tile only needs instances [0, max over pixels of last)
   uint32_t wmax = last;
@@ -257,17 +256,15 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
             dL_dalpha = dL_dalpha * Tr - T_final * inv_one_m * bg_dot;
             dL_dalpha = valid ? dL_dalpha : 0.f;
             last_alpha = al;
-            const float dL_dG = a1.w * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * a1.x - gdy * a1.y;
-            const float dG_ddely = -gdy * a1.z - gdx * a1.y;
-            // nine terms -> one per lane: component c of this Gaussian ends up in lanes with (lane & 15) == c
-            const float t0 = dL_dG * dG_ddelx * ddelx_dx;   // dL/dmean2D.x
-            const float t1 = dL_dG * dG_ddely * ddely_dy;   // dL/dmean2D.y
-            const float t2 = -0.5f * gdx * dx * dL_dG;      // dL/dconic a
-            const float t3 = -gdx * dy * dL_dG;             // dL/dconic b
-            const float t4 = -0.5f * gdy * dy * dL_dG;      // dL/dconic c
-            const float t5 = G * dL_dalpha;                 // dL/dopacity
+            // Moments of w = G * dL/dG over the wave's pixels: every screen-space gradient of this Gaussian is a fixed
+            // linear combination of them (coefficients = its own conic / opacity), applied once per Gaussian in
+            // k_preprocess_bwd instead of once per pixel here:
+            //   dL/dconic = (-1/2 sum w dx^2, -sum w dx dy, -1/2 sum w dy^2),  dL/dopacity = sum w / opacity,
+            //   dL/dmean2D = -(a sum w dx + b sum w dy, c sum w dy + b sum w dx) * (W/2, H/2)
+            const float w = G * (a1.w * dL_dalpha);
+            const float t0 = w * dx, t1 = w * dy;              // sum w dx, sum w dy
+            const float t2 = t0 * dx, t3 = t0 * dy, t4 = t1 * dy;  // sum w dx^2, sum w dx dy, sum w dy^2
+            const float t5 = w;                                 // sum w
             const float t6 = dchannel * g0, t7 = dchannel * g1, t8 = dchannel * g2;  // dL/drgb
             // lanes differing in bit 0 (quad_perm [1,0,3,2]) then bit 1 (quad_perm [2,3,0,1])
             const float w0 = gs_pair_reduce<0xB1>(bit0, t0, t1), w1 = gs_pair_reduce<0xB1>(bit0, t2, t3);

@@ -256,7 +256,7 @@ __device__ __forceinline__ void sh_backward(const float* sh, float* gsh, float x
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
     const float* __restrict__ rotations, int use_shs, int use_cov_precomp, CamParams cp, const int32_t* __restrict__ radii,
-    const float* __restrict__ cov3Ds, const uint8_t* __restrict__ clamped, const GsGrad* __restrict__ grads,
+    const GsRec* __restrict__ recs, const float* __restrict__ cov3Ds, const uint8_t* __restrict__ clamped, const GsGrad* __restrict__ grads,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ sh_gate) {
@@ -264,8 +264,20 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   if (i >= P) return;
   const bool vis = radii[i] > 0;
   GsGrad g;
-  if (vis) g = grads[i];
-  else { g.g0 = make_float4(0, 0, 0, 0); g.g1 = g.g0; g.g2 = g.g0; }
+  g.g0 = make_float4(0, 0, 0, 0); g.g1 = g.g0; g.g2 = g.g0;
+  if (vis) {
+    // moments (see GsGrad) -> screen-space gradients, with this Gaussian's conic (a, b, c) and opacity
+    const GsGrad mo = grads[i];
+    const float4 con = recs[i].q1;
+    const float m1 = mo.g0.x, m2 = mo.g0.y, m3 = mo.g0.z, m4 = mo.g0.w, m5 = mo.g1.x, m0 = mo.g1.y;
+    g.g0.x = -(con.x * m1 + con.y * m2) * (0.5f * cp.W);   // dL/dmean2D.x (NDC-scaled, as the reference reports it)
+    g.g0.y = -(con.z * m2 + con.y * m1) * (0.5f * cp.H);   // dL/dmean2D.y
+    g.g0.z = -0.5f * m3;                                    // dL/dconic a
+    g.g0.w = -m4;                                           // dL/dconic b (both off-diagonal entries)
+    g.g1.x = -0.5f * m5;                                    // dL/dconic c
+    g.g1.y = con.w != 0.f ? m0 / con.w : 0.f;               // dL/dopacity
+    g.g1.z = mo.g1.z; g.g1.w = mo.g1.w; g.g2.x = mo.g2.x;   // dL/drgb
+  }
   float gm[3] = {0.f, 0.f, 0.f};
   float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -429,12 +441,12 @@ int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const floa
 
 int gs_launch_preprocess_bwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs,
                              const float* scales, const float* rotations, int use_shs, int use_cov_precomp,
-                             const CamParams& cp, const int32_t* radii, const float* cov3Ds, const uint8_t* clamped,
+                             const CamParams& cp, const int32_t* radii, const GsRec* recs, const float* cov3Ds, const uint8_t* clamped,
                              const GsGrad* grads, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                              float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D, float* sh_gate) {
   if (P <= 0) return 0;
   hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, scales, rotations,
-                     use_shs, use_cov_precomp, cp, radii, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                     use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
                      dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate);
   return 0;
 }
