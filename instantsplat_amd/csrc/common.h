@@ -7,6 +7,7 @@
 #include <stddef.h>
 #include "../../include/mi355gs.h"
 
+#define GS_LOG2E 1.4426950408889634f
 #define GS_TILE 16
 #define GS_TILE_PIX 256
 #define GS_WAVE 64
@@ -15,7 +16,8 @@
 // with three 16-byte loads from one contiguous address (1 cache line most of the time).
 struct alignas(16) GsRec {
   float4 q0;  // x, y (pixel centre), hx, hy (half extents of the alpha >= 1/255 ellipse's AABB; <0: never visible)
-  float4 q1;  // conic a, b, c, opacity
+  float4 q1;  // conic pre-scaled for v_exp_f32: (-a/2, -b, -c/2) * log2(e), then opacity — so that
+              // G = exp2(q1.x*dx*dx + q1.z*dy*dy + q1.y*dx*dy) with no further multiplies
   float4 q2;  // r, g, b, depth
 };
 

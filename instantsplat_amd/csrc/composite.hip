@@ -50,26 +50,27 @@ __device__ __forceinline__ bool quad_hit(const float4& q0, const float4& q1, con
   if (q0.z > 1e29f) return true;
   const float gx = q0.x, gy = q0.y;
   if (gx >= q.x0 && gx <= q.x1 && gy >= q.y0 && gy <= q.y1) return true;
-  const float a = q1.x, b = q1.y, c = q1.z;
-  const float tau = __logf(255.0f * q1.w) * 1.01f + 1e-3f;
-  const float inv_a = __builtin_amdgcn_rcpf(a), inv_c = __builtin_amdgcn_rcpf(c);
+  // q1 holds the exp2-scaled conic: e(dx,dy) = A dx^2 + C dy^2 + B dx dy (A, C < 0) is log2 of the Gaussian falloff
+  const float A = q1.x, B = q1.y, C = q1.z;
+  const float tau = __log2f(255.0f * q1.w) * 1.01f + 1e-3f;
+  const float inv_2A = __builtin_amdgcn_rcpf(2.0f * A), inv_2C = __builtin_amdgcn_rcpf(2.0f * C);
   const float dx_lo = gx - q.x1, dx_hi = gx - q.x0, dy_lo = gy - q.y1, dy_hi = gy - q.y0;
   float best = -3.0e38f;
   {
-    const float dx = dx_hi, dy = fminf(dy_hi, fmaxf(dy_lo, -b * dx * inv_c));
-    best = fmaxf(best, -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy);
+    const float dx = dx_hi, dy = fminf(dy_hi, fmaxf(dy_lo, -B * dx * inv_2C));
+    best = fmaxf(best, A * dx * dx + C * dy * dy + B * dx * dy);
   }
   {
-    const float dx = dx_lo, dy = fminf(dy_hi, fmaxf(dy_lo, -b * dx * inv_c));
-    best = fmaxf(best, -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy);
+    const float dx = dx_lo, dy = fminf(dy_hi, fmaxf(dy_lo, -B * dx * inv_2C));
+    best = fmaxf(best, A * dx * dx + C * dy * dy + B * dx * dy);
   }
   {
-    const float dy = dy_hi, dx = fminf(dx_hi, fmaxf(dx_lo, -b * dy * inv_a));
-    best = fmaxf(best, -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy);
+    const float dy = dy_hi, dx = fminf(dx_hi, fmaxf(dx_lo, -B * dy * inv_2A));
+    best = fmaxf(best, A * dx * dx + C * dy * dy + B * dx * dy);
   }
   {
-    const float dy = dy_lo, dx = fminf(dx_hi, fmaxf(dx_lo, -b * dy * inv_a));
-    best = fmaxf(best, -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy);
+    const float dy = dy_lo, dx = fminf(dx_hi, fmaxf(dx_lo, -B * dy * inv_2A));
+    best = fmaxf(best, A * dx * dx + C * dy * dy + B * dx * dy);
   }
   return best >= -tau;
 }
@@ -92,12 +93,13 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
 
-  float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  // Tr: live transmittance, forced to 0 once the pixel is finished (T < 1e-4 reached, or outside the image);
+  // Tfin: transmittance after the last blended Gaussian (the value the reference stores as final_T)
+  float Tr = q.inside ? 1.0f : 0.0f, Tfin = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
-  bool done = !q.inside;
 
   for (uint32_t base = start; base < end; base += BATCH) {
-    const int wave_done = __all(done);
+    const int wave_done = __all(Tr == 0.0f);
     if (lane == 0) s_done[wave] = wave_done;
     __syncthreads();  // also fences the previous batch's LDS reads against the stores below
     if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
@@ -128,30 +130,31 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
           if (more) i_next = k + __ffsll(mask) - 1;
           n0 = s_q0[i_next]; n1 = s_q1[i_next]; n2 = s_q2[i_next];
           const float dx = a0.x - q.fx, dy = a0.y - q.fy;
-          const float power = -0.5f * (a1.x * dx * dx + a1.z * dy * dy) - a1.y * dx * dy;
-          const float alpha = fminf(0.99f, a1.w * __expf(fminf(power, 0.0f)));
-          const bool valid = !done && power <= 0.0f && alpha >= ALPHA_MIN;
-          const float test_T = Tr * (1.0f - alpha);
-          const bool stop = valid && test_T < T_MIN;
-          const bool blend = valid && !stop;
-          const float w = blend ? alpha * Tr : 0.0f;
+          const float power2 = a1.x * dx * dx + a1.z * dy * dy + a1.y * dx * dy;  // log2 of the falloff
+          const float alpha = fminf(0.99f, a1.w * __builtin_amdgcn_exp2f(power2));
+          // a skipped Gaussian is a transparent one; a finished pixel carries Tr == 0, so `stop` (and nothing else)
+          // also covers "already done" and no separate flag is tested here
+          const float al = (power2 <= 0.0f && alpha >= ALPHA_MIN) ? alpha : 0.0f;
+          const float test_T = Tr * (1.0f - al);
+          const bool stop = test_T < T_MIN;
+          const float w = stop ? 0.0f : al * Tr;
           C0 += a2.x * w; C1 += a2.y * w; C2 += a2.z * w;
-          Tr = blend ? test_T : Tr;
-          last = blend ? (base - start) + (uint32_t)i2 + 1u : last;
-          done = done || stop;
+          last = (al > 0.0f && !stop) ? (base - start) + (uint32_t)i2 + 1u : last;
+          Tfin = stop ? Tfin : test_T;
+          Tr = stop ? 0.0f : test_T;
           if (!more) break;
         }
       }
-      if (__all(done)) break;
+      if (__all(Tr == 0.0f)) break;
     }
   }
   if (q.inside) {
     const size_t pix = (size_t)q.py * W + q.px, plane = (size_t)W * H;
-    final_T[pix] = Tr;
+    final_T[pix] = Tfin;
     n_contrib[pix] = last;
-    out_color[pix] = C0 + Tr * bg[0];
-    out_color[plane + pix] = C1 + Tr * bg[1];
-    out_color[2 * plane + pix] = C2 + Tr * bg[2];
+    out_color[pix] = C0 + Tfin * bg[0];
+    out_color[plane + pix] = C1 + Tfin * bg[1];
+    out_color[2 * plane + pix] = C2 + Tfin * bg[2];
   }
 }
 
@@ -235,10 +238,10 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
 
           const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
           const float dx = a0.x - q.fx, dy = a0.y - q.fy;
-          const float power = -0.5f * (a1.x * dx * dx + a1.z * dy * dy) - a1.y * dx * dy;
-          const float G = __expf(fminf(power, 0.0f));
+          const float power2 = a1.x * dx * dx + a1.z * dy * dy + a1.y * dx * dy;  // log2 of the falloff
+          const float G = __builtin_amdgcn_exp2f(fminf(power2, 0.0f));
           const float alpha = fminf(0.99f, a1.w * G);
-          const bool valid = contributor <= last && power <= 0.0f && alpha >= ALPHA_MIN;
+          const bool valid = contributor <= last && power2 <= 0.0f && alpha >= ALPHA_MIN;
           if (__any(valid)) {
             // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T, accum_rec, last_alpha and
             // last_color then evolve exactly as if it had been skipped (acc' = 0*lc + 1*acc), so the replay state needs no

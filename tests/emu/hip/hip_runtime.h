@@ -395,6 +395,7 @@ static inline float __uint_as_float(unsigned u) { return emu::from_bits<float>(e
 static inline float __int_as_float(int u) { return emu::from_bits<float>(emu::to_bits(u)); }
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
+#define __log2f(x) log2f(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __fsqrt_rn(float a) { return sqrtf(a); }
