@@ -117,18 +117,10 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
       if (i < cnt) hit = quad_hit(s_q0[i], s_q1[i], q);
       unsigned long long mask = __ballot(hit);
       if (mask) {
-        // Software-pipelined walk over the hit mask: the next record's three LDS reads are issued
-        // before the current record's math, so their latency hides behind ~25 VALU ops.  The math
-        // is predicated (no exec-mask branches): `valid`/`blend` select results instead.
-        int i_next = k + __ffsll(mask) - 1;
-        float4 n0 = s_q0[i_next], n1 = s_q1[i_next], n2 = s_q2[i_next];
-        for (;;) {
-          const float4 a0 = n0, a1 = n1, a2 = n2;
-          const int i2 = i_next;
-          mask &= mask - 1;
-          const bool more = mask != 0;
-          if (more) i_next = k + __ffsll(mask) - 1;
-          n0 = s_q0[i_next]; n1 = s_q1[i_next]; n2 = s_q2[i_next];
+        // Software-pipelined walk over the hit mask, unrolled by two with ping-pong record registers: the next
+        // record's LDS reads are issued before the current record's math and no register copies are needed to
+        // rotate the prefetch.  The math is predicated (no exec-mask branches).
+        auto blend_one = [&](const float4& a0, const float4& a1, const float4& a2, int i2) {
           const float dx = a0.x - q.fx, dy = a0.y - q.fy;
           const float power2 = a1.x * dx * dx + a1.z * dy * dy + a1.y * dx * dy;  // log2 of the falloff
           const float alpha = fminf(0.99f, a1.w * __builtin_amdgcn_exp2f(power2));
@@ -142,7 +134,22 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
           last = (al > 0.0f && !stop) ? (base - start) + (uint32_t)i2 + 1u : last;
           Tfin = stop ? Tfin : test_T;
           Tr = stop ? 0.0f : test_T;
-          if (!more) break;
+        };
+        int iA = k + __ffsll(mask) - 1, iB = iA;
+        float4 A0 = s_q0[iA], A1 = s_q1[iA], A2 = s_q2[iA], B0 = A0, B1 = A1, B2 = A2;
+        for (;;) {
+          mask &= mask - 1;
+          const bool moreB = mask != 0;
+          if (moreB) iB = k + __ffsll(mask) - 1;
+          B0 = s_q0[iB]; B1 = s_q1[iB]; B2 = s_q2[iB];
+          blend_one(A0, A1, A2, iA);
+          if (!moreB) break;
+          mask &= mask - 1;
+          const bool moreA = mask != 0;
+          if (moreA) iA = k + __ffsll(mask) - 1;
+          A0 = s_q0[iA]; A1 = s_q1[iA]; A2 = s_q2[iA];
+          blend_one(B0, B1, B2, iB);
+          if (!moreA) break;
         }
       }
       if (__all(Tr == 0.0f)) break;
@@ -224,18 +231,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
       if (i < cnt && boff + (uint32_t)i < wmax) hit = quad_hit(s_q0[i], s_q1[i], q);
       unsigned long long mask = __ballot(hit);
       if (mask) {
-        int i_next = k + 63 - __clzll((long long)mask);
-        float4 n0 = s_q0[i_next], n1 = s_q1[i_next], n2 = s_q2[i_next];
-        uint32_t nid = s_id[i_next];
-        for (;;) {
-          const float4 a0 = n0, a1 = n1, a2 = n2;
-          const uint32_t id = nid;
-          const int i2 = i_next;
-          mask &= ~(1ull << (i2 - k));
-          const bool more = mask != 0;
-          if (more) i_next = k + 63 - __clzll((long long)mask);
-          n0 = s_q0[i_next]; n1 = s_q1[i_next]; n2 = s_q2[i_next]; nid = s_id[i_next];
-
+        // back-to-front walk over the hit mask, unrolled by two with ping-pong record registers (see the forward kernel)
+        auto replay_one = [&](const float4& a0, const float4& a1, const float4& a2, const uint32_t id, const int i2) {
           const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
           const float dx = a0.x - q.fx, dy = a0.y - q.fy;
           const float power2 = a1.x * dx * dx + a1.z * dy * dy + a1.y * dx * dy;  // log2 of the falloff
@@ -283,7 +280,23 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
             mine = gs_sum_rows(mine);  // the four rows
             if (lane < 9) atomicAdd(reinterpret_cast<float*>(grads + id) + lane, mine);
           }
-          if (!more) break;
+        };
+        int iA = k + 63 - __clzll((long long)mask), iB = iA;
+        float4 A0 = s_q0[iA], A1 = s_q1[iA], A2 = s_q2[iA], B0 = A0, B1 = A1, B2 = A2;
+        uint32_t idA = s_id[iA], idB = idA;
+        for (;;) {
+          mask &= ~(1ull << (iA - k));
+          const bool moreB = mask != 0;
+          if (moreB) iB = k + 63 - __clzll((long long)mask);
+          B0 = s_q0[iB]; B1 = s_q1[iB]; B2 = s_q2[iB]; idB = s_id[iB];
+          replay_one(A0, A1, A2, idA, iA);
+          if (!moreB) break;
+          mask &= ~(1ull << (iB - k));
+          const bool moreA = mask != 0;
+          if (moreA) iA = k + 63 - __clzll((long long)mask);
+          A0 = s_q0[iA]; A1 = s_q1[iA]; A2 = s_q2[iA]; idA = s_id[iA];
+          replay_one(B0, B1, B2, idB, iB);
+          if (!moreA) break;
         }
       }
     }
