@@ -1,0 +1,26 @@
+"""CPU tier: edge cases on the emulated kernels."""
+from tests import edge_cases
+
+
+def test_giant_and_needle_gaussians(emu):
+    edge_cases.check_giant_and_needle_gaussians(emu)
+
+
+def test_invisible_opacity_and_behind_camera(emu):
+    edge_cases.check_invisible_opacity_and_behind_camera(emu)
+
+
+def test_saturating_opacity_early_termination(emu):
+    edge_cases.check_saturating_opacity_early_termination(emu)
+
+
+def test_mark_visible(emu):
+    edge_cases.check_mark_visible(emu)
+
+
+def test_python_flag_paths(emu):
+    edge_cases.check_python_flag_paths(emu)
+
+
+def test_create_from_pcd_scales(emu):
+    edge_cases.check_create_from_pcd_scales(emu)

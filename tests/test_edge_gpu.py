@@ -1,0 +1,29 @@
+"""GPU tier: edge cases through the C ABI on cuda:0."""
+from tests import edge_cases
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_giant_and_needle_gaussians(gpu):
+    edge_cases.check_giant_and_needle_gaussians(gpu)
+
+
+def test_invisible_opacity_and_behind_camera(gpu):
+    edge_cases.check_invisible_opacity_and_behind_camera(gpu)
+
+
+def test_saturating_opacity_early_termination(gpu):
+    edge_cases.check_saturating_opacity_early_termination(gpu)
+
+
+def test_mark_visible(gpu):
+    edge_cases.check_mark_visible(gpu)
+
+
+def test_python_flag_paths(gpu):
+    edge_cases.check_python_flag_paths(gpu)
+
+
+def test_create_from_pcd_scales(gpu):
+    edge_cases.check_create_from_pcd_scales(gpu)
