@@ -174,6 +174,21 @@ def main():
     except Exception:
         traffic = None
 
+    valu = None
+    try:  # VALU issue evidence from the committed SQ counter pass (profiles/r01_pmc_c3_SQ_counters.csv, separate run)
+        import csv
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_c3_SQ_counters.csv")) as fh:
+            for row in csv.DictReader(fh):
+                if row["kernel"] == "k_composite_bwd":
+                    insts, busy = float(row["mean_SQ_INSTS_VALU"]), float(row["mean_SQ_BUSY_CYCLES"])
+                    # a wave64 VALU op occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles);
+                    # 256 CUs x 4 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines
+                    valu = {"wave_insts_per_launch": insts, "salu_insts_per_launch": float(row["mean_SQ_INSTS_SALU"]),
+                            "simd_issue_busy_frac": insts * 4.0 / (1024.0 * busy / 32.0),
+                            "source": "profiles/r01_pmc_c3_SQ_counters.csv"}
+    except Exception:
+        valu = None
+
     cpu_baseline = None
     if cpu_trainer is not None:
         from oracle import gs_ref
@@ -204,7 +219,7 @@ def main():
             "psnr_before": psnr_before, "psnr_after_mean": mean_psnr,
             "roofline": {"kernel": "k_composite_bwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": bwd_ms, "launches": bwd_n,
-                         "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs),
+                         "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs), "valu": valu,
                          "note": "VALU-issue-bound in practice (SURVEY.md 8d): HBM fraction is reported as the contract asks; "
                                  "see DESIGN.md for the instruction-count roofline",
                          "composite_fwd": {"avg_kernel_ms": fwd_ms, "launches": fwd_n, "algorithmic_bytes_per_launch": fwd_bytes,
