@@ -21,8 +21,8 @@ constexpr int SORT_SMALL_CAP = 2048;  // small kernel: <= 8 keys per thread, 16 
 constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64 KiB LDS
 
 // ---- K2: exclusive scan of per-tile counts (T <= ~10^5 fits one workgroup comfortably)
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* __restrict__ count,
-                                                              uint32_t* __restrict__ start, int32_t* __restrict__ num_rendered) {
+// (count and start may alias: every thread reads an element before it overwrites it)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -47,12 +47,54 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
   }
   uint32_t run = wave_off + incl - local;
   for (int i = lo; i < hi; ++i) {
+    const uint32_t c = count[i];
     start[i] = run;
-    run += count[i];
+    run += c;
   }
   if (tid == 0) {
     start[T] = total;
     *num_rendered = (int32_t)total;
+  }
+}
+
+// ---- large exclusive scan (used for the kNN cell table, up to 2^24 entries): per-block sums -> scan of the sums by
+// k_scan_tiles -> per-block rescan with offset.  SCAN_CHUNK consecutive elements per workgroup, coalesced.
+constexpr int SCAN_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void k_scan_block_sums(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t s_red[4];
+  const int base = blockIdx.x * SCAN_CHUNK;
+  uint32_t acc = 0;
+  for (int i = threadIdx.x; i < SCAN_CHUNK; i += 256) acc += (base + i < n) ? in[base + i] : 0u;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(int n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ block_off,
+                                                    uint32_t* __restrict__ out) {
+  __shared__ uint32_t s_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t run = block_off[blockIdx.x];
+  for (int it = 0; it < SCAN_CHUNK / 256; ++it) {
+    const int i = blockIdx.x * SCAN_CHUNK + it * 256 + tid;
+    const uint32_t v = i < n ? in[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) woff += w < wave ? s_wave[w] : 0u;
+    if (i < n) out[i] = run + woff + incl - v;
+    run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
   }
 }
 
@@ -295,6 +337,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_large(int T, const 
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered) {
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered);
+  return 0;
+}
+
+// exclusive scan of n counters into out[0..n] (out[n] = total); block_sums: ceil(n / 4096) + 2 uint32 of scratch
+int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t* out, uint32_t* block_sums, int32_t* total) {
+  const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total);  // in place
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
 }
 

@@ -11,7 +11,7 @@
 // whose search has not terminated after KNN_MAX_RING shells, e.g. far outliers, and for tiny clouds).
 #include "common.h"
 
-int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*);
+int gs_launch_scan_large(hipStream_t, int, const uint32_t*, uint32_t*, uint32_t*, int32_t*);
 
 namespace {
 
@@ -158,7 +158,7 @@ int knn_resolution(int N) {
 }
 
 struct KnnLayout {
-  size_t bbox, count, cursor, start, sorted, total;
+  size_t bbox, count, cursor, start, sorted, block_sums, total;
   int G;
   explicit KnnLayout(int N) {
     G = knn_resolution(N);
@@ -169,6 +169,7 @@ struct KnnLayout {
     cursor = o; o += gs_align(cells * 4);
     start = o; o += gs_align((cells + 1) * 4);
     sorted = o; o += gs_align(n * sizeof(float4));
+    block_sums = o; o += gs_align((cells / 4096 + 4) * 4);
     total = o;
   }
 };
@@ -199,7 +200,7 @@ int mi355gs_knn_dist2(void* stream_, int N, const float* points, float* mean_dis
   hipLaunchKernelGGL(k_knn_count, dim3(blocks), dim3(256), 0, stream, N, L.G, points, (const float*)bbox, count);
   GS_CHECK_LAUNCH("knn_count");
   // exclusive scan over the cell table (cells that the tight per-axis grid does not use stay 0)
-  gs_launch_scan_tiles(stream, cells, count, start, (int32_t*)(w + L.total));
+  gs_launch_scan_large(stream, cells + 1, count, start, (uint32_t*)(w + L.block_sums), (int32_t*)(w + L.total));
   GS_CHECK_LAUNCH("knn_scan");
   hipLaunchKernelGGL(k_knn_scatter, dim3(blocks), dim3(256), 0, stream, N, L.G, points, (const float*)bbox, (const uint32_t*)start,
                      cursor, sorted);
