@@ -113,12 +113,19 @@ def main():
 
     # ---- the same loop with the reference's two host read-backs per iteration (loss.item(), instance count)
     n_sync = min(args.steps, 100)
+    for _ in range(5):
+        train_iteration(st, fused_step=True)
     sync()
     ts = time.perf_counter()
     for _ in range(n_sync):
-        train_iteration(st)
+        train_iteration(st, fused_step=True)   # loss read back on the host every iteration, as in the reference
     sync()
     sync_loop_its = n_sync / (time.perf_counter() - ts)
+    ts = time.perf_counter()
+    for _ in range(n_sync):
+        train_iteration(st)                    # op-by-op autograd path with both of the reference's read-backs
+    sync()
+    autograd_loop_its = n_sync / (time.perf_counter() - ts)
 
     # ---- rasterize ms/frame (reference render.py:172-186 methodology, with an explicit synchronize)
     with torch.no_grad():
@@ -215,7 +222,7 @@ def main():
                                    f"iterations), one scene per GPU", "views": V, "gaussians": P, "width": res, "height": res,
                        "parallelism": f"scene-per-gpu x{world}"},
             "rasterize_ms_per_frame": raster_ms,
-            "iters_per_sec_with_reference_host_syncs": sync_loop_its, "run_ahead_window_replays": ra.replays,
+            "iters_per_sec_with_per_iteration_loss_readback": sync_loop_its, "iters_per_sec_autograd_path": autograd_loop_its, "run_ahead_window_replays": ra.replays,
             "psnr_before": psnr_before, "psnr_after_mean": mean_psnr,
             "roofline": {"kernel": "k_composite_bwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": bwd_ms, "launches": bwd_n,

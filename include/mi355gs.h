@@ -200,6 +200,10 @@ void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float
 int mi355gs_trainer_step(void* trainer, void* stream, int view, const float* gt_image, const float* projmatrix, float tanfovx,
                          float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
                          float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out);
+/* PerPointAdam over all 7 groups with the gradients left by the last mi355gs_trainer_step(..., do_optimizer_step = 0):
+ * lets a caller inspect the loss / instance count of an iteration before committing its update. */
+int mi355gs_trainer_optimizer_step(void* trainer, void* stream, const float* lr, const int32_t* step, float beta1, float beta2,
+                                   float eps);
 void mi355gs_trainer_destroy(void* trainer);
 
 #ifdef __cplusplus

@@ -82,6 +82,16 @@ __global__ __launch_bounds__(256) void k_trainer_prologue(float4* __restrict__ g
   if (gid < 8) adam_scratch[gid] = 0.f;
 }
 
+int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t* step, float beta1, float beta2, float eps) {
+  const int P = t->P;
+  const int64_t numel[7] = {3LL * P, 3LL * P, 45LL * P, (int64_t)P, 3LL * P, 4LL * P, 7LL * t->V};
+  const int32_t row[7] = {3, 1, 1, 1, 1, 1, 1};
+  float* params[7] = {t->xyz, t->f_dc, t->f_rest, t->opacity, t->scaling, t->rotation, t->poses};
+  const float* grads[7] = {t->g_xyz, t->g_fdc, t->g_frest, t->g_opacity, t->g_scaling, t->g_rot, t->g_poses};
+  const float* pplr[7] = {t->pplr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch);
+}
+
 __global__ void k_trainer_consts(float* consts) {
   const int i = threadIdx.x;
   if (i < 16) consts[i] = (i % 5 == 0) ? 1.f : 0.f;  // identity view matrix
@@ -178,17 +188,19 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_
                                   t->pose_scratch)))
     return rc;
   // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
-  if (do_optimizer_step) {
-    const int64_t numel[7] = {3LL * P, 3LL * P, 45LL * P, (int64_t)P, 3LL * P, 4LL * P, 7LL * t->V};
-    const int32_t row[7] = {3, 1, 1, 1, 1, 1, 1};
-    float* params[7] = {t->xyz, t->f_dc, t->f_rest, t->opacity, t->scaling, t->rotation, t->poses};
-    const float* grads[7] = {t->g_xyz, t->g_fdc, t->g_frest, t->g_opacity, t->g_scaling, t->g_rot, t->g_poses};
-    const float* pplr[7] = {t->pplr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if ((rc = mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step,
-                                      t->adam_scratch)))
-      return rc;
-  }
+  if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps);
   return MI355GS_OK;
+}
+
+int mi355gs_trainer_optimizer_step(void* handle, void* stream_, const float* lr, const int32_t* step, float beta1, float beta2,
+                                   float eps) {
+  Trainer* t = (Trainer*)handle;
+  if (!t || !lr || !step) return MI355GS_EINVAL;
+  // gate flags of the gradients produced by the preceding mi355gs_trainer_step(..., do_optimizer_step = 0) are still in place
+  g_fused.gate = t->adam_scratch;
+  const int rc = trainer_adam(t, (hipStream_t)stream_, lr, step, beta1, beta2, eps);
+  g_fused = GsFusedStepHooks();
+  return rc;
 }
 
 }  // extern "C"

@@ -49,6 +49,8 @@ class TrainState:
     viewpoint_stack: list = field(default_factory=list)
     rng: random.Random = field(default_factory=lambda: random.Random(0))
     last_loss: Optional[torch.Tensor] = None
+    _trainer: object = None
+    _loss_slot: Optional[torch.Tensor] = None
 
 
 def setup_training(scene: PointmapScene, device, opt: OptimizationParams | None = None, pipe: PipelineParams | None = None,
@@ -130,8 +132,49 @@ def _optimizer_step(st: TrainState):
             st.gaussians.optimizer.zero_grad(set_to_none=True)
 
 
-def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = True):
-    """One pass of reference train.py:140-211, with the reference's per-iteration `loss.item()` (sync_loss=True)."""
+def _fused_synced_iteration(st: TrainState):
+    """The reference's loop shape — loss read back on the host every iteration — on the one-call fused step: forward +
+    backward are enqueued, loss and instance count come back in ONE read-back, and only then is the optimizer update
+    committed; an iteration whose instance count exceeded the buffers is redone on the exact-sizing autograd path."""
+    tr = getattr(st, "_trainer", None)
+    if tr is None:
+        with torch.no_grad():
+            for cam in st.cameras:  # exact instance counts of every view size the fixed buffers
+                with binning_hint(("train", cam.uid)):
+                    render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
+        need = max(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
+        tr = st._trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
+        st._loss_slot = torch.zeros(1, dtype=torch.float32, device=tr.dev)
+    saved = (st.iteration, list(st.viewpoint_stack), st.rng.getstate(),
+             [st.gaussians.optimizer.state[p]["step"] for p in tr.params], [g["lr"] for g in st.gaussians.optimizer.param_groups])
+    cam = tr.step(st._loss_slot, defer_optimizer=True, verify_async=False)
+    loss, r = torch.cat([st._loss_slot, tr.num_rendered.to(torch.float32)]).tolist()   # the iteration's one host read-back
+    BinningPolicy.known[("train", cam.uid)] = int(r)
+    if r > tr.capacity:   # dropped instances: discard, redo exactly, and grow the buffers for the next iterations
+        st.iteration, st.viewpoint_stack = saved[0], saved[1]
+        st.rng.setstate(saved[2])
+        for p, s0 in zip(tr.params, saved[3]):
+            st.gaussians.optimizer.state[p]["step"] = s0
+        for g, lr in zip(st.gaussians.optimizer.param_groups, saved[4]):
+            g["lr"] = lr
+        tr.close()
+        st._trainer = None
+        return None
+    tr.apply_optimizer()
+    if r * 1.2 + 1024 > tr.capacity:
+        tr.close()
+        st._trainer = None
+    return loss
+
+
+def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = True, fused_step: bool = False):
+    """One pass of reference train.py:140-211, with the reference's per-iteration `loss.item()` (sync_loss=True).
+    fused_step=True takes the one-call library step when the configuration allows it (same results)."""
+    if fused_step and sync_loss and fused_loss and (st.iteration + 1) % 1000 != 0 and FusedTrainer.supported(st):
+        out = _fused_synced_iteration(st)
+        if out is not None:
+            st.last_loss = out
+            return out
     loss = _forward_backward_step(st, fused_loss)
     out = loss.item() if sync_loss else loss
     _optimizer_step(st)
@@ -192,8 +235,9 @@ class FusedTrainer:
 
     __del__ = close
 
-    def step(self, loss_slot: torch.Tensor):
-        """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1])."""
+    def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True):
+        """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1]).
+        defer_optimizer: stop after backward; `apply_optimizer()` then commits the update (or the caller discards it)."""
         st = self.st
         st.iteration += 1
         it, g, opt = st.iteration, st.gaussians, st.opt
@@ -214,7 +258,10 @@ class FusedTrainer:
             ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), _lib.ptr(st.gt_images[cam.uid]),
             _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(bg),
             F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"]), float(opt.lambda_dssim),
-            1 if do_opt else 0, _lib.ptr(loss_slot), _lib.ptr(self.num_rendered)), "trainer_step")
+            1 if (do_opt and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(self.num_rendered)), "trainer_step")
+        self._pending_opt = (F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"])) if do_opt else None
+        if not verify_async:
+            return cam
         # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy)
         if self.dev.type == "cuda":
             pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
@@ -224,6 +271,14 @@ class FusedTrainer:
         else:
             pinned, ev = self.num_rendered.clone(), None
         BinningPolicy.pending.append((ev, pinned, self.capacity, ("train", cam.uid), it))
+        return cam
+
+    def apply_optimizer(self):
+        if self._pending_opt is not None:
+            lr, steps, b1, b2, eps = self._pending_opt
+            _lib.check(_lib.lib().mi355gs_trainer_optimizer_step(ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), lr, steps,
+                                                                 b1, b2, eps), "trainer_optimizer_step")
+            self._pending_opt = None
 
 
 # ---- run-ahead variant: same arithmetic, no host synchronisation inside the iteration ------------------------

@@ -282,3 +282,59 @@ def check_fused_train_step_equals_autograd_path(dev, iters=6, Wm=12, W=32):
                 assert float((a - b).norm() / (b.norm() + 1e-12)) <= tol, (n, k, float((a - b).norm() / (b.norm() + 1e-12)))
     finally:
         BinningPolicy.reset("exact")
+
+
+def check_run_ahead_crosses_sh_degree_step(dev, Wm=10, W=24):
+    """Iteration 1000 raises the SH degree (reference train.py:148-149): the fused step only covers degree 0, so the
+    driver must hand over to the autograd path there and keep going; the last iteration skips the optimizer."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import FusedTrainer, RunAhead, setup_training
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=13)
+    st = setup_training(sc, dev, opt=OptimizationParams(iterations=1003, pp_optimizer=True, optim_pose=True))
+    try:
+        st.iteration = 996
+        ra = RunAhead(st, window=2)
+        assert ra.trainer is not None
+        for _ in range(7):          # iterations 997..1003
+            ra.step()
+        ema = ra.flush()
+        assert st.iteration == 1003 and st.gaussians.active_sh_degree == 1 and not FusedTrainer.supported(st)
+        assert ema == ema and ema > 0  # finite
+        s = st.gaussians.optimizer.state[st.gaussians._xyz]["step"]
+        assert s == 6, s            # 7 iterations, the last one (== opt.iterations) without an optimizer step
+    finally:
+        BinningPolicy.reset("exact")
+
+
+def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=False, Wm=12, W=32):
+    """train_iteration(fused_step=True): reference loop shape (loss read back every iteration) on the one-call step,
+    optimizer committed only after the read-back; must equal the autograd loop, also when every iteration overflows
+    its instance buffers and is redone exactly."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training, train_iteration
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=17)
+    mk = lambda: setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True))
+    names = ("_xyz", "_features_dc", "_opacity", "_scaling", "P")
+    cuda = torch.device(dev).type == "cuda"
+    try:
+        BinningPolicy.reset("exact")
+        a = mk()
+        la = [train_iteration(a) for _ in range(iters)]
+        if force_overflow:
+            BinningPolicy.slack, BinningPolicy.pad = 0.5, 0
+        b = mk()
+        lb = [train_iteration(b, fused_step=True) for _ in range(iters)]
+        if not force_overflow:
+            assert b._trainer is not None
+        for x, y in zip(la, lb):
+            assert abs(x - y) <= (5e-3 if cuda else 1e-6) * max(1e-2, abs(x)), (la, lb)
+        for n in names:
+            p, q = getattr(a.gaussians, n).detach().cpu(), getattr(b.gaussians, n).detach().cpu()
+            assert float((p - q).norm() / (p.norm() + 1e-12)) <= (2e-2 if cuda else 1e-5), n
+    finally:
+        BinningPolicy.slack, BinningPolicy.pad = 1.5, 16384
+        BinningPolicy.reset("exact")

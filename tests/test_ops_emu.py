@@ -49,6 +49,15 @@ def test_fused_train_step_equals_autograd_path(emu):
     ops_util.check_fused_train_step_equals_autograd_path(emu)
 
 
+def test_run_ahead_crosses_sh_degree_step(emu):
+    ops_util.check_run_ahead_crosses_sh_degree_step(emu)
+
+
+@pytest.mark.parametrize("overflow", [False, True])
+def test_fused_synced_loop_equals_autograd_loop(emu, overflow):
+    ops_util.check_fused_synced_loop_equals_autograd_loop(emu, force_overflow=overflow)
+
+
 def test_adam_matches_reference_trajectory(emu):
     ops_util.check_adam_golden(emu)
 

@@ -45,6 +45,15 @@ def test_fused_train_step_equals_autograd_path(gpu):
     ops_util.check_fused_train_step_equals_autograd_path(gpu, iters=12, Wm=48, W=96)
 
 
+def test_run_ahead_crosses_sh_degree_step(gpu):
+    ops_util.check_run_ahead_crosses_sh_degree_step(gpu)
+
+
+@pytest.mark.parametrize("overflow", [False, True])
+def test_fused_synced_loop_equals_autograd_loop(gpu, overflow):
+    ops_util.check_fused_synced_loop_equals_autograd_loop(gpu, force_overflow=overflow, iters=12, Wm=48, W=96)
+
+
 def test_adam_matches_reference_trajectory(gpu):
     ops_util.check_adam_golden(gpu)
 
