@@ -1,6 +1,6 @@
 """Ad-hoc measurement of the other BASELINE configs (not bench lines): C2 forward-only, C4 1M/1080p."""
 import math, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from instantsplat_amd.synthetic import syn_blob, syn_pointmap
 from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, keep_last_frame, last_frame_stats
 from tests.util import settings_for

@@ -1,6 +1,6 @@
 """Ad-hoc GPU probe (not part of the product): time the raster stages at the BASELINE shapes."""
 import math, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from instantsplat_amd.synthetic import syn_blob
 from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from tests.util import settings_for
