@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int BATCH = 256;
+constexpr int BATCH = 512;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_MIN = 0.0001f;
 
@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
     if (lane == 0) s_done[wave] = wave_done;
     __syncthreads();  // also fences the previous batch's LDS reads against the stores below
     if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
-    const uint32_t j = base + tid;
-    if (j < end) {
-      const GsRec* r = recs + list[j];
-      s_q0[tid] = r->q0; s_q1[tid] = r->q1; s_q2[tid] = r->q2;
+#pragma unroll
+    for (int sl = tid; sl < BATCH; sl += 256) {
+      const uint32_t j = base + sl;
+      if (j < end) {
+        const GsRec* r = recs + list[j];
+        s_q0[sl] = r->q0; s_q1[sl] = r->q1; s_q2[sl] = r->q2;
+      }
     }
     __syncthreads();
     if (wave_done) continue;
@@ -215,11 +218,13 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
   for (uint32_t bi = nb; bi-- > 0;) {
     const uint32_t boff = bi * BATCH;  // contributor index (0-based) of this batch's first instance
     __syncthreads();
-    const uint32_t j = start + boff + tid;
-    if (boff + tid < tile_max) {
-      const uint32_t id = list[j];
-      const GsRec* r = recs + id;
-      s_id[tid] = id; s_q0[tid] = r->q0; s_q1[tid] = r->q1; s_q2[tid] = r->q2;
+#pragma unroll
+    for (int sl = tid; sl < BATCH; sl += 256) {
+      if (boff + sl < tile_max) {
+        const uint32_t id = list[start + boff + sl];
+        const GsRec* r = recs + id;
+        s_id[sl] = id; s_q0[sl] = r->q0; s_q1[sl] = r->q1; s_q2[sl] = r->q2;
+      }
     }
     __syncthreads();
     if (boff >= wmax) continue;  // nothing in this batch is in front of any of this wave's pixels' last contributor
