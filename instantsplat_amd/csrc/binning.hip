@@ -230,7 +230,8 @@ __device__ __forceinline__ void bitonic_sort_any(KeyPtr a, int n, int tid, int n
 // so compare-exchange partners at distance < E sit in the same thread, at distance < 64*E in the same wave
 // (one 64-bit lane shuffle, no barrier) and only the last two distance bits (across the 4 waves) go through
 // LDS: 3 barrier stages in total instead of one per network stage (55 for 1024 keys).
-// Slots >= n hold 0xFFFF... (sorts last, never written back).
+// Slots >= n hold 0xFFFF... (sorts last, never written back).  Keys are distinct (they end in the Gaussian index), so
+// "the lower position keeps the minimum" is one 64-bit compare: take the partner's key iff (partner < mine) == lower.
 template <int E>
 __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
                                                uint32_t s, int n) {
@@ -257,7 +258,7 @@ __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, co
         for (int e = 0; e < E; ++e) other[e] = __shfl_xor(k[E - 1 - e], lm);
         const bool lower = ((base) & (kk >> 1)) == 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = other[e]; k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = other[e]; k[e] = ((b < a) == lower) ? b : a; }
       } else {
         __syncthreads();
 #pragma unroll
@@ -265,7 +266,7 @@ __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, co
         __syncthreads();
         const bool lower = (base & (kk >> 1)) == 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ m]; k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ m]; k[e] = ((b < a) == lower) ? b : a; }
       }
     }
     // ---- disperse stages: partner = i ^ d
@@ -280,7 +281,7 @@ __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, co
         const int lm = d / E;
         const bool lower = (base & d) == 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = __shfl_xor(a, lm); k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = __shfl_xor(a, lm); k[e] = ((b < a) == lower) ? b : a; }
       } else {
         __syncthreads();
 #pragma unroll
@@ -288,7 +289,7 @@ __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, co
         __syncthreads();
         const bool lower = (base & d) == 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ d]; k[e] = lower ? (a < b ? a : b) : (a > b ? a : b); }
+        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ d]; k[e] = ((b < a) == lower) ? b : a; }
       }
     }
   }
