@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2, help="CPU-baseline iterations (bounded sample); 0 disables")
     ap.add_argument("--pointmap", type=int, default=256, help="pointmap edge (Gaussians = 3 * edge^2)")
     ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--sh-degree", type=int, default=0,
+                    help="active SH degree during the run (exploratory; the reference's 1000-iteration schedule trains at 0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,6 +66,9 @@ def main():
     opt = OptimizationParams(iterations=total_iters, pp_optimizer=True, optim_pose=True)
     st = setup_training(scene, dev, opt=opt)
     P = st.gaussians.get_xyz.shape[0]
+    st.gaussians.active_sh_degree = args.sh_degree
+    if args.sh_degree:
+        args.cpu_iters = 0   # the CPU trainer restates the degree-0 schedule only
 
     # ---- CPU baseline state is cloned BEFORE the GPU run changes the parameters
     cpu_trainer = None
@@ -218,8 +223,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: {V}-view sparse scene, {P} Gaussians, {res}x{res}, joint pose+Gaussian "
-                                   f"optimisation (PerPointAdam, lambda_dssim 0.2, SH degree 0 as in the reference's first 1000 "
-                                   f"iterations), one scene per GPU", "views": V, "gaussians": P, "width": res, "height": res,
+                                   f"optimisation (PerPointAdam, lambda_dssim 0.2, SH degree {args.sh_degree}"
+                                   f"{' as in the reference first 1000 iterations' if args.sh_degree == 0 else ' (exploratory)'}"
+                                   f"), one scene per GPU", "views": V, "gaussians": P, "width": res, "height": res,
                        "parallelism": f"scene-per-gpu x{world}"},
             "rasterize_ms_per_frame": raster_ms,
             "iters_per_sec_with_per_iteration_loss_readback": sync_loop_its, "iters_per_sec_autograd_path": autograd_loop_its, "run_ahead_window_replays": ra.replays,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 1
+#define MI355GS_ABI_VERSION 2
 
 /* error codes */
 #define MI355GS_OK 0
@@ -58,14 +58,17 @@ size_t mi355gs_raster_binning_bytes(int64_t num_instances);
 /* Stage 1: per-Gaussian projection (frustum cull, EWA 2-D covariance, conic, radius, tile rect,
  * SH -> RGB), per-tile instance counts and their exclusive scan.
  *   means3D[P,3] scales[P,3] rotations[P,4] (w,x,y,z, used un-normalised) opacities[P]
- *   shs[P,M,3] (D = active degree 0..3, M = coefficients stored per Gaussian) or colors_precomp[P,3]
+ *   shs[P,M,3] (D = active degree 0..3, M = coefficients stored per Gaussian) or colors_precomp[P,3];
+ *   split SH storage (the reference's own parameter layout, scene/gaussian_model.py:168-169): when shs_rest is
+ *   non-null, shs is the DC coefficient [P,1,3] and shs_rest the remaining M-1 coefficients [P,M-1,3] — no
+ *   cat(f_dc, f_rest) (scene/gaussian_model.py:114-117) has to be materialised
  *   cov3D_precomp[P,6] replaces scales/rotations when non-null
  *   viewmatrix[16], projmatrix[16]: row-vector convention, i.e. the transposed matrices the
  *     reference stores (scene/cameras.py:54-55) in flat memory; campos[3]
  *   radii[P] (int32, output); num_rendered: device int32, receives the instance count R */
 int mi355gs_raster_forward_preprocess(
     void* stream, int P, int D, int M, int W, int H,
-    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tanfovx, float tanfovy, int prefiltered,
@@ -80,20 +83,20 @@ int mi355gs_raster_forward_render(
 
 /* Backward of both stages.  dL_dpix[3,H,W] in; gradients out (all written, zero where unused):
  *   dL_dmeans3D[P,3] dL_dmeans2D[P,3] (x,y in the reference's NDC-scaled screen units, z = 0)
- *   dL_dshs[P,M,3] or dL_dcolors[P,3] (the other may be null), dL_dopacities[P],
+ *   dL_dshs[P,M,3] (split storage: dL_dshs[P,1,3] + dL_dshs_rest[P,M-1,3]) or dL_dcolors[P,3], dL_dopacities[P],
  *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
  *   geom/tiles/binning/capacity/radii: exactly what the forward of this frame used and produced
  *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes */
 size_t mi355gs_raster_grad_scratch_bytes(int P);
 int mi355gs_raster_backward(
     void* stream, int P, int D, int M, int W, int H, const float* bg,
-    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tanfovx, float tanfovy,
     const void* geom, const void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
     const float* dL_dpix, void* grad_scratch,
-    float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
+    float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities,
     float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int debug);
 
 /* Visibility test only — replaces diff_gaussian_rasterization._C.mark_visible
@@ -183,8 +186,9 @@ int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* ro
 /* ------------------------------------------------------------------------------------------------
  * Whole train iteration in one call
  * replaces: the body of the loop at reference train.py:140-211 — render(camera_pose=P[view]) -> (1-l)*L1 +
- *   l*(1-SSIM) -> backward -> PerPointAdam.step() — for the configuration the reference's scripts run: SH degree 0
- *   (first 1000 iterations), scale/rotation covariance, --pp_optimizer --optim_pose.  17 launches, no host sync.
+ *   l*(1-SSIM) -> backward -> PerPointAdam.step() — for the configuration the reference's scripts run: SH colours
+ *   (active degree sh_degree 0..3 over 16 stored coefficients), scale/rotation covariance, --pp_optimizer
+ *   --optim_pose.  17 launches, no host sync.
  *   Parameter tensors use the reference's GaussianModel layouts (scene/gaussian_model.py:166-171): xyz[P,3],
  *   f_dc[P,1,3], f_rest[P,15,3], opacity[P,1], scaling[P,3], rotation[P,4], poses[V,7]; exp_avg/exp_avg_sq: host
  *   arrays of 7 device pointers in the optimizer's group order (xyz, f_dc, f_rest, opacity, scaling, rotation, pose).
@@ -197,8 +201,8 @@ size_t mi355gs_trainer_workspace_bytes(int P, int W, int H, int V, int64_t capac
 void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float* xyz, float* f_dc, float* f_rest, float* opacity,
                              float* scaling, float* rotation, float* poses, float* const* exp_avg, float* const* exp_avg_sq,
                              const float* per_point_lr, void* workspace);
-int mi355gs_trainer_step(void* trainer, void* stream, int view, const float* gt_image, const float* projmatrix, float tanfovx,
-                         float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
+int mi355gs_trainer_step(void* trainer, void* stream, int view, int sh_degree, const float* gt_image, const float* projmatrix,
+                         float tanfovx, float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
                          float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out);
 /* PerPointAdam over all 7 groups with the gradients left by the last mi355gs_trainer_step(..., do_optimizer_step = 0):
  * lets a caller inspect the loss / instance count of an iteration before committing its update. */

@@ -25,11 +25,11 @@ _SIGNATURES = {
     "mi355gs_raster_tiles_bytes": (c_size_t, [c_int, c_int]),
     "mi355gs_raster_binning_bytes": (c_size_t, [c_int64]),
     "mi355gs_raster_grad_scratch_bytes": (c_size_t, [c_int]),
-    "mi355gs_raster_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P,
+    "mi355gs_raster_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P,
                                                   _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_forward_render": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int]),
-    "mi355gs_raster_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
-                                        _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "mi355gs_raster_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
+                                        _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                         c_int]),
     "mi355gs_raster_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),
@@ -47,7 +47,7 @@ _SIGNATURES = {
     "mi355gs_pose_backward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_trainer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
     "mi355gs_trainer_create": (c_void_p, [c_int, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mi355gs_trainer_step": (c_int, [_P, _P, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
+    "mi355gs_trainer_step": (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
                                      c_int, _P, _P]),
     "mi355gs_trainer_optimizer_step": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float]),
     "mi355gs_trainer_destroy": (None, [_P]),

@@ -4,12 +4,12 @@
 #include "common.h"
 
 // launchers implemented next to their kernels
-int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*,
+int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*,
                              const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*);
 int gs_launch_count_tiles(hipStream_t, int, int, int, const uint2*, uint32_t*);
-int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, int, int,
+int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, int, int,
                              const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
-                             float*, float*, float*, float*, float*, float*, float*);
+                             float*, float*, float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
 int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*);
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t);
@@ -85,7 +85,7 @@ size_t mi355gs_raster_binning_bytes(int64_t n) { return BinningLayout(n).total; 
 size_t mi355gs_raster_grad_scratch_bytes(int P) { return gs_align((size_t)(P > 0 ? P : 1) * sizeof(GsGrad)); }
 
 int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
-                                      const float* colors_precomp, const float* opacities, const float* scales,
+                                      const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
                                       const float* viewmatrix, const float* projmatrix, const float* campos, float tanfovx,
                                       float tanfovy, int prefiltered, int32_t* radii, void* geom, void* tiles,
@@ -97,6 +97,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   if (P > 0 && (!means3D || !opacities || !radii)) return MI355GS_EINVAL;
   if (P > 0 && ((shs == nullptr) == (colors_precomp == nullptr))) return MI355GS_EINVAL;
   if (P > 0 && shs && M < (D + 1) * (D + 1)) return MI355GS_EINVAL;
+  if (shs_rest && (!shs || M < 2)) return MI355GS_EINVAL;
   if (P > 0 && !cov3D_precomp && (!scales || !rotations)) return MI355GS_EINVAL;
   const GeomLayout gl(P);
   const TilesLayout tl(W, H);
@@ -105,7 +106,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   // count + cursor are adjacent
   if (!g_fused.skip_memsets && hipMemsetAsync(t + tl.count, 0, tl.start - tl.count, stream) != hipSuccess) return MI355GS_ELAUNCH;
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
-  gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
+  gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
                            (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped));
   GS_CHECK_LAUNCH("preprocess_fwd");
   gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
@@ -141,12 +142,12 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
 }
 
 int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, const float* bg, const float* means3D,
-                            const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                            const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                             float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                             const float* projmatrix, const float* campos, float tanfovx, float tanfovy, const void* geom,
                             const void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
                             const float* dL_dpix, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
-                            float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                            float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                             int debug) {
   (void)opacities; (void)colors_precomp;
   hipStream_t stream = (hipStream_t)stream_;
@@ -155,6 +156,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   if (P > 0 && (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities)) return MI355GS_EINVAL;
   const int use_shs = shs != nullptr, use_cov = cov3D_precomp != nullptr;
   if (P > 0 && use_shs && !dL_dshs) return MI355GS_EINVAL;
+  if (shs_rest && !use_shs) return MI355GS_EINVAL;
   if (P > 0 && !use_shs && !dL_dcolors) return MI355GS_EINVAL;
   if (P > 0 && !use_cov && (!scales || !rotations || !dL_dscales || !dL_drotations)) return MI355GS_EINVAL;
   if (P > 0 && use_cov && !dL_dcov3D) return MI355GS_EINVAL;
@@ -179,10 +181,11 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
     GS_CHECK_LAUNCH("composite_bwd");
   }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
-  gs_launch_preprocess_bwd(stream, P, D, M, means3D, shs, scales, rotations, use_shs, use_cov, cp, radii,
+  gs_launch_preprocess_bwd(stream, P, D, M, means3D, shs, shs_rest, scales, rotations, use_shs, use_cov, cp, radii,
                            (const GsRec*)(g + gl.rec), (const float*)(g + gl.cov3D), (const uint8_t*)(g + gl.clamped), grads, dL_dmeans3D, dL_dmeans2D,
-                           dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D,
-                           (g_fused.gate && g_fused.gate_sh >= 0) ? g_fused.gate + g_fused.gate_sh : nullptr);
+                           dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D,
+                           (g_fused.gate && g_fused.gate_sh >= 0) ? g_fused.gate + g_fused.gate_sh : nullptr,
+                           (g_fused.gate && g_fused.gate_sh_rest >= 0) ? g_fused.gate + g_fused.gate_sh_rest : nullptr);
   GS_CHECK_LAUNCH("preprocess_bwd");
   return MI355GS_OK;
 }

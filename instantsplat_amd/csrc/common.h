@@ -159,6 +159,6 @@ void gs_log_error(const char* where, const char* what);
 struct GsFusedStepHooks {
   bool skip_memsets = false;
   float* gate = nullptr;   // device float[8] or null
-  int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_pose = -1;
+  int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_sh_rest = -1, gate_pose = -1;
 };
 extern thread_local GsFusedStepHooks g_fused;

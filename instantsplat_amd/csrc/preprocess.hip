@@ -102,7 +102,7 @@ __device__ __forceinline__ float3 sh_eval(const float* sh /*[M,3]*/, float x, fl
 // K1 forward: projection + per-tile instance counting
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_preprocess_fwd(
-    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, CamParams cp,
     int32_t* __restrict__ radii, GsRec* __restrict__ recs, float* __restrict__ cov3Ds, uint2* __restrict__ rects,
@@ -167,12 +167,26 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     float dx = m.x - cp.campos[0], dy = m.y - cp.campos[1], dz = m.z - cp.campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     dx *= inv; dy *= inv; dz *= inv;
-    const float* sh = shs + (size_t)i * M * 3;
     float3 v;
-    if (D == 0) v = sh_eval<1>(sh, dx, dy, dz);
-    else if (D == 1) v = sh_eval<4>(sh, dx, dy, dz);
-    else if (D == 2) v = sh_eval<9>(sh, dx, dy, dz);
-    else v = sh_eval<16>(sh, dx, dy, dz);
+    if (shs_rest == nullptr) {
+      const float* sh = shs + (size_t)i * M * 3;
+      if (D == 0) v = sh_eval<1>(sh, dx, dy, dz);
+      else if (D == 1) v = sh_eval<4>(sh, dx, dy, dz);
+      else if (D == 2) v = sh_eval<9>(sh, dx, dy, dz);
+      else v = sh_eval<16>(sh, dx, dy, dz);
+    } else {
+      // split storage (the reference's own parameter layout: _features_dc [P,1,3] + _features_rest [P,M-1,3]):
+      // no cat(f_dc, f_rest) has to be materialised for the rasterizer
+      float shl[48];
+      const int nbl = (D + 1) * (D + 1);
+      shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
+      const float* rest = shs_rest + (size_t)i * (M - 1) * 3;
+      for (int k = 3; k < nbl * 3; ++k) shl[k] = rest[k - 3];
+      if (D == 0) v = sh_eval<1>(shl, dx, dy, dz);
+      else if (D == 1) v = sh_eval<4>(shl, dx, dy, dz);
+      else if (D == 2) v = sh_eval<9>(shl, dx, dy, dz);
+      else v = sh_eval<16>(shl, dx, dy, dz);
+    }
     v.x += 0.5f; v.y += 0.5f; v.z += 0.5f;
     clamp_bits = (uint8_t)((v.x < 0.f ? 1 : 0) | (v.y < 0.f ? 2 : 0) | (v.z < 0.f ? 4 : 0));
     rgb = make_float3(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f));
@@ -254,12 +268,12 @@ __device__ __forceinline__ void sh_backward(const float* sh, float* gsh, float x
 }
 
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
-    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
-    const float* __restrict__ rotations, int use_shs, int use_cov_precomp, CamParams cp, const int32_t* __restrict__ radii,
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+    const float* __restrict__ scales, const float* __restrict__ rotations, int use_shs, int use_cov_precomp, CamParams cp, const int32_t* __restrict__ radii,
     const GsRec* __restrict__ recs, const float* __restrict__ cov3Ds, const uint8_t* __restrict__ clamped, const GsGrad* __restrict__ grads,
-    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ sh_gate) {
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ sh_gate, float* __restrict__ sh_rest_gate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const bool vis = radii[i] > 0;
@@ -284,7 +298,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
   const float3 gcol = make_float3(g.g1.z, g.g1.w, g.g2.x);
   const int nb = (D + 1) * (D + 1);
-  float* gsh = dL_dshs ? dL_dshs + (size_t)i * M * 3 : nullptr;
+  const bool split = shs_rest != nullptr;
+  float gsh_local[48];
+  float* gsh = dL_dshs ? (split ? gsh_local : dL_dshs + (size_t)i * M * 3) : nullptr;
 
   if (vis) {
     const float* view = cp.view;
@@ -355,7 +371,14 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       dx *= inv; dy *= inv; dz *= inv;
       const uint8_t cl = clamped[i];
       const float3 gr = make_float3((cl & 1) ? 0.f : gcol.x, (cl & 2) ? 0.f : gcol.y, (cl & 4) ? 0.f : gcol.z);
+      float shl[48];
       const float* sh = shs + (size_t)i * M * 3;
+      if (split) {
+        shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
+        const float* rest = shs_rest + (size_t)i * (M - 1) * 3;
+        for (int k = 3; k < nb * 3; ++k) shl[k] = rest[k - 3];
+        sh = shl;
+      }
       float gd[3];
       if (D == 0) sh_backward<1>(sh, gsh, dx, dy, dz, gr, gd);
       else if (D == 1) sh_backward<4>(sh, gsh, dx, dy, dz, gr, gd);
@@ -403,11 +426,24 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   if (dL_dcolors) { dL_dcolors[3 * (size_t)i] = gcol.x; dL_dcolors[3 * (size_t)i + 1] = gcol.y; dL_dcolors[3 * (size_t)i + 2] = gcol.z; }
   if (gsh) {
     const int first = (vis && use_shs) ? nb : 0;  // coefficients [0,nb) were written by sh_backward
-    for (int k = first * 3; k < M * 3; ++k) gsh[k] = 0.f;
-    if (sh_gate && first) {  // benign race: every writer stores the same value
-      bool nz = false;
-      for (int k = 0; k < first * 3; ++k) nz = nz || gsh[k] != 0.f;
-      if (nz) *sh_gate = 1.0f;
+    if (!split) {
+      for (int k = first * 3; k < M * 3; ++k) gsh[k] = 0.f;
+      if (sh_gate && first) {  // benign race: every writer stores the same value
+        bool nz = false;
+        for (int k = 0; k < first * 3; ++k) nz = nz || gsh[k] != 0.f;
+        if (nz) *sh_gate = 1.0f;
+      }
+    } else {
+      // scatter the local gradient to the two parameter tensors; untouched coefficients get explicit zeros
+      float* gdc = dL_dshs + 3 * (size_t)i;
+      bool nz_dc = false, nz_rest = false;
+      for (int c = 0; c < 3; ++c) { const float v = first ? gsh_local[c] : 0.f; gdc[c] = v; nz_dc = nz_dc || v != 0.f; }
+      if (dL_dshs_rest) {
+        float* grest = dL_dshs_rest + (size_t)i * (M - 1) * 3;
+        for (int k = 3; k < M * 3; ++k) { const float v = k < first * 3 ? gsh_local[k] : 0.f; grest[k - 3] = v; nz_rest = nz_rest || v != 0.f; }
+      }
+      if (sh_gate && nz_dc) *sh_gate = 1.0f;
+      if (sh_rest_gate && nz_rest) *sh_rest_gate = 1.0f;
     }
   }
   if (dL_dscales) { dL_dscales[3 * (size_t)i] = gs[0]; dL_dscales[3 * (size_t)i + 1] = gs[1]; dL_dscales[3 * (size_t)i + 2] = gs[2]; }
@@ -430,25 +466,26 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 }  // namespace
 
 // ---- host-side launchers (called from api.hip)
-int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs,
+int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
                              const float* colors_precomp, const float* opacities, const float* scales,
                              const float* rotations, const float* cov3D_precomp, const CamParams& cp, int32_t* radii,
                              GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped) {
   if (P <= 0) return 0;
-  hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, colors_precomp,
+  hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, colors_precomp,
                      opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped);
   return 0;
 }
 
-int gs_launch_preprocess_bwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs,
+int gs_launch_preprocess_bwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
                              const float* scales, const float* rotations, int use_shs, int use_cov_precomp,
                              const CamParams& cp, const int32_t* radii, const GsRec* recs, const float* cov3Ds, const uint8_t* clamped,
-                             const GsGrad* grads, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
-                             float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D, float* sh_gate) {
+                             const GsGrad* grads, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dshs_rest,
+                             float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D, float* sh_gate,
+                             float* sh_rest_gate) {
   if (P <= 0) return 0;
-  hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, scales, rotations,
-                     use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
-                     dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate);
+  hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, scales, rotations,
+                     use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dshs_rest,
+                     dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate, sh_rest_gate);
   return 0;
 }
 

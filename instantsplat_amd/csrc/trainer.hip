@@ -131,19 +131,20 @@ void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float
 
 void mi355gs_trainer_destroy(void* handle) { free(handle); }
 
-int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_image, const float* projmatrix, float tanfovx,
-                         float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
+int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, const float* gt_image, const float* projmatrix,
+                         float tanfovx, float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
                          float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out) {
   Trainer* t = (Trainer*)handle;
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
-  if (!t || view < 0 || view >= t->V || !gt_image || !projmatrix || !bg || !lr || !step || !loss_out || !num_rendered_out)
+  if (!t || view < 0 || view >= t->V || sh_degree < 0 || sh_degree > 3 || !gt_image || !projmatrix || !bg || !lr || !step || !loss_out || !num_rendered_out)
     return MI355GS_EINVAL;
   const int P = t->P, W = t->W, H = t->H;
   if (!t->consts_ready) {
     hipLaunchKernelGGL(k_trainer_consts, dim3(1), dim3(64), 0, stream, t->consts);
     GS_CHECK_LAUNCH("trainer_consts");
-    // f_rest never receives a gradient at SH degree 0: its (all-zero) gradient buffer is written once
+    // at SH degree 0 f_rest receives no gradient: its (all-zero) gradient buffer is written once here and first
+    // touched again when the degree is raised (the backward then rewrites every element each step)
     if (hipMemsetAsync(t->g_frest, 0, (size_t)P * 45 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
     t->consts_ready = true;
   }
@@ -157,7 +158,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_
   struct HookScope {
     HookScope(float* gate) {
       g_fused.skip_memsets = true; g_fused.gate = gate;
-      g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5; g_fused.gate_pose = 6;
+      g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_sh_rest = 2; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5; g_fused.gate_pose = 6;
     }
     ~HookScope() { g_fused = GsFusedStepHooks(); }
   } hook_scope(t->adam_scratch);
@@ -169,7 +170,11 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_
   if ((rc = mi355gs_pose_forward(stream, P, t->xyz, t->rotation, t->scaling, t->opacity, pose, t->means_cam, t->rot_cam, t->scales,
                                  t->opac)))
     return rc;
-  if ((rc = mi355gs_raster_forward_preprocess(stream, P, 0, 1, W, H, t->means_cam, t->f_dc, nullptr, t->opac, t->scales, 1.0f,
+  // degree 0 reads only the DC coefficient; higher degrees read f_dc + f_rest in place (split storage)
+  const int D = sh_degree, M = D == 0 ? 1 : 16;
+  const float* rest = D == 0 ? nullptr : t->f_rest;
+  float* g_rest = D == 0 ? nullptr : t->g_frest;
+  if ((rc = mi355gs_raster_forward_preprocess(stream, P, D, M, W, H, t->means_cam, t->f_dc, rest, nullptr, t->opac, t->scales, 1.0f,
                                               t->rot_cam, nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, 0, t->radii,
                                               t->geom, t->tiles, num_rendered_out, 0)))
     return rc;
@@ -178,10 +183,10 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, const float* gt_
     return rc;
   // ---- backward
   if ((rc = gs_loss_backward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, lambda_dssim, t->dL_dimg))) return rc;
-  if ((rc = mi355gs_raster_backward(stream, P, 0, 1, W, H, bg, t->means_cam, t->f_dc, nullptr, t->opac, t->scales, 1.0f, t->rot_cam,
+  if ((rc = mi355gs_raster_backward(stream, P, D, M, W, H, bg, t->means_cam, t->f_dc, rest, nullptr, t->opac, t->scales, 1.0f, t->rot_cam,
                                     nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, t->geom, t->tiles, t->binning,
                                     t->capacity, t->radii, t->dL_dimg, t->grad_scratch, t->g_means3D, t->g_means2D, t->g_fdc,
-                                    t->g_colors, t->g_opac, t->g_scales, t->g_rot_cam, nullptr, 0)))
+                                    g_rest, t->g_colors, t->g_opac, t->g_scales, t->g_rot_cam, nullptr, 0)))
     return rc;
   if ((rc = mi355gs_pose_backward(stream, P, t->xyz, t->rotation, t->scales, t->opac, pose, t->g_means3D, t->g_rot_cam, t->g_scales,
                                   t->g_opac, t->g_xyz, t->g_rot, t->g_scaling, t->g_opacity, t->g_poses + 7 * (size_t)view,

@@ -124,20 +124,22 @@ def _cpu_deep_copy_tuple(input_tuple):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                sh_rest=None):
         s = raster_settings
         L = _lib.lib()
         opt = lambda t: None if (t is None or t.numel() == 0) else _lib.f32c(t)
         means3D = _lib.f32c(means3D)
         opac = _lib.f32c(opacities)
         sh_, col_, sc_, rot_, cov_ = opt(sh), opt(colors_precomp), opt(scales), opt(rotations), opt(cov3Ds_precomp)
+        shr_ = opt(sh_rest)  # split SH storage: sh = DC [P,1,3], sh_rest = the other coefficients [P,M-1,3]
         bg, view, proj, campos = _lib.f32c(s.bg), _lib.f32c(s.viewmatrix), _lib.f32c(s.projmatrix), _lib.f32c(s.campos)
-        dev = _lib.require_device(means3D, opac, sh_, col_, sc_, rot_, cov_, bg, view, proj, campos)
+        dev = _lib.require_device(means3D, opac, sh_, shr_, col_, sc_, rot_, cov_, bg, view, proj, campos)
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
         P = means3D.shape[0]
         H, W = int(s.image_height), int(s.image_width)
-        M = sh_.shape[1] if sh_ is not None else 0
+        M = (sh_.shape[1] + (shr_.shape[1] if shr_ is not None else 0)) if sh_ is not None else 0
         D = int(s.sh_degree)
         stream = _lib.stream_ptr(dev)
         debug = 1 if s.debug else 0
@@ -150,7 +152,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         def run():
             _lib.check(L.mi355gs_raster_forward_preprocess(
-                stream, P, D, M, W, H, _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(opac), _lib.ptr(sc_),
+                stream, P, D, M, W, H, _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(shr_), _lib.ptr(col_), _lib.ptr(opac), _lib.ptr(sc_),
                 float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos),
                 float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _lib.ptr(radii), _lib.ptr(geom),
                 _lib.ptr(tiles), _lib.ptr(num_rendered), debug), "raster_forward_preprocess")
@@ -189,6 +191,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = s
         ctx.num_rendered = R
         ctx.dims = (P, D, M, W, H)
+        ctx.sh_rest = shr_
         ctx.save_for_backward(means3D, sh_ if sh_ is not None else torch.empty(0), col_ if col_ is not None else torch.empty(0),
                               opac, sc_ if sc_ is not None else torch.empty(0), rot_ if rot_ is not None else torch.empty(0),
                               cov_ if cov_ is not None else torch.empty(0), radii, geom, tiles, binning, bg, view, proj, campos)
@@ -209,7 +212,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         _lib.require_device(g)
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         dL_dmeans3D, dL_dmeans2D, dL_dopac = new(P, 3), new(P, 3), new(P)
-        dL_dsh = new(P, M, 3) if sh_ is not None else None
+        shr_ = ctx.sh_rest
+        dL_dsh = (new(P, M, 3) if shr_ is None else new(P, 1, 3)) if sh_ is not None else None
+        dL_dshr = new(P, M - 1, 3) if shr_ is not None else None
         dL_dcol = new(P, 3)
         dL_dscales = new(P, 3) if cov_ is None else None
         dL_drot = new(P, 4) if cov_ is None else None
@@ -219,11 +224,11 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         def run():
             _lib.check(L.mi355gs_raster_backward(
-                stream, P, D, M, W, H, _lib.ptr(bg), _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(opac),
+                stream, P, D, M, W, H, _lib.ptr(bg), _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(shr_), _lib.ptr(col_), _lib.ptr(opac),
                 _lib.ptr(sc_), float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj),
                 _lib.ptr(campos), float(s.tanfovx), float(s.tanfovy), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(binning),
                 int(ctx.num_rendered), _lib.ptr(radii), _lib.ptr(g), _lib.ptr(scratch), _lib.ptr(dL_dmeans3D),
-                _lib.ptr(dL_dmeans2D), _lib.ptr(dL_dsh), _lib.ptr(dL_dcol), _lib.ptr(dL_dopac), _lib.ptr(dL_dscales),
+                _lib.ptr(dL_dmeans2D), _lib.ptr(dL_dsh), _lib.ptr(dL_dshr), _lib.ptr(dL_dcol), _lib.ptr(dL_dopac), _lib.ptr(dL_dscales),
                 _lib.ptr(dL_drot), _lib.ptr(dL_dcov), 1 if s.debug else 0), "raster_backward")
 
         if s.debug:
@@ -236,12 +241,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             run()
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcol if sh_ is None else None, dL_dopac.reshape(ctx.opacity_shape),
-                dL_dscales, dL_drot, dL_dcov, None)
+                dL_dscales, dL_drot, dL_dcov, None, dL_dshr)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, sh_rest)
 
 
 class GaussianRasterizer(nn.Module):
@@ -260,7 +266,9 @@ class GaussianRasterizer(nn.Module):
         return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, shs_rest=None):
+        """Same arguments as the reference operator, plus `shs_rest`: with it, `shs` is the DC coefficient [P,1,3] and
+        `shs_rest` the remaining ones [P,M-1,3] (GaussianModel's own storage), so no concatenated copy is needed."""
         raster_settings = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -270,4 +278,4 @@ class GaussianRasterizer(nn.Module):
         e = torch.Tensor([])
         return rasterize_gaussians(means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp,
                                    opacities, e if scales is None else scales, e if rotations is None else rotations,
-                                   e if cov3D_precomp is None else cov3D_precomp, raster_settings)
+                                   e if cov3D_precomp is None else cov3D_precomp, raster_settings, shs_rest)

@@ -71,6 +71,7 @@ class _SHDegree0View(torch.autograd.Function):
 
 
 def sh_features(pc):
+    """-> (shs, shs_rest) for GaussianRasterizer.forward without materialising cat(f_dc, f_rest)."""
     if pc.active_sh_degree == 0:
-        return _SHDegree0View.apply(pc._features_dc, pc._features_rest)
-    return pc.get_features
+        return _SHDegree0View.apply(pc._features_dc, pc._features_rest), None
+    return pc._features_dc, pc._features_rest

@@ -56,8 +56,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if fused:
         # one HIP launch each way for the pose transform + activations (and the pose-gradient reduction)
         means3D, rot_cam, scales_act, opacity = pose_activations(pc._xyz, pc._rotation, pc._scaling, pc._opacity, camera_pose)
-        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=sh_features(pc), colors_precomp=None,
-                                           opacities=opacity, scales=scales_act, rotations=rot_cam, cov3D_precomp=None)
+        shs_dc, shs_rest = sh_features(pc)
+        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs_dc, colors_precomp=None,
+                                           opacities=opacity, scales=scales_act, rotations=rot_cam, cov3D_precomp=None,
+                                           shs_rest=shs_rest)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
     rel_w2c = get_camera_from_tensor(camera_pose)

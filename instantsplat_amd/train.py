@@ -145,17 +145,17 @@ def _fused_synced_iteration(st: TrainState):
         need = max(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
         tr = st._trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
         st._loss_slot = torch.zeros(1, dtype=torch.float32, device=tr.dev)
-    saved = (st.iteration, list(st.viewpoint_stack), st.rng.getstate(),
+    saved = (st.iteration, list(st.viewpoint_stack), st.rng.getstate(), st.gaussians.active_sh_degree,
              [st.gaussians.optimizer.state[p]["step"] for p in tr.params], [g["lr"] for g in st.gaussians.optimizer.param_groups])
     cam = tr.step(st._loss_slot, defer_optimizer=True, verify_async=False)
     loss, r = torch.cat([st._loss_slot, tr.num_rendered.to(torch.float32)]).tolist()   # the iteration's one host read-back
     BinningPolicy.known[("train", cam.uid)] = int(r)
     if r > tr.capacity:   # dropped instances: discard, redo exactly, and grow the buffers for the next iterations
-        st.iteration, st.viewpoint_stack = saved[0], saved[1]
+        st.iteration, st.viewpoint_stack, st.gaussians.active_sh_degree = saved[0], saved[1], saved[3]
         st.rng.setstate(saved[2])
-        for p, s0 in zip(tr.params, saved[3]):
+        for p, s0 in zip(tr.params, saved[4]):
             st.gaussians.optimizer.state[p]["step"] = s0
-        for g, lr in zip(st.gaussians.optimizer.param_groups, saved[4]):
+        for g, lr in zip(st.gaussians.optimizer.param_groups, saved[5]):
             g["lr"] = lr
         tr.close()
         st._trainer = None
@@ -170,7 +170,7 @@ def _fused_synced_iteration(st: TrainState):
 def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = True, fused_step: bool = False):
     """One pass of reference train.py:140-211, with the reference's per-iteration `loss.item()` (sync_loss=True).
     fused_step=True takes the one-call library step when the configuration allows it (same results)."""
-    if fused_step and sync_loss and fused_loss and (st.iteration + 1) % 1000 != 0 and FusedTrainer.supported(st):
+    if fused_step and sync_loss and fused_loss and FusedTrainer.supported(st):
         out = _fused_synced_iteration(st)
         if out is not None:
             st.last_loss = out
@@ -185,14 +185,14 @@ def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = T
 class FusedTrainer:
     """Whole iteration in one library call (mi355gs_trainer_step): same kernels as the op-by-op path, no autograd
     graph, no temporaries, ~17 launches.  Used by RunAhead whenever the configuration is the one the reference's
-    scripts run (SH degree 0, scale/rotation covariance, SH colours, PerPointAdam with pose optimisation)."""
+    scripts run (SH colours of any active degree, scale/rotation covariance, PerPointAdam with pose optimisation)."""
 
     ORDER = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
 
     @staticmethod
     def supported(st: TrainState) -> bool:
         g, o, p = st.gaussians, st.opt, st.pipe
-        if g.active_sh_degree != 0 or g.max_sh_degree != 3 or not o.optim_pose or p.debug or p.compute_cov3D_python or p.convert_SHs_python:
+        if g.max_sh_degree != 3 or not o.optim_pose or p.debug or p.compute_cov3D_python or p.convert_SHs_python:
             return False
         if not isinstance(g.optimizer, PerPointAdam) or len(g.optimizer.param_groups) != 7:
             return False
@@ -242,6 +242,8 @@ class FusedTrainer:
         st.iteration += 1
         it, g, opt = st.iteration, st.gaussians, st.opt
         g.update_learning_rate(it)
+        if it % 1000 == 0:
+            g.oneupSHdegree()
         cam = _pick_camera(st)
         bg = torch.rand(3, device=self.dev) if opt.random_background else st.background
         do_opt = it < opt.iterations
@@ -255,7 +257,8 @@ class FusedTrainer:
         b1, b2 = grp[0]["betas"]
         F7, I7 = ctypes.c_float * 7, ctypes.c_int32 * 7
         _lib.check(_lib.lib().mi355gs_trainer_step(
-            ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), _lib.ptr(st.gt_images[cam.uid]),
+            ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), int(g.active_sh_degree),
+            _lib.ptr(st.gt_images[cam.uid]),
             _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(bg),
             F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"]), float(opt.lambda_dssim),
             1 if (do_opt and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(self.num_rendered)), "trainer_step")
@@ -356,8 +359,7 @@ class RunAhead:
 
     def step(self):
         """One training iteration; returns the EMA loss at window boundaries (like the reference's progress bar), else None."""
-        nxt = self.st.iteration + 1
-        if self.trainer is not None and nxt % 1000 != 0 and FusedTrainer.supported(self.st):
+        if self.trainer is not None and FusedTrainer.supported(self.st):
             self.trainer.step(self.ring[self.n_in_window:self.n_in_window + 1])
         else:
             loss = _forward_backward_step(self.st, self.fused)

@@ -285,27 +285,86 @@ def check_fused_train_step_equals_autograd_path(dev, iters=6, Wm=12, W=32):
 
 
 def check_run_ahead_crosses_sh_degree_step(dev, Wm=10, W=24):
-    """Iteration 1000 raises the SH degree (reference train.py:148-149): the fused step only covers degree 0, so the
-    driver must hand over to the autograd path there and keep going; the last iteration skips the optimizer."""
+    """Iteration 1000 raises the SH degree (reference train.py:148-149).  The one-call step covers every degree (it takes
+    f_dc / f_rest as separate tensors), so it stays engaged across the change and must keep matching the autograd path —
+    including the f_rest parameters, which only start receiving gradients at degree 1; the last iteration skips the
+    optimizer."""
     from instantsplat_amd.arguments import OptimizationParams
     from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
     from instantsplat_amd.synthetic import syn_pointmap
     from instantsplat_amd.train import FusedTrainer, RunAhead, setup_training
     sc = syn_pointmap(3, Wm, Wm, W, W, seed=13)
-    st = setup_training(sc, dev, opt=OptimizationParams(iterations=1003, pp_optimizer=True, optim_pose=True))
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "P")
+    cuda = torch.device(dev).type == "cuda"
     try:
-        st.iteration = 996
-        ra = RunAhead(st, window=2)
-        assert ra.trainer is not None
-        for _ in range(7):          # iterations 997..1003
-            ra.step()
-        ema = ra.flush()
-        assert st.iteration == 1003 and st.gaussians.active_sh_degree == 1 and not FusedTrainer.supported(st)
-        assert ema == ema and ema > 0  # finite
-        s = st.gaussians.optimizer.state[st.gaussians._xyz]["step"]
-        assert s == 6, s            # 7 iterations, the last one (== opt.iterations) without an optimizer step
+        res = {}
+        for fused in (False, True):
+            st = setup_training(sc, dev, opt=OptimizationParams(iterations=1003, pp_optimizer=True, optim_pose=True))
+            st.iteration = 996
+            ra = RunAhead(st, window=2, fused_step=fused)
+            assert (ra.trainer is not None) == fused
+            for _ in range(7):          # iterations 997..1003
+                ra.step()
+            ema = ra.flush()
+            assert st.iteration == 1003 and st.gaussians.active_sh_degree == 1 and FusedTrainer.supported(st)
+            assert (ra.trainer is not None) == fused
+            assert ema == ema and ema > 0  # finite
+            for n in ("_xyz", "_features_rest"):
+                s_ = st.gaussians.optimizer.state[getattr(st.gaussians, n)]["step"]
+                assert s_ == 6, (n, s_)   # 7 iterations, the last one (== opt.iterations) without an optimizer step
+            assert float(st.gaussians._features_rest.detach().abs().max()) > 0   # degree-1 coefficients are being trained
+            assert float(st.gaussians._features_rest.detach()[:, 3:].abs().max()) == 0   # higher bands still untouched
+            res[fused] = (ema, {n: getattr(st.gaussians, n).detach().cpu().clone() for n in names})
+            BinningPolicy.reset("exact")
+        assert abs(res[True][0] - res[False][0]) <= (1e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
+        for n in names:
+            a_, b_ = res[True][1][n], res[False][1][n]
+            rel = float((a_ - b_).norm() / (b_.norm() + 1e-12))
+            assert rel <= (5e-2 if cuda else 1e-5), (n, rel)
     finally:
         BinningPolicy.reset("exact")
+
+
+def check_split_sh_equals_concatenated(dev, degree=2, P=300, W=64, H=48, seed=5):
+    """GaussianRasterizer.forward(shs=f_dc, shs_rest=f_rest) must give what shs=cat(f_dc, f_rest) gives: same image, radii
+    and gradients (reference scene/gaussian_model.py:129-132 concatenates; here the two tensors go in as they are)."""
+    from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizer
+    from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings
+    from instantsplat_amd.synthetic import syn_blob
+    from tests.util import settings_for
+    dev = torch.device(dev)
+    sc = syn_blob(P, W, H, seed=seed, scale_mean=0.05)
+    settings = settings_for(sc.camera, degree, GaussianRasterizationSettings, torch.tensor([0.2, 0.5, 0.9]), device=dev)
+    M = sc.shs.shape[1]
+    outs = {}
+    for split in (False, True):
+        leaves = dict(means3D=sc.means3D, op=sc.opacity_logit, scaling=sc.scaling_logit, rot=sc.rotation)
+        leaves = {k: v.clone().to(dev).requires_grad_(True) for k, v in leaves.items()}
+        f_dc = sc.shs[:, :1].clone().to(dev).requires_grad_(True)
+        f_rest = sc.shs[:, 1:].clone().to(dev).requires_grad_(True)
+        means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+        kw = dict(means3D=leaves["means3D"], means2D=means2D, opacities=torch.sigmoid(leaves["op"]),
+                  scales=torch.exp(leaves["scaling"]), rotations=leaves["rot"])
+        r = GaussianRasterizer(settings)
+        if split:
+            img, radii = r(shs=f_dc, shs_rest=f_rest, **kw)
+        else:
+            img, radii = r(shs=torch.cat([f_dc, f_rest], 1), **kw)
+        wgt = torch.linspace(0.2, 1.0, img.numel(), device=img.device).reshape(img.shape)
+        (img * wgt).sum().backward()
+        outs[split] = dict(img=img.detach().cpu(), radii=radii.cpu(), f_dc=f_dc.grad.cpu(), f_rest=f_rest.grad.cpu(),
+                           means2D=means2D.grad.cpu(), **{k: v.grad.cpu() for k, v in leaves.items()})
+    assert M == 16
+    assert torch.equal(outs[True]["radii"], outs[False]["radii"])
+    assert torch.equal(outs[True]["img"], outs[False]["img"])
+    assert float(outs[False]["f_rest"].abs().max()) > 0
+    cuda = torch.device(dev).type == "cuda"   # float atomics in the per-tile backward: order-dependent rounding on the GPU
+    for k in outs[True]:
+        if k in ("img", "radii"):
+            continue
+        a_, b_ = outs[True][k], outs[False][k]
+        tol = 1e-4 if cuda else 0.0
+        assert float((a_ - b_).abs().max()) <= tol * max(1.0, float(b_.abs().max())), k
 
 
 def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=False, Wm=12, W=32):

@@ -79,7 +79,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.mi355gs_abi_version.restype = ctypes.c_int
-    assert lib.mi355gs_abi_version() == 1
+    assert lib.mi355gs_abi_version() == 2
 
 
 def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
@@ -92,3 +92,8 @@ def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
     monkeypatch.setattr(_lib, "_LIB", None)
     with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
         _lib.lib()
+
+
+@pytest.mark.parametrize("degree", [1, 3])
+def test_split_sh_equals_concatenated(emu, degree):
+    ops_util.check_split_sh_equals_concatenated(emu, degree=degree)

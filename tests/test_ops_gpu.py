@@ -68,3 +68,8 @@ def test_training_improves_psnr(gpu):
     r = training(syn_pointmap(3, 64, 64, 128, 128, seed=0), gpu, iterations=150)
     assert r["last_loss"] < r["first_loss"]
     assert r["psnr_after"] > r["psnr_before"] + 0.5
+
+
+@pytest.mark.parametrize("degree", [1, 3])
+def test_split_sh_equals_concatenated(gpu, degree):
+    ops_util.check_split_sh_equals_concatenated(gpu, degree=degree)
