@@ -16,8 +16,9 @@
 // with three 16-byte loads from one contiguous address (1 cache line most of the time).
 struct alignas(16) GsRec {
   float4 q0;  // x, y (pixel centre), hx, hy (half extents of the alpha >= 1/255 ellipse's AABB; <0: never visible)
-  float4 q1;  // conic pre-scaled for v_exp_f32: (-a/2, -b, -c/2) * log2(e), then opacity — so that
-              // G = exp2(q1.x*dx*dx + q1.z*dy*dy + q1.y*dx*dy) with no further multiplies
+  float4 q1;  // conic pre-scaled for v_exp_f32 and ordered for packed-FP32 math: (-a/2, -c/2, -b) * log2(e), then
+              // opacity — so that G = exp2(q1.x*dx*dx + q1.y*dy*dy + q1.z*dx*dy) with no further multiplies and
+              // (q1.x, q1.y) * (dx, dy) is one v_pk_mul_f32
   float4 q2;  // r, g, b, depth
 };
 
@@ -115,6 +116,17 @@ __device__ __forceinline__ float gs_wave_sum_row3(float v) {
   v += gs_dpp<0x140>(v);       // row_mirror        -> every lane holds its row's sum
   v += gs_dpp<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
   v += gs_dpp<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> row 3 holds the wave total
+  return v;
+}
+
+// Two floats in an aligned VGPR pair: element-wise arithmetic on it compiles to CDNA3/4's full-rate packed-FP32 ops
+// (v_pk_add/mul/fma_f32: two lanes' worth of work per issue slot).
+typedef float gs_v2f __attribute__((vector_size(8)));
+
+// Hides a value's producer from the optimiser (no instruction is emitted): stops it from re-computing a product on
+// both sides of a DPP exchange, which costs more VALU ops than the exchange saves.
+__device__ __forceinline__ float gs_opaque(float v) {
+  asm volatile("" : "+v"(v));
   return v;
 }
 

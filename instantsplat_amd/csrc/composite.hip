@@ -17,7 +17,7 @@ constexpr float T_MIN = 0.0001f;
 
 struct Quad {
   int px, py;          // this lane's pixel
-  float fx, fy;        // as float
+  gs_v2f f;            // as float (x, y)
   float x0, x1, y0, y1;  // the wave's 8x8 pixel box (inclusive, float)
   bool inside;
 };
@@ -29,7 +29,7 @@ __device__ __forceinline__ Quad make_quad(int tile, int gx, int W, int H) {
   Quad q;
   q.px = bx + (lane & 7);
   q.py = by + (lane >> 3);
-  q.fx = (float)q.px; q.fy = (float)q.py;
+  q.f = gs_v2f{(float)q.px, (float)q.py};
   q.x0 = (float)bx; q.x1 = (float)(bx + 7); q.y0 = (float)by; q.y1 = (float)(by + 7);
   q.inside = q.px < W && q.py < H;
   return q;
@@ -51,7 +51,7 @@ __device__ __forceinline__ bool quad_hit(const float4& q0, const float4& q1, con
   const float gx = q0.x, gy = q0.y;
   if (gx >= q.x0 && gx <= q.x1 && gy >= q.y0 && gy <= q.y1) return true;
   // q1 holds the exp2-scaled conic: e(dx,dy) = A dx^2 + C dy^2 + B dx dy (A, C < 0) is log2 of the Gaussian falloff
-  const float A = q1.x, B = q1.y, C = q1.z;
+  const float A = q1.x, C = q1.y, B = q1.z;
   const float tau = __log2f(255.0f * q1.w) * 1.01f + 1e-3f;
   const float inv_2A = __builtin_amdgcn_rcpf(2.0f * A), inv_2C = __builtin_amdgcn_rcpf(2.0f * C);
   const float dx_lo = gx - q.x1, dx_hi = gx - q.x0, dy_lo = gy - q.y1, dy_hi = gy - q.y0;
@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
         // record's LDS reads are issued before the current record's math and no register copies are needed to
         // rotate the prefetch.  The math is predicated (no exec-mask branches).
         auto blend_one = [&](const float4& a0, const float4& a1, const float4& a2, int i2) {
-          const float dx = a0.x - q.fx, dy = a0.y - q.fy;
-          const float power2 = a1.x * dx * dx + a1.z * dy * dy + a1.y * dx * dy;  // log2 of the falloff
+          const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
+          const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
+          const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
           const float alpha = fminf(0.99f, a1.w * __builtin_amdgcn_exp2f(power2));
           // a skipped Gaussian is a transparent one; a finished pixel carries Tr == 0, so `stop` (and nothing else)
           // also covers "already done" and no separate flag is tested here
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
   if (q.inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[plane + pix]; g2 = dL_dpix[2 * plane + pix]; }
   const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+  const gs_v2f g01 = {g0, g1};
 
   // the tile only needs instances [0, max over pixels of last)
   uint32_t wmax = last;
@@ -208,10 +210,9 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
   const uint32_t tile_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
   if (tile_max == 0) return;
 
-  const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
-  const int r16 = lane & 15;
+  const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0, bit2 = (lane & 4) != 0, bit3 = (lane & 8) != 0;
   float Tr = T_final;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+  float behind = T_final * bg_dot;  // dL/dC . (everything composited behind the current Gaussian, background included)
 
   // batches are aligned to the list start so that batch boundaries match contributor numbering
   const uint32_t nb = (tile_max + BATCH - 1) / BATCH;
@@ -239,38 +240,40 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
         // back-to-front walk over the hit mask, unrolled by two with ping-pong record registers (see the forward kernel)
         auto replay_one = [&](const float4& a0, const float4& a1, const float4& a2, const uint32_t id, const int i2) {
           const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
-          const float dx = a0.x - q.fx, dy = a0.y - q.fy;
-          const float power2 = a1.x * dx * dx + a1.z * dy * dy + a1.y * dx * dy;  // log2 of the falloff
+          const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
+          const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
+          const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
           const float G = __builtin_amdgcn_exp2f(fminf(power2, 0.0f));
           const float alpha = fminf(0.99f, a1.w * G);
           const bool valid = contributor <= last && power2 <= 0.0f && alpha >= ALPHA_MIN;
           if (__any(valid)) {
-            // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T, accum_rec, last_alpha and
-            // last_color then evolve exactly as if it had been skipped (acc' = 0*lc + 1*acc), so the replay state needs no
-            // per-field selects; only alpha itself and dL/dalpha are masked.
+            // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T and the colour behind then
+            // evolve exactly as if it had been skipped, so the replay state needs no per-field selects; only alpha itself
+            // and dL/dalpha are masked.
             const float al = valid ? alpha : 0.f;
-            const float one_m = 1.f - al;
-            const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // v_rcp_f32 (1 ulp) instead of two IEEE divisions
-            Tr = Tr * inv_one_m;
-            const float dchannel = al * Tr;
-            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-            lc0 = a2.x; lc1 = a2.y; lc2 = a2.z;
-            float dL_dalpha = (a2.x - acc0) * g0 + (a2.y - acc1) * g1 + (a2.z - acc2) * g2;
-            dL_dalpha = dL_dalpha * Tr - T_final * inv_one_m * bg_dot;
+            const float inv_one_m = __builtin_amdgcn_rcpf(1.f - al);  // v_rcp_f32 (1 ulp) instead of two IEEE divisions
+            Tr = Tr * inv_one_m;                                       // transmittance in front of this Gaussian
+            // dC/dalpha_k = c_k T_k - (sum_{j behind k} c_j alpha_j T_j + T_final bg) / (1 - alpha_k).  Contracted with
+            // dL/dC first, the "colour behind" term is ONE running scalar (behind) instead of the reference's three-channel
+            // accum_rec / last_color / last_alpha recursion (same quantity: accum_rec_k = sum_{j>k} c_j alpha_j T_j / T_{k+1}).
+            const float cg = a2.x * g0 + a2.y * g1 + a2.z * g2;
+            float dL_dalpha = Tr * cg - behind * inv_one_m;
             dL_dalpha = valid ? dL_dalpha : 0.f;
-            last_alpha = al;
+            const float dchannel = al * Tr;
+            behind += cg * dchannel;
             // Moments of w = G * dL/dG over the wave's pixels: every screen-space gradient of this Gaussian is a fixed
             // linear combination of them (coefficients = its own conic / opacity), applied once per Gaussian in
             // k_preprocess_bwd instead of once per pixel here:
             //   dL/dconic = (-1/2 sum w dx^2, -sum w dx dy, -1/2 sum w dy^2),  dL/dopacity = sum w / opacity,
             //   dL/dmean2D = -(a sum w dx + b sum w dy, c sum w dy + b sum w dx) * (W/2, H/2)
             const float w = G * (a1.w * dL_dalpha);
-            const float t0 = w * dx, t1 = w * dy;              // sum w dx, sum w dy
-            const float t2 = t0 * dx, t3 = t0 * dy, t4 = t1 * dy;  // sum w dx^2, sum w dx dy, sum w dy^2
-            const float t5 = w;                                 // sum w
-            const float t6 = dchannel * g0, t7 = dchannel * g1, t8 = dchannel * g2;  // dL/drgb
+            const gs_v2f t01 = gs_v2f{w, w} * d;               // sum w dx, sum w dy
+            const gs_v2f t24 = t01 * d;                        // sum w dx^2, sum w dy^2
+            const float t0 = t01[0], t1 = t01[1], t2 = t24[0], t4 = t24[1];
+            const float t3 = t0 * d[1];                        // sum w dx dy
+            const float t5 = w;                                // sum w
+            const gs_v2f t67 = gs_v2f{dchannel, dchannel} * g01;
+            const float t6 = t67[0], t7 = t67[1], t8 = gs_opaque(dchannel * g2);  // dL/drgb
             // lanes differing in bit 0 (quad_perm [1,0,3,2]) then bit 1 (quad_perm [2,3,0,1])
             const float w0 = gs_pair_reduce<0xB1>(bit0, t0, t1), w1 = gs_pair_reduce<0xB1>(bit0, t2, t3);
             const float w2 = gs_pair_reduce<0xB1>(bit0, t4, t5), w3 = gs_pair_reduce<0xB1>(bit0, t6, t7);
@@ -278,10 +281,12 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
             float x0 = gs_pair_reduce<0x4E>(bit1, w0, w1);  // component 2*bit1 + bit0, summed over the quad
             float x1 = gs_pair_reduce<0x4E>(bit1, w2, w3);  // component 4 + 2*bit1 + bit0
             float x2 = w4 + gs_dpp<0x4E>(w4);               // component 8
-            // the four quads of each 16-lane row (row_ror:4, row_ror:8 keep the low two lane bits)
-            x0 += gs_dpp<0x124>(x0); x1 += gs_dpp<0x124>(x1); x2 += gs_dpp<0x124>(x2);
-            x0 += gs_dpp<0x128>(x0); x1 += gs_dpp<0x128>(x1); x2 += gs_dpp<0x128>(x2);
-            float mine = r16 < 4 ? x0 : (r16 < 8 ? x1 : x2);
+            // the four quads of each 16-lane row, still transposed: row_ror:4 pairs quads of opposite parity (even quads
+            // keep x0, odd quads x1), row_ror:8 pairs the half rows (low half keeps the x0/x1 mix, high half x2); both
+            // rotations keep the low two lane bits, so lane l < 9 of every row ends up with component l of the row sum
+            const float y0 = gs_pair_reduce<0x124>(bit2, x0, x1);
+            const float y1 = x2 + gs_dpp<0x124>(x2);
+            float mine = gs_pair_reduce<0x128>(bit3, y0, y1);
             mine = gs_sum_rows(mine);  // the four rows
             if (lane < 9) atomicAdd(reinterpret_cast<float*>(grads + id) + lane, mine);
           }

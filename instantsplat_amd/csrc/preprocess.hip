@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   rects[i] = make_uint2((uint32_t)bminx | ((uint32_t)bminy << 16), (uint32_t)bmaxx | ((uint32_t)bmaxy << 16));
   GsRec rec;
   rec.q0 = make_float4(px, py, hx, hy);
-  rec.q1 = make_float4(-0.5f * GS_LOG2E * ca, -GS_LOG2E * cb, -0.5f * GS_LOG2E * cc, opac);
+  rec.q1 = make_float4(-0.5f * GS_LOG2E * ca, -0.5f * GS_LOG2E * cc, -GS_LOG2E * cb, opac);
   rec.q2 = make_float4(rgb.x, rgb.y, rgb.z, pv.z);
   recs[i] = rec;
 }
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   if (vis) {
     // moments (see GsGrad) -> screen-space gradients, with this Gaussian's conic (a, b, c) and opacity
     const GsGrad mo = grads[i];
-    float4 con = recs[i].q1;  // undo the exp2 pre-scaling: back to the conic (a, b, c)
-    con.x *= -2.0f / GS_LOG2E; con.y *= -1.0f / GS_LOG2E; con.z *= -2.0f / GS_LOG2E;
+    const float4 pre = recs[i].q1;  // undo the exp2 pre-scaling and ordering: back to the conic (a, b, c)
+    const float4 con = make_float4(pre.x * (-2.0f / GS_LOG2E), pre.z * (-1.0f / GS_LOG2E), pre.y * (-2.0f / GS_LOG2E), pre.w);
     const float m1 = mo.g0.x, m2 = mo.g0.y, m3 = mo.g0.z, m4 = mo.g0.w, m5 = mo.g1.x, m0 = mo.g1.y;
     g.g0.x = -(con.x * m1 + con.y * m2) * (0.5f * cp.W);   // dL/dmean2D.x (NDC-scaled, as the reference reports it)
     g.g0.y = -(con.z * m2 + con.y * m1) * (0.5f * cp.H);   // dL/dmean2D.y
