@@ -86,6 +86,7 @@ int mi355gs_raster_forward_render(
  *   dL_dshs[P,M,3] (split storage: dL_dshs[P,1,3] + dL_dshs_rest[P,M-1,3]) or dL_dcolors[P,3], dL_dopacities[P],
  *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
  *   geom/tiles/binning/capacity/radii: exactly what the forward of this frame used and produced
+ *   (`tiles` also holds the tile scheduler's counters, which the kernels consume and re-arm: not const)
  *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes */
 size_t mi355gs_raster_grad_scratch_bytes(int P);
 int mi355gs_raster_backward(
@@ -94,7 +95,7 @@ int mi355gs_raster_backward(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tanfovx, float tanfovy,
-    const void* geom, const void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
+    const void* geom, void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
     const float* dL_dpix, void* grad_scratch,
     float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities,
     float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int debug);

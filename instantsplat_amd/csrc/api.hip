@@ -11,12 +11,12 @@ int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const flo
                              const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
                              float*, float*, float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
-int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*);
+int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, GsSched*);
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            float*, float*, uint32_t*);
+                            float*, float*, uint32_t*, const uint32_t*, GsSched*);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            const float*, const uint32_t*, const float*, GsGrad*);
+                            const float*, const uint32_t*, const float*, GsGrad*, const uint32_t*, GsSched*);
 
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
@@ -48,6 +48,18 @@ struct ProfScope {
 }  // namespace
 
 thread_local GsFusedStepHooks g_fused;
+
+int gs_num_cus() {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
+    cached[dev] = n < GS_SCHED_SLOTS ? n : GS_SCHED_SLOTS;
+  }
+  return cached[dev];
+}
 
 void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
 
@@ -111,7 +123,8 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   GS_CHECK_LAUNCH("preprocess_fwd");
   gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
   GS_CHECK_LAUNCH("count_tiles");
-  gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered);
+  gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered,
+                       (uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched));
   GS_CHECK_LAUNCH("scan_tiles");
   return MI355GS_OK;
 }
@@ -135,7 +148,8 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
   {
     ProfScope prof(0, stream);
     gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
-                            (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib));
+                            (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
+                            (const uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched));
   }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;
@@ -145,7 +159,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                             const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                             float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                             const float* projmatrix, const float* campos, float tanfovx, float tanfovy, const void* geom,
-                            const void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
+                            void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
                             const float* dL_dpix, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                             float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                             int debug) {
@@ -167,7 +181,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   const TilesLayout tl(W, H);
   const BinningLayout bl(capacity);
   const char* g = (const char*)geom;
-  const char* t = (const char*)tiles;
+  char* t = (char*)tiles;  // geometry of the frame is read-only here; the tile scheduler's words are consumed and re-armed
   const char* b = (const char*)binning;
   GsGrad* grads = (GsGrad*)grad_scratch;
   if (!g_fused.skip_memsets && hipMemsetAsync(grads, 0, (size_t)P * sizeof(GsGrad), stream) != hipSuccess) return MI355GS_ELAUNCH;
@@ -176,7 +190,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
       ProfScope prof(1, stream);
       gs_launch_composite_bwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                               (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
-                              dL_dpix, grads);
+                              dL_dpix, grads, (const uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched));
     }
     GS_CHECK_LAUNCH("composite_bwd");
   }

@@ -22,7 +22,12 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 
 // ---- K2: exclusive scan of per-tile counts (T <= ~10^5 fits one workgroup comfortably)
 // (count and start may alias: every thread reads an element before it overwrites it)
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered) {
+// With `order` set it also prepares the tile scheduler (common.h, GsSched): order[] = tile indices by descending count
+// (counting sort over 1024 count buckets — exact order inside a bucket is irrelevant for load balance) and the scheduler
+// words are cleared.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
+                                                               uint32_t* __restrict__ order, uint32_t* __restrict__ sched_words,
+                                                               int n_sched_words) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -44,6 +49,44 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     const uint32_t v = wave_tot[w];
     if (w < wave) wave_off += v;
     total += v;
+  }
+  // ---- scheduler preparation first: it reads count[], which the scan below may overwrite (count and start can alias)
+  if (order) {
+    __shared__ uint32_t hist[SCAN_THREADS];
+    __shared__ uint32_t s_max;
+    for (int i = tid; i < n_sched_words; i += SCAN_THREADS) sched_words[i] = 0u;
+    uint32_t mx = 0;
+    for (int i = lo; i < hi; ++i) mx = max(mx, count[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+    hist[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint32_t cmax = max(s_max, 1u);
+    auto bucket = [&](uint32_t c) { return (uint32_t)(SCAN_THREADS - 1) - (uint32_t)(((uint64_t)c * (SCAN_THREADS - 1)) / cmax); };
+    for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(count[i])], 1u);
+    __syncthreads();
+    // exclusive scan of the 1024 bucket sizes (one per thread)
+    const uint32_t h = hist[tid];
+    uint32_t hi_ = h;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(hi_, d);
+      if (lane >= d) hi_ += o;
+    }
+    __shared__ uint32_t hist_wave[SCAN_THREADS / GS_WAVE];
+    if (lane == 63) hist_wave[wave] = hi_;
+    __syncthreads();
+    uint32_t hoff = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w)
+      if (w < wave) hoff += hist_wave[w];
+    hist[tid] = hoff + hi_ - h;
+    __syncthreads();
+    for (int i = lo; i < hi; ++i) order[atomicAdd(&hist[bucket(count[i])], 1u)] = (uint32_t)i;
+    __syncthreads();
   }
   uint32_t run = wave_off + incl - local;
   for (int i = lo; i < hi; ++i) {
@@ -336,8 +379,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_large(int T, const 
 
 }  // namespace
 
-int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered) {
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered);
+int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
+                         GsSched* sched) {
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order,
+                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4));
   return 0;
 }
 
@@ -345,7 +390,8 @@ int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint3
 int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t* out, uint32_t* block_sums, int32_t* total) {
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total);  // in place
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
+                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0);  // in place
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
 }

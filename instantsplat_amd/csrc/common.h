@@ -45,8 +45,26 @@ struct GeomLayout {
   }
 };
 
+// ---- CU-balanced tile scheduling ---------------------------------------------------------------------------------
+// A 512^2 frame has 1024 tiles = 4096 quadrant waves — exactly the 4 waves/SIMD the chip holds, so the hardware never
+// gets to rebalance: every workgroup is resident from the first cycle and the kernel lasts as long as the CU whose
+// tiles happen to be the heaviest (measured on the C3 workload: busiest CU 1.42x the mean, and where a workgroup lands
+// is not predictable from its index).  The per-tile kernels therefore run as persistent workgroups over per-CU bins:
+// k_scan_tiles orders the tiles by instance count (descending) and bin b owns the entries b, 2NB-1-b, 2NB+b, ... of that
+// order (a serpentine deal, NB = number of CUs, bin loads within ~2 % of each other); the first workgroup to start on a
+// physical CU (s_getreg HW_ID / XCC_ID) claims a bin for that CU, workgroups pop tiles from their CU's bin and steal from
+// the other bins once it is empty.  Placement only affects speed: any mapping of workgroups to bins processes every tile
+// exactly once.
+constexpr int GS_SCHED_SLOTS = 512;  // >= physical CU ids (xcc:3 | se:2 | cu:4) and >= NB
+struct GsSched {
+  uint32_t cu_bin[GS_SCHED_SLOTS];  // physical CU -> 2 + bin (0: unclaimed, 1: claim in progress)
+  uint32_t next[GS_SCHED_SLOTS];    // per-bin pop counter
+  uint32_t claimed, done, pad0, pad1;
+};
+enum { GS_SCHED_FWD = 0, GS_SCHED_BWD = 1, GS_SCHED_COUNT = 2 };
+
 struct TilesLayout {
-  size_t count, start, cursor, final_T, n_contrib, total;
+  size_t count, start, cursor, final_T, n_contrib, order, sched, total;
   int gx, gy, T;
   __host__ TilesLayout(int W, int H) {
     gx = (W + GS_TILE - 1) / GS_TILE; gy = (H + GS_TILE - 1) / GS_TILE; T = gx * gy;
@@ -56,6 +74,8 @@ struct TilesLayout {
     start = o; o += gs_align(((size_t)T + 1) * 4);
     final_T = o; o += gs_align(npix * 4);
     n_contrib = o; o += gs_align(npix * 4);
+    order = o; o += gs_align((size_t)T * 4);
+    sched = o; o += gs_align(GS_SCHED_COUNT * sizeof(GsSched));
     total = o;
   }
 };
@@ -77,6 +97,9 @@ __device__ __forceinline__ int gs_tile_of_block(int b, int T) {
   return (b & 7) * per + (b >> 3);
 }
 static inline int gs_grid_for_tiles(int T) { return ((T + 7) >> 3) << 3; }
+int gs_num_cus();  // api.hip: compute units of the current device (cached)
+// persistent per-tile kernels: at most six workgroups per CU (LDS-limited residency of the composite kernels)
+static inline int gs_grid_persistent(int T, int NB) { return T < 6 * NB ? T : 6 * NB; }
 
 // transposed (column-major flat) 4x4 helpers, the storage the reference hands over
 __device__ __forceinline__ float3 gs_tp43(const float* m, float3 p) {
@@ -149,6 +172,87 @@ __device__ __forceinline__ float gs_sum_rows(float v) {
   const unsigned w = __float_as_uint(s);
   const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Transposed pair steps ACROSS rows with the same swaps: v_permlane16_swap exchanges the odd rows of its first operand
+// with the even rows of its second, so (first + second) afterwards holds a summed over each row pair in the even rows and
+// b in the odd rows — a pair step in two VALU ops, no selects.  v_permlane32_swap does the same for the wave halves.
+__device__ __forceinline__ float gs_pair_reduce_rows16(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float gs_pair_reduce_rows32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- device side of the tile scheduler (see GsSched).  Called by wave 0 of a workgroup with all 64 lanes active.
+__device__ __forceinline__ uint32_t gs_physical_cu() {
+  const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [14:13]
+  const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));  // HW_REG_XCC_ID [3:0]
+  return ((xcc & 7u) << 6) | (((hw >> 13) & 3u) << 4) | ((hw >> 8) & 15u);
+}
+
+__device__ __forceinline__ int gs_sched_claim(GsSched* s, int NB) {
+  uint32_t v = 0;
+  if ((threadIdx.x & 63) == 0) {
+    uint32_t* slot = &s->cu_bin[gs_physical_cu() & (GS_SCHED_SLOTS - 1)];
+    v = atomicCAS(slot, 0u, 1u);
+    if (v == 0u) {  // first workgroup on this CU: take the next unowned bin (NB = "none left", go straight to stealing)
+      const uint32_t b = atomicAdd(&s->claimed, 1u);
+      v = 2u + min(b, (uint32_t)NB);
+      atomicExch(slot, v);
+    } else {
+      while (v == 1u) {  // the claimer publishes within two atomics and waits for nobody
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  return (int)__builtin_amdgcn_readfirstlane(v) - 2;
+}
+
+// next tile for this workgroup, or -1 when every bin is empty
+__device__ __forceinline__ int gs_sched_pop(GsSched* s, int bin, int NB, int T, const uint32_t* __restrict__ order) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t per_bin = (uint32_t)((T + NB - 1) / NB);
+  auto take = [&](int b) -> int {  // b wave-uniform; index into `order`, or -1 once bin b is exhausted
+    for (;;) {
+      uint32_t j = 0;
+      if (lane == 0) j = atomicAdd(&s->next[b], 1u);
+      j = __builtin_amdgcn_readfirstlane(j);
+      if (j >= per_bin) return -1;
+      const int idx = (int)j * NB + ((j & 1u) ? NB - 1 - b : b);
+      if (idx < T) return idx;
+    }
+  };
+  if (bin < NB) {
+    const int idx = take(bin);
+    if (idx >= 0) return (int)order[idx];
+  }
+  for (int base = 0; base < NB; base += 64) {  // steal: 64 bins inspected per step, starting after the own bin
+    const int off = base + lane;
+    bool avail = false;
+    if (off < NB) avail = __hip_atomic_load(&s->next[(bin + 1 + off) % NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per_bin;
+    unsigned long long mask = __ballot(avail);
+    while (mask) {
+      const int l = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int idx = take((bin + 1 + base + l) % NB);
+      if (idx >= 0) return (int)order[idx];
+    }
+  }
+  return -1;
+}
+
+// whole workgroup, after its last pop: the last workgroup of the launch re-arms the structure (a second backward over the
+// same forward, or a second render over the same preprocess, finds it as k_scan_tiles left it)
+__device__ __forceinline__ void gs_sched_finish(GsSched* s) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = atomicAdd(&s->done, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (s_last)
+    for (int i = threadIdx.x; i < (int)(sizeof(GsSched) / 4); i += blockDim.x) reinterpret_cast<uint32_t*>(s)[i] = 0u;
 }
 
 #define GS_CHECK_LAUNCH(name)                                                   \

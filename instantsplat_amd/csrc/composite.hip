@@ -78,17 +78,15 @@ __device__ __forceinline__ bool quad_hit(const float4& q0, const float4& q1, con
 // ------------------------------------------------------------------------------------------------
 // K6 forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity,
-                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
-                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
-                                                        float* __restrict__ out_color, float* __restrict__ final_T,
-                                                        uint32_t* __restrict__ n_contrib) {
+__device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int H, uint32_t capacity,
+                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                   const GsRec* __restrict__ recs, const float* __restrict__ bg,
+                                                   float* __restrict__ out_color, float* __restrict__ final_T,
+                                                   uint32_t* __restrict__ n_contrib) {
   __shared__ float4 s_q0[BATCH];
   __shared__ float4 s_q1[BATCH];
   __shared__ float4 s_q2[BATCH];
   __shared__ int s_done[4];
-  const int tile = gs_tile_of_block(blockIdx.x, T);
-  if (tile >= T) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
@@ -169,6 +167,35 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
   }
 }
 
+// Persistent workgroups over the CU-balanced tile bins (common.h, GsSched).
+#define GS_PERSISTENT_TILE_LOOP(sched, NB, T, order, CALL)                     \
+  __shared__ int s_tile;                                                        \
+  const int wave_ = threadIdx.x >> 6;                                           \
+  int bin_ = 0;                                                                 \
+  if (wave_ == 0) bin_ = gs_sched_claim(sched, NB);                             \
+  for (;;) {                                                                    \
+    if (wave_ == 0) {                                                           \
+      const int t_ = gs_sched_pop(sched, bin_, NB, T, order);                   \
+      if ((threadIdx.x & 63) == 0) s_tile = t_;                                 \
+    }                                                                           \
+    __syncthreads();                                                            \
+    const int tile = s_tile;                                                    \
+    if (tile < 0) break;                                                        \
+    CALL;                                                                       \
+    __syncthreads(); /* s_tile and the tile's LDS staging are reused */         \
+  }                                                                             \
+  gs_sched_finish(sched);
+
+__global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity,
+                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
+                                                        float* __restrict__ out_color, float* __restrict__ final_T,
+                                                        uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order,
+                                                        GsSched* sched, int NB) {
+  GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
+                          composite_fwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T, n_contrib))
+}
+
 // ------------------------------------------------------------------------------------------------
 // K7 backward: replay each tile back to front.  Per (pixel, Gaussian) the nine screen-space
 // gradient terms are reduced across the wave's 64 pixels in registers (butterfly shuffles) and
@@ -176,18 +203,15 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
 // them per pixel).  Gaussians whose box misses the wave's quadrant, or that lie behind every
 // pixel's last contributor, are skipped wave-wide.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int H, uint32_t capacity,
-                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
-                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
-                                                        const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                                                        const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads) {
+__device__ __forceinline__ void composite_bwd_tile(int tile, int gx, int W, int H, uint32_t capacity,
+                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                   const GsRec* __restrict__ recs, const float* __restrict__ bg,
+                                                   const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                                   const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads) {
   __shared__ float4 s_q0[BATCH];
   __shared__ float4 s_q1[BATCH];
   __shared__ float4 s_q2[BATCH];
-  __shared__ uint32_t s_id[BATCH];
   __shared__ uint32_t s_max[4];
-  const int tile = gs_tile_of_block(blockIdx.x, T);
-  if (tile >= T) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
@@ -210,7 +234,9 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
   const uint32_t tile_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
   if (tile_max == 0) return;
 
-  const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0, bit2 = (lane & 4) != 0, bit3 = (lane & 8) != 0;
+  const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
+  const bool out_lane = (lane & 14) == 0 || lane == 2;                 // the nine lanes that hold a finished sum
+  const int out_comp = lane == 2 ? 8 : (lane >> 4) + 4 * (lane & 1);   // ... and which of the nine it is
   float Tr = T_final;
   float behind = T_final * bg_dot;  // dL/dC . (everything composited behind the current Gaussian, background included)
 
@@ -224,7 +250,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
       if (boff + sl < tile_max) {
         const uint32_t id = list[start + boff + sl];
         const GsRec* r = recs + id;
-        s_id[sl] = id; s_q0[sl] = r->q0; s_q1[sl] = r->q1; s_q2[sl] = r->q2;
+        const float4 c = r->q2;  // (r, g, b, depth): depth is not used here, its slot carries the Gaussian's index
+        s_q0[sl] = r->q0; s_q1[sl] = r->q1; s_q2[sl] = make_float4(c.x, c.y, c.z, __uint_as_float(id));
       }
     }
     __syncthreads();
@@ -238,27 +265,29 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
       unsigned long long mask = __ballot(hit);
       if (mask) {
         // back-to-front walk over the hit mask, unrolled by two with ping-pong record registers (see the forward kernel)
-        auto replay_one = [&](const float4& a0, const float4& a1, const float4& a2, const uint32_t id, const int i2) {
+        auto replay_one = [&](const float4& a0, const float4& a1, const float4& a2, const int i2) {
+          const uint32_t id = __float_as_uint(a2.w);
           const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
           const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
           const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
           const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
-          const float G = __builtin_amdgcn_exp2f(fminf(power2, 0.0f));
-          const float alpha = fminf(0.99f, a1.w * G);
-          const bool valid = contributor <= last && power2 <= 0.0f && alpha >= ALPHA_MIN;
+          // opacity * G, unclamped: the reference clamps alpha to 0.99 but lets dL/dalpha through to G unchanged, so
+          // G * dL/dG = (opacity G) dL/dalpha needs the unclamped product.  power2 > 0 can make it inf; such lanes are
+          // invalid and every use below selects, never multiplies, them away.
+          const float au = a1.w * __builtin_amdgcn_exp2f(power2);
+          const bool valid = contributor <= last && power2 <= 0.0f && au >= ALPHA_MIN;
           if (__any(valid)) {
             // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T and the colour behind then
-            // evolve exactly as if it had been skipped, so the replay state needs no per-field selects; only alpha itself
-            // and dL/dalpha are masked.
-            const float al = valid ? alpha : 0.f;
+            // evolve exactly as if it had been skipped, so the replay state needs no per-field selects.
+            const float av = valid ? au : 0.f;
+            const float al = fminf(0.99f, av);
             const float inv_one_m = __builtin_amdgcn_rcpf(1.f - al);  // v_rcp_f32 (1 ulp) instead of two IEEE divisions
             Tr = Tr * inv_one_m;                                       // transmittance in front of this Gaussian
             // dC/dalpha_k = c_k T_k - (sum_{j behind k} c_j alpha_j T_j + T_final bg) / (1 - alpha_k).  Contracted with
             // dL/dC first, the "colour behind" term is ONE running scalar (behind) instead of the reference's three-channel
             // accum_rec / last_color / last_alpha recursion (same quantity: accum_rec_k = sum_{j>k} c_j alpha_j T_j / T_{k+1}).
             const float cg = a2.x * g0 + a2.y * g1 + a2.z * g2;
-            float dL_dalpha = Tr * cg - behind * inv_one_m;
-            dL_dalpha = valid ? dL_dalpha : 0.f;
+            const float dL_dalpha = Tr * cg - behind * inv_one_m;
             const float dchannel = al * Tr;
             behind += cg * dchannel;
             // Moments of w = G * dL/dG over the wave's pixels: every screen-space gradient of this Gaussian is a fixed
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
             // k_preprocess_bwd instead of once per pixel here:
             //   dL/dconic = (-1/2 sum w dx^2, -sum w dx dy, -1/2 sum w dy^2),  dL/dopacity = sum w / opacity,
             //   dL/dmean2D = -(a sum w dx + b sum w dy, c sum w dy + b sum w dx) * (W/2, H/2)
-            const float w = G * (a1.w * dL_dalpha);
+            const float w = av * dL_dalpha;
             const gs_v2f t01 = gs_v2f{w, w} * d;               // sum w dx, sum w dy
             const gs_v2f t24 = t01 * d;                        // sum w dx^2, sum w dy^2
             const float t0 = t01[0], t1 = t01[1], t2 = t24[0], t4 = t24[1];
@@ -274,43 +303,53 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int
             const float t5 = w;                                // sum w
             const gs_v2f t67 = gs_v2f{dchannel, dchannel} * g01;
             const float t6 = t67[0], t7 = t67[1], t8 = gs_opaque(dchannel * g2);  // dL/drgb
-            // lanes differing in bit 0 (quad_perm [1,0,3,2]) then bit 1 (quad_perm [2,3,0,1])
-            const float w0 = gs_pair_reduce<0xB1>(bit0, t0, t1), w1 = gs_pair_reduce<0xB1>(bit0, t2, t3);
-            const float w2 = gs_pair_reduce<0xB1>(bit0, t4, t5), w3 = gs_pair_reduce<0xB1>(bit0, t6, t7);
-            const float w4 = t8 + gs_dpp<0xB1>(t8);
-            float x0 = gs_pair_reduce<0x4E>(bit1, w0, w1);  // component 2*bit1 + bit0, summed over the quad
-            float x1 = gs_pair_reduce<0x4E>(bit1, w2, w3);  // component 4 + 2*bit1 + bit0
-            float x2 = w4 + gs_dpp<0x4E>(w4);               // component 8
-            // the four quads of each 16-lane row, still transposed: row_ror:4 pairs quads of opposite parity (even quads
-            // keep x0, odd quads x1), row_ror:8 pairs the half rows (low half keeps the x0/x1 mix, high half x2); both
-            // rotations keep the low two lane bits, so lane l < 9 of every row ends up with component l of the row sum
-            const float y0 = gs_pair_reduce<0x124>(bit2, x0, x1);
-            const float y1 = x2 + gs_dpp<0x124>(x2);
-            float mine = gs_pair_reduce<0x128>(bit3, y0, y1);
-            mine = gs_sum_rows(mine);  // the four rows
-            if (lane < 9) atomicAdd(reinterpret_cast<float*>(grads + id) + lane, mine);
+            // Nine values x 64 lanes -> nine sums, transposed so that every step halves the number of live values:
+            // rows first (v_permlane16/32_swap pair steps, two ops per pair), then lane bits 0 and 1 inside the row (DPP
+            // quad_perm pair steps), then the four quads of the row (row_ror:4, row_ror:8) on the single survivor.
+            const float u0 = gs_pair_reduce_rows16(t0, t1), u1 = gs_pair_reduce_rows16(t2, t3);
+            const float u2 = gs_pair_reduce_rows16(t4, t5), u3 = gs_pair_reduce_rows16(t6, t7);
+            const float u4 = gs_pair_reduce_rows16(t8, t8);
+            const float v0 = gs_pair_reduce_rows32(u0, u1);  // row r holds component r     (t0..t3)
+            const float v1 = gs_pair_reduce_rows32(u2, u3);  // row r holds component 4 + r (t4..t7)
+            const float v2 = gs_pair_reduce_rows32(u4, u4);  // every row holds component 8
+            const float y0 = gs_pair_reduce<0xB1>(bit0, v0, v1);
+            const float y1 = v2 + gs_dpp<0xB1>(v2);
+            float mine = gs_pair_reduce<0x4E>(bit1, y0, y1);
+            mine += gs_dpp<0x124>(mine);
+            mine += gs_dpp<0x128>(mine);
+            // lanes 16r and 16r+1 now hold components r and 4+r, lane 2 holds component 8
+            if (out_lane) atomicAdd(reinterpret_cast<float*>(grads + id) + out_comp, mine);
           }
         };
         int iA = k + 63 - __clzll((long long)mask), iB = iA;
         float4 A0 = s_q0[iA], A1 = s_q1[iA], A2 = s_q2[iA], B0 = A0, B1 = A1, B2 = A2;
-        uint32_t idA = s_id[iA], idB = idA;
         for (;;) {
           mask &= ~(1ull << (iA - k));
           const bool moreB = mask != 0;
           if (moreB) iB = k + 63 - __clzll((long long)mask);
-          B0 = s_q0[iB]; B1 = s_q1[iB]; B2 = s_q2[iB]; idB = s_id[iB];
-          replay_one(A0, A1, A2, idA, iA);
+          B0 = s_q0[iB]; B1 = s_q1[iB]; B2 = s_q2[iB];
+          replay_one(A0, A1, A2, iA);
           if (!moreB) break;
           mask &= ~(1ull << (iB - k));
           const bool moreA = mask != 0;
           if (moreA) iA = k + 63 - __clzll((long long)mask);
-          A0 = s_q0[iA]; A1 = s_q1[iA]; A2 = s_q2[iA]; idA = s_id[iA];
-          replay_one(B0, B1, B2, idB, iB);
+          A0 = s_q0[iA]; A1 = s_q1[iA]; A2 = s_q2[iA];
+          replay_one(B0, B1, B2, iB);
           if (!moreA) break;
         }
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int H, uint32_t capacity,
+                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
+                                                        const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                                        const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
+                                                        const uint32_t* __restrict__ order, GsSched* sched, int NB) {
+  GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
+                          composite_bwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, final_T, n_contrib, dL_dpix, grads))
 }
 
 // per-tile max of n_contrib -> R_eff (roofline accounting only)
@@ -342,16 +381,18 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
 
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
-                            uint32_t* n_contrib) {
-  hipLaunchKernelGGL(k_composite_fwd, dim3(gs_grid_for_tiles(T)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
-                     recs, bg, out_color, final_T, n_contrib);
+                            uint32_t* n_contrib, const uint32_t* order, GsSched* sched) {
+  const int NB = gs_num_cus();
+  hipLaunchKernelGGL(k_composite_fwd, dim3(gs_grid_persistent(T, NB)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
+                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB);
   return 0;
 }
 
 int gs_launch_composite_bwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
-                            const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads) {
-  hipLaunchKernelGGL(k_composite_bwd, dim3(gs_grid_for_tiles(T)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
-                     recs, bg, final_T, n_contrib, dL_dpix, grads);
+                            const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const uint32_t* order, GsSched* sched) {
+  const int NB = gs_num_cus();
+  hipLaunchKernelGGL(k_composite_bwd, dim3(gs_grid_persistent(T, NB)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
+                     recs, bg, final_T, n_contrib, dL_dpix, grads, order, sched + GS_SCHED_BWD, NB);
   return 0;
 }

@@ -62,6 +62,10 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// six "compute units": fewer bins than the emulated placement has CUs, several tiles per bin
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 6; return hipSuccess; }
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
@@ -377,6 +381,13 @@ static inline emu_uint2v __builtin_amdgcn_permlane32_swap(unsigned old, unsigned
   r.v[1] = l >= 32 ? S(l) : D(l + 32);
   return r;
 }
+// hardware-id registers: a made-up, scattered placement (7 "CUs" x 2 "XCCs") so the tile scheduler's claim / steal paths run
+static inline unsigned __builtin_amdgcn_s_getreg(int simm16) {
+  const unsigned b = blockIdx.x;
+  return (simm16 & 63) == 20 ? (b & 1u) : (((b * 5u + 3u) % 7u) << 8);
+}
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
