@@ -17,7 +17,7 @@ namespace {
 
 constexpr int SCAN_THREADS = 1024;
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_SMALL_CAP = 2048;  // small kernel: <= 8 keys per thread, 16 KiB LDS, ~40 VGPRs -> 8 workgroups per CU
+constexpr int SORT_SMALL_CAP = GS_SORT_SMALL_CAP;  // small kernel: <= 8 keys per thread, 16 KiB LDS, ~40 VGPRs -> 8 workgroups per CU
 constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64 KiB LDS
 
 // ---- K2: exclusive scan of per-tile counts (T <= ~10^5 fits one workgroup comfortably)
@@ -27,7 +27,7 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 // words are cleared.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ sched_words,
-                                                               int n_sched_words) {
+                                                               int n_sched_words, uint32_t* __restrict__ meta) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -65,7 +65,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     if (lane == 0) atomicMax(&s_max, mx);
     __syncthreads();
     const uint32_t cmax = max(s_max, 1u);
-    auto bucket = [&](uint32_t c) { return (uint32_t)(SCAN_THREADS - 1) - (uint32_t)(((uint64_t)c * (SCAN_THREADS - 1)) / cmax); };
+    // buckets 0..511: tiles for the large-tile sort kernel (count > SORT_SMALL_CAP), 512..1023: the others — so the
+    // large tiles are exactly the first meta[0] entries of order[]
+    constexpr uint32_t HALF = SCAN_THREADS / 2;
+    auto bucket = [&](uint32_t c) {
+      if (c > (uint32_t)SORT_SMALL_CAP)
+        return (HALF - 1) - (uint32_t)(((uint64_t)(c - SORT_SMALL_CAP - 1) * (HALF - 1)) / max(cmax - SORT_SMALL_CAP - 1, 1u));
+      return (SCAN_THREADS - 1) - (uint32_t)(((uint64_t)c * (HALF - 1)) / min(cmax, (uint32_t)SORT_SMALL_CAP));
+    };
     for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(count[i])], 1u);
     __syncthreads();
     // exclusive scan of the 1024 bucket sizes (one per thread)
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w)
       if (w < wave) hoff += hist_wave[w];
     hist[tid] = hoff + hi_ - h;
+    if (tid == (int)HALF) meta[0] = hoff + hi_ - h;  // tiles in buckets [0, HALF)
     __syncthreads();
     for (int i = lo; i < hi; ++i) order[atomicAdd(&hist[bucket(count[i])], 1u)] = (uint32_t)i;
     __syncthreads();
@@ -268,13 +276,121 @@ __device__ __forceinline__ void bitonic_sort_any(KeyPtr a, int n, int tid, int n
   }
 }
 
+// Lane exchange for the sort network without the LDS crossbar (ds_bpermute, two per 64-bit key): every partner pattern
+// of a bitonic network inside a wave is a DPP move or a gfx950 row swap.
+//   xor 1, 2: quad_perm          xor 4: row_shl:4 into banks 0,2 + row_shr:4 into banks 1,3      xor 8: row_ror:8
+//   xor 16 / 32: v_permlane16_swap / v_permlane32_swap of the value with itself, then pick by row / half
+//   flips (xor 2^k - 1): quad_perm [3,2,1,0], row_half_mirror, row_mirror (+ the xor-16 / xor-32 steps above)
+template <int CTRL>
+__device__ __forceinline__ uint32_t sort_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t sort_xor16(uint32_t u) {
+  const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return (threadIdx.x & 16) ? p[0] : p[1];
+}
+__device__ __forceinline__ uint32_t sort_xor32(uint32_t u) {
+  const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return (threadIdx.x & 32) ? p[0] : p[1];
+}
+template <int LM>
+__device__ __forceinline__ uint32_t lane_xchg32(uint32_t v) {
+  if constexpr (LM == 1) return sort_dpp<0xB1>(v);
+  else if constexpr (LM == 2) return sort_dpp<0x4E>(v);
+  else if constexpr (LM == 3) return sort_dpp<0x1B>(v);
+  else if constexpr (LM == 4) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);         // banks 0,2 <- lane + 4
+    return (uint32_t)__builtin_amdgcn_update_dpp(lo, (int)v, 0x114, 0xF, 0xA, false);     // banks 1,3 <- lane - 4
+  }
+  else if constexpr (LM == 7) return sort_dpp<0x141>(v);
+  else if constexpr (LM == 8) return sort_dpp<0x128>(v);
+  else if constexpr (LM == 15) return sort_dpp<0x140>(v);
+  else if constexpr (LM == 16) return sort_xor16(v);
+  else if constexpr (LM == 31) return sort_xor16(sort_dpp<0x140>(v));
+  else if constexpr (LM == 32) return sort_xor32(v);
+  else {
+    static_assert(LM == 63, "lane mask of a bitonic network inside a wave64");
+    return sort_xor32(sort_xor16(sort_dpp<0x140>(v)));
+  }
+}
+template <int LM>
+__device__ __forceinline__ uint64_t lane_xchg64(uint64_t v) {
+  return ((uint64_t)lane_xchg32<LM>((uint32_t)(v >> 32)) << 32) | lane_xchg32<LM>((uint32_t)v);
+}
+
 // Register/wave/LDS bitonic sort of one tile's keys: thread t owns E keys; key index
 //   i = wave * (64*E) + lane * E + e          (e = low bits, lane = middle 6 bits, wave = top 2 bits)
 // so compare-exchange partners at distance < E sit in the same thread, at distance < 64*E in the same wave
-// (one 64-bit lane shuffle, no barrier) and only the last two distance bits (across the 4 waves) go through
-// LDS: 3 barrier stages in total instead of one per network stage (55 for 1024 keys).
+// (VALU lane exchanges, no barrier) and only the last two distance bits (across the 4 waves) go through
+// LDS: 3 barrier stages in total instead of one per network stage (55 for 1024 keys).  The network is unrolled at
+// compile time (template recursion), so every partner pattern is a constant.
 // Slots >= n hold 0xFFFF... (sorts last, never written back).  Keys are distinct (they end in the Gaussian index), so
 // "the lower position keeps the minimum" is one 64-bit compare: take the partner's key iff (partner < mine) == lower.
+template <int E, int KK>
+__device__ __forceinline__ void sort_flip_stage(uint64_t (&k)[E], uint64_t* __restrict__ s_keys, int base) {
+  // partner = i ^ (KK-1); the lower index keeps the minimum
+  constexpr int m = KK - 1;
+  if constexpr (KK <= E) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int pe = e ^ (m & (E - 1));
+      if (e < pe) { const uint64_t a = k[e], b = k[pe]; if (a > b) { k[e] = b; k[pe] = a; } }
+    }
+  } else if constexpr (KK <= 64 * E) {
+    constexpr int lm = (m / E) & 63;  // lane bits of the mask
+    uint64_t other[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) other[e] = lane_xchg64<lm>(k[E - 1 - e]);
+    const bool lower = (base & (KK >> 1)) == 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = other[e]; k[e] = ((b < a) == lower) ? b : a; }
+  } else {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_keys[base + e] = k[e];
+    __syncthreads();
+    const bool lower = (base & (KK >> 1)) == 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ m]; k[e] = ((b < a) == lower) ? b : a; }
+  }
+}
+
+template <int E, int D>
+__device__ __forceinline__ void sort_disperse_from(uint64_t (&k)[E], uint64_t* __restrict__ s_keys, int base) {
+  // partner = i ^ D, then D/2, ... 1
+  if constexpr (D >= 1) {
+    if constexpr (D < E) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int pe = e ^ D;
+        if (e < pe) { const uint64_t a = k[e], b = k[pe]; if (a > b) { k[e] = b; k[pe] = a; } }
+      }
+    } else if constexpr (D < 64 * E) {
+      const bool lower = (base & D) == 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = lane_xchg64<D / E>(a); k[e] = ((b < a) == lower) ? b : a; }
+    } else {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) s_keys[base + e] = k[e];
+      __syncthreads();
+      const bool lower = (base & D) == 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ D]; k[e] = ((b < a) == lower) ? b : a; }
+    }
+    sort_disperse_from<E, D / 2>(k, s_keys, base);
+  }
+}
+
+template <int E, int KK, int NP2>
+__device__ __forceinline__ void sort_merge_from(uint64_t (&k)[E], uint64_t* __restrict__ s_keys, int base) {
+  if constexpr (KK <= NP2) {
+    sort_flip_stage<E, KK>(k, s_keys, base);
+    sort_disperse_from<E, KK / 4>(k, s_keys, base);
+    sort_merge_from<E, KK * 2, NP2>(k, s_keys, base);
+  }
+}
+
 template <int E>
 __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
                                                uint32_t s, int n) {
@@ -283,59 +399,7 @@ __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, co
   uint64_t k[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) k[e] = (base + e < n) ? keys[s + base + e] : ~0ull;
-  constexpr int NP2 = SORT_THREADS * E;
-  for (int kk = 2; kk <= NP2; kk <<= 1) {
-    // ---- flip stage: partner = i ^ (kk-1); the lower index keeps the minimum
-    {
-      const int m = kk - 1;
-      if (kk <= E) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int pe = e ^ (m & (E - 1));
-          if (e < pe) { const uint64_t a = k[e], b = k[pe]; if (a > b) { k[e] = b; k[pe] = a; } }
-        }
-      } else if (kk <= 64 * E) {
-        const int lm = (m / E) & 63;  // lane bits of the mask
-        uint64_t other[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) other[e] = __shfl_xor(k[E - 1 - e], lm);
-        const bool lower = ((base) & (kk >> 1)) == 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = other[e]; k[e] = ((b < a) == lower) ? b : a; }
-      } else {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e) s_keys[base + e] = k[e];
-        __syncthreads();
-        const bool lower = (base & (kk >> 1)) == 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ m]; k[e] = ((b < a) == lower) ? b : a; }
-      }
-    }
-    // ---- disperse stages: partner = i ^ d
-    for (int d = kk >> 2; d >= 1; d >>= 1) {
-      if (d < E) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int pe = e ^ d;
-          if (e < pe) { const uint64_t a = k[e], b = k[pe]; if (a > b) { k[e] = b; k[pe] = a; } }
-        }
-      } else if (d < 64 * E) {
-        const int lm = d / E;
-        const bool lower = (base & d) == 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = __shfl_xor(a, lm); k[e] = ((b < a) == lower) ? b : a; }
-      } else {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e) s_keys[base + e] = k[e];
-        __syncthreads();
-        const bool lower = (base & d) == 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { const uint64_t a = k[e], b = s_keys[(base + e) ^ d]; k[e] = ((b < a) == lower) ? b : a; }
-      }
-    }
-  }
+  sort_merge_from<E, 2, SORT_THREADS * E>(k, s_keys, base);
 #pragma unroll
   for (int e = 0; e < E; ++e)
     if (base + e < n) list[s + base + e] = (uint32_t)k[e];
@@ -344,45 +408,57 @@ __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, co
 // Two launches per frame: the small-tile kernel keeps its register and LDS footprint low so 8 workgroups fit a CU
 // (a single kernel with the 32-keys-per-thread path compiled in needs 134 VGPRs and ran one workgroup per CU);
 // the large-tile kernel exits at once for every tile the small one handled.
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_small(int T, const uint32_t* __restrict__ start,
-                                                                    const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
-                                                                    uint32_t capacity) {
+__device__ __forceinline__ void sort_small_tile(int tile, const uint32_t* __restrict__ start, const uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ list, uint32_t capacity) {
   __shared__ uint64_t s_keys[SORT_SMALL_CAP];
-  const int tile = gs_tile_of_block(blockIdx.x, T);
-  if (tile >= T) return;
+  if (start[tile + 1] - start[tile] > (uint32_t)SORT_SMALL_CAP) return;  // the large-tile kernel's (same test there)
   const uint32_t s = min(start[tile], capacity), e = min(start[tile + 1], capacity);
   const int n = (int)(e - s);
-  if (n <= 0 || n > SORT_SMALL_CAP) return;
+  if (n <= 0) return;
   if (n <= SORT_THREADS) sort_tile_regs<1>(s_keys, keys, list, s, n);
   else if (n <= SORT_THREADS * 2) sort_tile_regs<2>(s_keys, keys, list, s, n);
   else if (n <= SORT_THREADS * 4) sort_tile_regs<4>(s_keys, keys, list, s, n);
   else sort_tile_regs<8>(s_keys, keys, list, s, n);
 }
 
+// persistent workgroups over the CU-balanced tile bins (common.h, GsSched)
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_small(int T, const uint32_t* __restrict__ start,
+                                                                    const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
+                                                                    uint32_t capacity, const uint32_t* __restrict__ order, GsSched* sched,
+                                                                    int NB) {
+  GS_PERSISTENT_TILE_LOOP(sched, NB, T, order, sort_small_tile(tile, start, keys, list, capacity))
+}
+
+// the tiles with more than SORT_SMALL_CAP instances are the first meta[0] entries of order[] (usually none)
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_large(int T, const uint32_t* __restrict__ start, uint64_t* __restrict__ keys,
-                                                                    uint32_t* __restrict__ list, uint32_t capacity) {
+                                                                    uint32_t* __restrict__ list, uint32_t capacity,
+                                                                    const uint32_t* __restrict__ order, const uint32_t* __restrict__ meta) {
   __shared__ uint64_t s_keys[SORT_LDS_CAP];
-  const int tile = gs_tile_of_block(blockIdx.x, T);
-  if (tile >= T) return;
-  const uint32_t s = min(start[tile], capacity), e = min(start[tile + 1], capacity);
-  const int n = (int)(e - s);
-  if (n <= SORT_SMALL_CAP) return;
+  const int n_large = (int)min(meta[0], (uint32_t)T);
   const int tid = threadIdx.x;
-  if (n <= SORT_THREADS * 16) sort_tile_regs<16>(s_keys, keys, list, s, n);
-  else if (n <= SORT_THREADS * 32) sort_tile_regs<32>(s_keys, keys, list, s, n);
-  else {
-    uint64_t* seg = keys + s;
-    bitonic_sort_any(seg, n, tid, SORT_THREADS);
-    for (int i = tid; i < n; i += SORT_THREADS) list[s + i] = (uint32_t)seg[i];
+  for (int idx = blockIdx.x; idx < n_large; idx += gridDim.x) {
+    const int tile = (int)order[idx];
+    const uint32_t s = min(start[tile], capacity), e = min(start[tile + 1], capacity);
+    const int n = (int)(e - s);
+    if (n > 0) {
+      if (n <= SORT_THREADS * 16) sort_tile_regs<16>(s_keys, keys, list, s, n);
+      else if (n <= SORT_THREADS * 32) sort_tile_regs<32>(s_keys, keys, list, s, n);
+      else {
+        uint64_t* seg = keys + s;
+        bitonic_sort_any(seg, n, tid, SORT_THREADS);
+        for (int i = tid; i < n; i += SORT_THREADS) list[s + i] = (uint32_t)seg[i];
+      }
+    }
+    __syncthreads();
   }
 }
 
 }  // namespace
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
-                         GsSched* sched) {
+                         GsSched* sched, uint32_t* meta) {
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order,
-                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4));
+                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4), meta);
   return 0;
 }
 
@@ -391,7 +467,7 @@ int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
-                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0);  // in place
+                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0, (uint32_t*)nullptr);  // in place
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
 }
@@ -406,14 +482,17 @@ int gs_launch_count_tiles(hipStream_t stream, int P, int T, int gx, const uint2*
 }
 
 int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const GsRec* recs, const uint2* rects, const uint32_t* start,
-                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity) {
+                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity, const uint32_t* order, GsSched* sched,
+                      const uint32_t* meta) {
   if (P <= 0 || capacity == 0) return 0;
   if (T <= BIN_MAX_LDS_TILES)
     hipLaunchKernelGGL(k_scatter_lds, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), (size_t)T * 4, stream, P, T, gx, recs, rects,
                        start, cursor, keys, capacity);
   else
     hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, recs, rects, start, cursor, keys, capacity);
-  hipLaunchKernelGGL(k_sort_tiles_small, dim3(gs_grid_for_tiles(T)), dim3(SORT_THREADS), 0, stream, T, start, (const uint64_t*)keys, list, capacity);
-  hipLaunchKernelGGL(k_sort_tiles_large, dim3(gs_grid_for_tiles(T)), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity);
+  const int NB = gs_num_cus();
+  hipLaunchKernelGGL(k_sort_tiles_small, dim3(gs_grid_persistent(T, NB)), dim3(SORT_THREADS), 0, stream, T, start, (const uint64_t*)keys, list,
+                     capacity, order, sched + GS_SCHED_SORT, NB);
+  hipLaunchKernelGGL(k_sort_tiles_large, dim3(T < NB ? T : NB), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order, meta);
   return 0;
 }

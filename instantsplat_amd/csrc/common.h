@@ -61,10 +61,11 @@ struct GsSched {
   uint32_t next[GS_SCHED_SLOTS];    // per-bin pop counter
   uint32_t claimed, done, pad0, pad1;
 };
-enum { GS_SCHED_FWD = 0, GS_SCHED_BWD = 1, GS_SCHED_COUNT = 2 };
+enum { GS_SCHED_FWD = 0, GS_SCHED_BWD = 1, GS_SCHED_SORT = 2, GS_SCHED_COUNT = 3 };
+constexpr int GS_SORT_SMALL_CAP = 2048;  // tiles above this many instances are sorted by the large-tile kernel; k_scan_tiles puts them first in `order`
 
 struct TilesLayout {
-  size_t count, start, cursor, final_T, n_contrib, order, sched, total;
+  size_t count, start, cursor, final_T, n_contrib, order, sched, meta, total;
   int gx, gy, T;
   __host__ TilesLayout(int W, int H) {
     gx = (W + GS_TILE - 1) / GS_TILE; gy = (H + GS_TILE - 1) / GS_TILE; T = gx * gy;
@@ -76,6 +77,7 @@ struct TilesLayout {
     n_contrib = o; o += gs_align(npix * 4);
     order = o; o += gs_align((size_t)T * 4);
     sched = o; o += gs_align(GS_SCHED_COUNT * sizeof(GsSched));
+    meta = o; o += gs_align(16);   // [0]: number of tiles with more than GS_SORT_SMALL_CAP instances
     total = o;
   }
 };
@@ -254,6 +256,25 @@ __device__ __forceinline__ void gs_sched_finish(GsSched* s) {
   if (s_last)
     for (int i = threadIdx.x; i < (int)(sizeof(GsSched) / 4); i += blockDim.x) reinterpret_cast<uint32_t*>(s)[i] = 0u;
 }
+
+// Persistent workgroups over the CU-balanced tile bins (common.h, GsSched).
+#define GS_PERSISTENT_TILE_LOOP(sched, NB, T, order, CALL)                     \
+  __shared__ int s_tile;                                                        \
+  const int wave_ = threadIdx.x >> 6;                                           \
+  int bin_ = 0;                                                                 \
+  if (wave_ == 0) bin_ = gs_sched_claim(sched, NB);                             \
+  for (;;) {                                                                    \
+    if (wave_ == 0) {                                                           \
+      const int t_ = gs_sched_pop(sched, bin_, NB, T, order);                   \
+      if ((threadIdx.x & 63) == 0) s_tile = t_;                                 \
+    }                                                                           \
+    __syncthreads();                                                            \
+    const int tile = s_tile;                                                    \
+    if (tile < 0) break;                                                        \
+    CALL;                                                                       \
+    __syncthreads(); /* s_tile and the tile's LDS staging are reused */         \
+  }                                                                             \
+  gs_sched_finish(sched);
 
 #define GS_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \

@@ -167,25 +167,6 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
   }
 }
 
-// Persistent workgroups over the CU-balanced tile bins (common.h, GsSched).
-#define GS_PERSISTENT_TILE_LOOP(sched, NB, T, order, CALL)                     \
-  __shared__ int s_tile;                                                        \
-  const int wave_ = threadIdx.x >> 6;                                           \
-  int bin_ = 0;                                                                 \
-  if (wave_ == 0) bin_ = gs_sched_claim(sched, NB);                             \
-  for (;;) {                                                                    \
-    if (wave_ == 0) {                                                           \
-      const int t_ = gs_sched_pop(sched, bin_, NB, T, order);                   \
-      if ((threadIdx.x & 63) == 0) s_tile = t_;                                 \
-    }                                                                           \
-    __syncthreads();                                                            \
-    const int tile = s_tile;                                                    \
-    if (tile < 0) break;                                                        \
-    CALL;                                                                       \
-    __syncthreads(); /* s_tile and the tile's LDS staging are reused */         \
-  }                                                                             \
-  gs_sched_finish(sched);
-
 __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity,
                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
