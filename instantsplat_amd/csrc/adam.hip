@@ -5,7 +5,7 @@
 //   - eps is added to sqrt(v) before bias correction (folded into step_size, :72-76);
 //   - an optional per-point multiplier scales the step of every element of a point's row (:87-88);
 //     the reference computes an adjusted multiplier and discards it (:89), so it stays constant.
-// HBM-bound: 16 B read + 12 B written per element.
+// HBM-bound: 16 B read + 12 B written per element (4 B read for a gated-off tensor whose first moment is still zero).
 #include <math.h>
 #include "common.h"
 
@@ -18,7 +18,9 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, int row, float* __restr
   const bool update = grad_sumsq ? (*grad_sumsq > 0.f) : true;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float m = exp_avg[i], v = exp_avg_sq[i];
+    float m = exp_avg[i];
+    if (!update && m == 0.f) continue;  // gated-off tensor, zero first moment: p - s * (0 / denom) == p bit for bit
+    float v = exp_avg_sq[i];
     if (update) {
       const float g = grad[i];
       m = m * beta1 + g * (1.f - beta1);
@@ -92,7 +94,12 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
   const int row = a.row[t];
   const float step_size = a.step_size[t];
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    float m = mm[i], v = vv[i];
+    float m = mm[i];
+    // A tensor whose gradient is all zero keeps its moments but still takes the parameter step (the reference's
+    // whole-tensor gate).  Where the first moment is zero that step is p - s * (0 / denom) == p bit for bit, so only
+    // exp_avg is read: f_rest before the SH degree is raised costs 4 B per element instead of 16.
+    if (!update && m == 0.f) continue;
+    float v = vv[i];
     if (update) {
       const float gi = g[i];
       m = m * beta1 + gi * (1.f - beta1);

@@ -165,19 +165,45 @@ __device__ __forceinline__ bool unpack_rect(uint2 r, int& x0, int& y0, int& x1, 
   return x1 > x0 && y1 > y0;
 }
 
-__global__ __launch_bounds__(256) void k_count_tiles_lds(int P, int T, int gx, const uint2* __restrict__ rects,
-                                                          uint32_t* __restrict__ tile_count) {
-  HIP_DYNAMIC_SHARED(uint32_t, s_bins)
+// A thread walks its own Gaussian's tile rectangle only when that is short: one Gaussian that has grown over hundreds of
+// tiles would otherwise keep a single lane busy (with a dependent LDS-atomic -> global-store chain per tile in the scatter)
+// long after the rest of the grid has finished — measured on the C3 run as k_scatter_lds drifting from 8 to 60 us while
+// the instance count grew by 13 %.  Rectangles above BIN_WIDE tiles are queued in LDS and walked by a 16-lane row each.
+constexpr int BIN_WIDE = 8;
+
+template <class F>
+__device__ __forceinline__ void for_each_instance(int lo, int hi, const uint2* __restrict__ rects, uint32_t* s_wide, uint32_t* s_nwide,
+                                                  F&& f) {
   const int tid = threadIdx.x;
-  for (int t = tid; t < T; t += 256) s_bins[t] = 0;
-  __syncthreads();
-  const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
   for (int i = lo + tid; i < hi; i += 256) {
     int x0, y0, x1, y1;
     if (!unpack_rect(rects[i], x0, y0, x1, y1)) continue;
+    if ((x1 - x0) * (y1 - y0) > BIN_WIDE) { s_wide[atomicAdd(s_nwide, 1u)] = (uint32_t)i; continue; }
     for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) atomicAdd(&s_bins[y * gx + x], 1u);
+      for (int x = x0; x < x1; ++x) f(i, x, y);
   }
+  __syncthreads();
+  const int nwide = (int)*s_nwide;
+  for (int q = tid >> 4; q < nwide; q += 16) {  // one 16-lane row per queued Gaussian
+    const int i = (int)s_wide[q];
+    int x0, y0, x1, y1;
+    unpack_rect(rects[i], x0, y0, x1, y1);
+    const int w = x1 - x0, n = w * (y1 - y0);
+    for (int j = tid & 15; j < n; j += 16) f(i, x0 + j % w, y0 + j / w);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_count_tiles_lds(int P, int T, int gx, const uint2* __restrict__ rects,
+                                                          uint32_t* __restrict__ tile_count) {
+  HIP_DYNAMIC_SHARED(uint32_t, s_bins)
+  __shared__ uint32_t s_wide[BIN_CHUNK];
+  __shared__ uint32_t s_nwide;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < T; t += 256) s_bins[t] = 0;
+  if (tid == 0) s_nwide = 0;
+  __syncthreads();
+  const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
+  for_each_instance(lo, hi, rects, s_wide, &s_nwide, [&](int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
   __syncthreads();
   for (int t = tid; t < T; t += 256) {
     const uint32_t c = s_bins[t];
@@ -189,32 +215,26 @@ __global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const
                                                       const uint2* __restrict__ rects, const uint32_t* __restrict__ start,
                                                       uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, uint32_t capacity) {
   HIP_DYNAMIC_SHARED(uint32_t, s_bins)
+  __shared__ uint32_t s_wide[BIN_CHUNK];
+  __shared__ uint32_t s_nwide;
   const int tid = threadIdx.x;
   for (int t = tid; t < T; t += 256) s_bins[t] = 0;
+  if (tid == 0) s_nwide = 0;
   __syncthreads();
   const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
-  for (int i = lo + tid; i < hi; i += 256) {
-    int x0, y0, x1, y1;
-    if (!unpack_rect(rects[i], x0, y0, x1, y1)) continue;
-    for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) atomicAdd(&s_bins[y * gx + x], 1u);
-  }
+  for_each_instance(lo, hi, rects, s_wide, &s_nwide, [&](int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
   __syncthreads();
   for (int t = tid; t < T; t += 256) {
     const uint32_t c = s_bins[t];
     if (c) s_bins[t] = start[t] + atomicAdd(&cursor[t], c);  // first slot of this workgroup's range in tile t
   }
+  if (tid == 0) s_nwide = 0;
   __syncthreads();
-  for (int i = lo + tid; i < hi; i += 256) {
-    int x0, y0, x1, y1;
-    if (!unpack_rect(rects[i], x0, y0, x1, y1)) continue;
+  for_each_instance(lo, hi, rects, s_wide, &s_nwide, [&](int i, int x, int y) {
     const uint64_t key = ((uint64_t)__float_as_uint(recs[i].q2.w) << 32) | (uint32_t)i;
-    for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) {
-        const uint32_t pos = atomicAdd(&s_bins[y * gx + x], 1u);
-        if (pos < capacity) keys[pos] = key;
-      }
-  }
+    const uint32_t pos = atomicAdd(&s_bins[y * gx + x], 1u);
+    if (pos < capacity) keys[pos] = key;
+  });
 }
 
 // direct global-atomic variants for tile grids too large for an LDS histogram
