@@ -303,7 +303,8 @@ __device__ __forceinline__ void bitonic_sort_any(KeyPtr a, int n, int tid, int n
 //   flips (xor 2^k - 1): quad_perm [3,2,1,0], row_half_mirror, row_mirror (+ the xor-16 / xor-32 steps above)
 template <int CTRL>
 __device__ __forceinline__ uint32_t sort_dpp(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+  // every lane has an in-range source for these patterns, so bound_ctrl only spares the compiler a zero-initialised `old`
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t sort_xor16(uint32_t u) {
   const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);

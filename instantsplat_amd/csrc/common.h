@@ -52,14 +52,17 @@ struct GeomLayout {
 // is not predictable from its index).  The per-tile kernels therefore run as persistent workgroups over per-CU bins:
 // k_scan_tiles orders the tiles by instance count (descending) and bin b owns the entries b, 2NB-1-b, 2NB+b, ... of that
 // order (a serpentine deal, NB = number of CUs, bin loads within ~2 % of each other); the first workgroup to start on a
-// physical CU (s_getreg HW_ID / XCC_ID) claims a bin for that CU, workgroups pop tiles from their CU's bin and steal from
-// the other bins once it is empty.  Placement only affects speed: any mapping of workgroups to bins processes every tile
+// physical CU (s_getreg HW_ID / XCC_ID) claims a bin for that CU, workgroups pop tiles from their CU's bin and, once it is
+// empty, from bins that no CU claimed.  Placement only affects speed: any mapping of workgroups to bins processes every tile
 // exactly once.
 constexpr int GS_SCHED_SLOTS = 512;  // >= physical CU ids (xcc:3 | se:2 | cu:4) and >= NB
 struct GsSched {
   uint32_t cu_bin[GS_SCHED_SLOTS];  // physical CU -> 2 + bin (0: unclaimed, 1: claim in progress)
   uint32_t next[GS_SCHED_SLOTS];    // per-bin pop counter
-  uint32_t claimed, done, pad0, pad1;
+  // `claimed` is read by finishing workgroups and `done` is incremented by them: on separate 64-byte lines, because a
+  // line that takes loads and device-scope atomics from all eight XCDs at once is very slow
+  uint32_t claimed, pad_a[15];
+  uint32_t done, pad_b[15];
 };
 enum { GS_SCHED_FWD = 0, GS_SCHED_BWD = 1, GS_SCHED_SORT = 2, GS_SCHED_COUNT = 3 };
 constexpr int GS_SORT_SMALL_CAP = 2048;  // tiles above this many instances are sorted by the large-tile kernel; k_scan_tiles puts them first in `order`
@@ -214,7 +217,10 @@ __device__ __forceinline__ int gs_sched_claim(GsSched* s, int NB) {
   return (int)__builtin_amdgcn_readfirstlane(v) - 2;
 }
 
-// next tile for this workgroup, or -1 when every bin is empty
+// Next tile for this workgroup, or -1.  A workgroup drains the bin of its CU; bins nobody claimed (fewer CUs received a
+// workgroup than there are bins) are drained by the first workgroups of the grid once their own bins are empty.  There is
+// deliberately no stealing from claimed bins: the bins are balanced by construction, and a scan of all bin counters by a
+// thousand workgroups finishing together cost 14 us of a 32 us kernel.
 __device__ __forceinline__ int gs_sched_pop(GsSched* s, int bin, int NB, int T, const uint32_t* __restrict__ order) {
   const int lane = threadIdx.x & 63;
   const uint32_t per_bin = (uint32_t)((T + NB - 1) / NB);
@@ -232,15 +238,21 @@ __device__ __forceinline__ int gs_sched_pop(GsSched* s, int bin, int NB, int T, 
     const int idx = take(bin);
     if (idx >= 0) return (int)order[idx];
   }
-  for (int base = 0; base < NB; base += 64) {  // steal: 64 bins inspected per step, starting after the own bin
-    const int off = base + lane;
+  // Only the first eight workgroups of the grid (one per XCD) look for unclaimed bins: a thousand workgroups reading this
+  // line when they finish cost more than the kernel they schedule (measured: +28 us on a 21 us kernel).
+  if (blockIdx.x >= 8) return -1;
+  uint32_t c = 0;
+  if (lane == 0) c = atomicAdd(&s->claimed, 0u);  // a stale (smaller) value would only cost failed tickets
+  const int first = (int)__builtin_amdgcn_readfirstlane(c), lim = NB < T ? NB : T;  // bins >= T hold no entries
+  for (int base = first; base < lim; base += 64) {
+    const int b2 = base + lane;
     bool avail = false;
-    if (off < NB) avail = __hip_atomic_load(&s->next[(bin + 1 + off) % NB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per_bin;
+    if (b2 < lim) avail = __hip_atomic_load(&s->next[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per_bin;
     unsigned long long mask = __ballot(avail);
     while (mask) {
       const int l = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
-      const int idx = take((bin + 1 + base + l) % NB);
+      const int idx = take(base + l);
       if (idx >= 0) return (int)order[idx];
     }
   }

@@ -64,8 +64,9 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-// six "compute units": fewer bins than the emulated placement has CUs, several tiles per bin
-static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 6; return hipSuccess; }
+// twenty "compute units" while the made-up placement below only ever uses fourteen: some bins are never claimed and must
+// be drained by the first workgroups of the grid
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 20; return hipSuccess; }
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
