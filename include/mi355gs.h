@@ -174,7 +174,7 @@ int mi355gs_adam_multi_step(void* stream, int ntensors, const int64_t* numel, co
  *   means_cam = rel_w2c @ [xyz,1], rot_cam = quadmultiply(pose[:4], rotation) (raw quaternions),
  *   opacity = sigmoid(_opacity), scales = exp(_scaling) (scene/gaussian_model.py:101-124) — and their
  *   autograd backward, including the reduction over all Gaussians to dL/dpose[7].
- *   pose[7] = (qw,qx,qy,qz,tx,ty,tz) on the device; scratch16: device float[16].
+ *   pose[7] = (qw,qx,qy,qz,tx,ty,tz) on the device; scratch: device float[32] (16 sums, a ticket counter, padding).
  * ---------------------------------------------------------------------------------------------- */
 int mi355gs_pose_forward(void* stream, int P, const float* xyz, const float* rot, const float* scaling,
                          const float* opacity_logit, const float* pose, float* means_cam, float* rot_cam, float* scales,
@@ -182,7 +182,7 @@ int mi355gs_pose_forward(void* stream, int P, const float* xyz, const float* rot
 int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* rot, const float* scales, const float* opac,
                           const float* pose, const float* g_means, const float* g_rot, const float* g_scales,
                           const float* g_opac, float* d_xyz, float* d_rot, float* d_scaling, float* d_opacity_logit,
-                          float* d_pose, float* scratch16);
+                          float* d_pose, float* scratch);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole train iteration in one call

@@ -442,12 +442,12 @@ __device__ __forceinline__ void sort_small_tile(int tile, const uint32_t* __rest
   else sort_tile_regs<8>(s_keys, keys, list, s, n);
 }
 
-// persistent workgroups over the CU-balanced tile bins (common.h, GsSched)
+// One workgroup per tile, heaviest tiles first (order[] from k_scan_tiles).  No persistent scheduling here: a tile's sort is
+// short and latency-bound, so the ~9 us of scheduler round trips cost more than CU balance gains (22 vs 13 us on C3).
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_small(int T, const uint32_t* __restrict__ start,
                                                                     const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
-                                                                    uint32_t capacity, const uint32_t* __restrict__ order, GsSched* sched,
-                                                                    int NB) {
-  GS_PERSISTENT_TILE_LOOP(sched, NB, T, order, sort_small_tile(tile, start, keys, list, capacity))
+                                                                    uint32_t capacity, const uint32_t* __restrict__ order) {
+  sort_small_tile((int)order[blockIdx.x], start, keys, list, capacity);
 }
 
 // the tiles with more than SORT_SMALL_CAP instances are the first meta[0] entries of order[] (usually none)
@@ -512,8 +512,7 @@ int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const GsRec* rec
   else
     hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, recs, rects, start, cursor, keys, capacity);
   const int NB = gs_num_cus();
-  hipLaunchKernelGGL(k_sort_tiles_small, dim3(gs_grid_persistent(T, NB)), dim3(SORT_THREADS), 0, stream, T, start, (const uint64_t*)keys, list,
-                     capacity, order, sched + GS_SCHED_SORT, NB);
+  hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(SORT_THREADS), 0, stream, T, start, (const uint64_t*)keys, list, capacity, order);
   hipLaunchKernelGGL(k_sort_tiles_large, dim3(T < NB ? T : NB), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order, meta);
   return 0;
 }

@@ -64,7 +64,7 @@ struct GsSched {
   uint32_t claimed, pad_a[15];
   uint32_t done, pad_b[15];
 };
-enum { GS_SCHED_FWD = 0, GS_SCHED_BWD = 1, GS_SCHED_SORT = 2, GS_SCHED_COUNT = 3 };
+enum { GS_SCHED_FWD = 0, GS_SCHED_BWD = 1, GS_SCHED_COUNT = 2 };
 constexpr int GS_SORT_SMALL_CAP = 2048;  // tiles above this many instances are sorted by the large-tile kernel; k_scan_tiles puts them first in `order`
 
 struct TilesLayout {
@@ -305,8 +305,16 @@ void gs_log_error(const char* where, const char* what);
 // and it collects the "gradient tensor has a non-zero" gate flags for PerPointAdam from the kernels that write the
 // gradients (gate[k] > 0  <=>  tensor k of the optimizer's group order has a non-zero gradient) instead of a
 // separate pass over all gradients.
+struct GsPrologue {  // accumulators of one train step, zeroed by the step's first kernel (k_pose_fwd) instead of memsets
+  float4* grad_records = nullptr; size_t n_vec = 0;      // the 48-byte GsGrad records, as float4
+  uint32_t* tile_counters = nullptr; int n_counters = 0;  // per-tile count + cursor
+  float* g_poses = nullptr; int n_pose = 0;
+  float* pose_scratch = nullptr;                           // 32 floats
+  float* adam_scratch = nullptr;                           // 8 gate flags
+};
 struct GsFusedStepHooks {
   bool skip_memsets = false;
+  GsPrologue prologue;
   float* gate = nullptr;   // device float[8] or null
   int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_sh_rest = -1, gate_pose = -1;
 };

@@ -40,9 +40,19 @@ __device__ __forceinline__ PoseMat load_pose(const float* __restrict__ pose) {
 __global__ __launch_bounds__(256) void k_pose_fwd(int P, const float* __restrict__ xyz, const float* __restrict__ rot,
                                                    const float* __restrict__ scaling, const float* __restrict__ opacity_logit,
                                                    const float* __restrict__ pose, float* __restrict__ means_cam,
-                                                   float* __restrict__ rot_cam, float* __restrict__ scales, float* __restrict__ opac) {
+                                                   float* __restrict__ rot_cam, float* __restrict__ scales, float* __restrict__ opac,
+                                                   GsPrologue pro) {
   const PoseMat m = load_pose(pose);
   const int stride = gridDim.x * blockDim.x;
+  if (pro.grad_records) {  // first kernel of a fused train step: clear the step's accumulators on the way
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = gid; i < pro.n_vec; i += (size_t)stride) pro.grad_records[i] = z;
+    for (size_t i = gid; i < (size_t)pro.n_counters; i += (size_t)stride) pro.tile_counters[i] = 0u;
+    if (gid < (size_t)pro.n_pose) pro.g_poses[gid] = 0.f;
+    if (gid < 32) pro.pose_scratch[gid] = 0.f;
+    if (gid < 8) pro.adam_scratch[gid] = 0.f;
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
     const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     means_cam[3 * (size_t)i] = m.R[0] * x + m.R[1] * y + m.R[2] * z + m.t[0];
@@ -60,6 +70,36 @@ __global__ __launch_bounds__(256) void k_pose_fwd(int P, const float* __restrict
     for (int k = 0; k < 3; ++k) scales[3 * (size_t)i + k] = expf(scaling[3 * (size_t)i + k]);
     opac[i] = 1.0f / (1.0f + expf(-opacity_logit[i]));
   }
+}
+
+// acc -> dL/dpose (run by one thread once every workgroup's partial sums are in)
+__device__ __forceinline__ void pose_finish(const float* __restrict__ pose, const float* acc, float* __restrict__ d_pose,
+                                            float* __restrict__ pose_gate) {
+  const PoseMat m = load_pose(pose);
+  const float* Rp = acc + 3;  // dL/dR, row-major: Rp[3*i+j]
+  const float r = m.qn[0], x = m.qn[1], y = m.qn[2], z = m.qn[3];
+  float gq[4];
+  gq[0] = 2.f * (z * (Rp[3] - Rp[1]) + y * (Rp[2] - Rp[6]) + x * (Rp[7] - Rp[5]));
+  gq[1] = 2.f * (y * (Rp[1] + Rp[3]) + z * (Rp[2] + Rp[6]) + r * (Rp[7] - Rp[5])) - 4.f * x * (Rp[4] + Rp[8]);
+  gq[2] = 2.f * (x * (Rp[1] + Rp[3]) + r * (Rp[2] - Rp[6]) + z * (Rp[5] + Rp[7])) - 4.f * y * (Rp[0] + Rp[8]);
+  gq[3] = 2.f * (r * (Rp[3] - Rp[1]) + x * (Rp[2] + Rp[6]) + y * (Rp[5] + Rp[7])) - 4.f * z * (Rp[0] + Rp[4]);
+  // through q_hat = q / |q|
+  const float dot = m.qn[0] * gq[0] + m.qn[1] * gq[1] + m.qn[2] * gq[2] + m.qn[3] * gq[3];
+  float d[7];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k] = (gq[k] - m.qn[k] * dot) * m.inv_norm + acc[12 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[4 + k] = acc[k];
+  bool nz = false;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { d_pose[k] = d[k]; nz = nz || d[k] != 0.f; }
+  if (pose_gate && nz) *pose_gate = 1.0f;
+}
+
+__global__ void k_pose_finish(const float* __restrict__ pose, const float* __restrict__ acc, float* __restrict__ d_pose,
+                              float* __restrict__ pose_gate) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  pose_finish(pose, acc, d_pose, pose_gate);
 }
 
 // acc[0..2] = dL/dt, acc[3..11] = dL/dR (row-major, sum of g_m (x) xyz), acc[12..15] = dL/dq_raw via the Hamilton product
@@ -133,30 +173,6 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
   }
 }
 
-__global__ void k_pose_finish(const float* __restrict__ pose, const float* __restrict__ acc, float* __restrict__ d_pose,
-                              float* __restrict__ pose_gate) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const PoseMat m = load_pose(pose);
-  const float* Rp = acc + 3;  // dL/dR, row-major: Rp[3*i+j]
-  const float r = m.qn[0], x = m.qn[1], y = m.qn[2], z = m.qn[3];
-  float gq[4];
-  gq[0] = 2.f * (z * (Rp[3] - Rp[1]) + y * (Rp[2] - Rp[6]) + x * (Rp[7] - Rp[5]));
-  gq[1] = 2.f * (y * (Rp[1] + Rp[3]) + z * (Rp[2] + Rp[6]) + r * (Rp[7] - Rp[5])) - 4.f * x * (Rp[4] + Rp[8]);
-  gq[2] = 2.f * (x * (Rp[1] + Rp[3]) + r * (Rp[2] - Rp[6]) + z * (Rp[5] + Rp[7])) - 4.f * y * (Rp[0] + Rp[8]);
-  gq[3] = 2.f * (r * (Rp[3] - Rp[1]) + x * (Rp[2] + Rp[6]) + y * (Rp[5] + Rp[7])) - 4.f * z * (Rp[0] + Rp[4]);
-  // through q_hat = q / |q|
-  const float dot = m.qn[0] * gq[0] + m.qn[1] * gq[1] + m.qn[2] * gq[2] + m.qn[3] * gq[3];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) d_pose[k] = (gq[k] - m.qn[k] * dot) * m.inv_norm + acc[12 + k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) d_pose[4 + k] = acc[k];
-  if (pose_gate) {
-    bool nz = false;
-    for (int k = 0; k < 7; ++k) nz = nz || d_pose[k] != 0.f;
-    if (nz) *pose_gate = 1.0f;
-  }
-}
-
 }  // namespace
 
 extern "C" {
@@ -171,7 +187,7 @@ int mi355gs_pose_forward(void* stream_, int P, const float* xyz, const float* ro
   if (!xyz || !rot || !scaling || !opacity_logit || !means_cam || !rot_cam || !scales || !opac) return MI355GS_EINVAL;
   const int blocks = min((P + 255) / 256, 4096);
   hipLaunchKernelGGL(k_pose_fwd, dim3(blocks), dim3(256), 0, stream, P, xyz, rot, scaling, opacity_logit, pose, means_cam, rot_cam,
-                     scales, opac);
+                     scales, opac, g_fused.prologue);
   GS_CHECK_LAUNCH("pose_fwd");
   return MI355GS_OK;
 }
@@ -183,7 +199,8 @@ int mi355gs_pose_backward(void* stream_, int P, const float* xyz, const float* r
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (P < 0 || !pose || !d_pose || !scratch16) return MI355GS_EINVAL;
-  if (!g_fused.skip_memsets && hipMemsetAsync(scratch16, 0, 16 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if (!g_fused.skip_memsets && hipMemsetAsync(scratch16, 0, 32 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  float* pose_gate = (g_fused.gate && g_fused.gate_pose >= 0) ? g_fused.gate + g_fused.gate_pose : nullptr;
   if (P > 0) {
     if (!xyz || !rot || !scales || !opac || !g_means || !g_rot || !g_scales || !g_opac || !d_xyz || !d_rot || !d_scaling ||
         !d_opacity_logit)
@@ -194,8 +211,8 @@ int mi355gs_pose_backward(void* stream_, int P, const float* xyz, const float* r
                        g_fused.gate_scaling, g_fused.gate_opacity);
     GS_CHECK_LAUNCH("pose_bwd");
   }
-  hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, (const float*)scratch16, d_pose,
-                     (g_fused.gate && g_fused.gate_pose >= 0) ? g_fused.gate + g_fused.gate_pose : nullptr);
+  // (folding this into k_pose_bwd's last workgroup was measured: the ticket round trips cost more than the launch)
+  hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, (const float*)scratch16, d_pose, pose_gate);
   GS_CHECK_LAUNCH("pose_finish");
   return MI355GS_OK;
 }

@@ -119,7 +119,25 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
                                                    const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
                                                    const float* __restrict__ dm_dsigma12, const float* __restrict__ ssim_scale,
                                                    const float* __restrict__ l1_scale, float ssim_scale_host, float l1_scale_host,
-                                                   float* __restrict__ dL_dimg1) {
+                                                   float* __restrict__ dL_dimg1, const float* __restrict__ fwd_partial, int fwd_nblocks,
+                                                   double fwd_inv_n, float lambda_dssim, float* __restrict__ loss) {
+  // Fused train step: the loss value itself (only ever read by the host) is reduced here by workgroup 0 from the forward
+  // kernel's per-block partial sums, instead of by a launch of its own between forward and backward.
+  if (loss && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    __shared__ double s_fa[4], s_fb[4];
+    const int t = threadIdx.y * TS + threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = t; i < fwd_nblocks; i += 256) { a += (double)fwd_partial[2 * i]; b += (double)fwd_partial[2 * i + 1]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+    if ((t & 63) == 0) { s_fa[t >> 6] = a; s_fb[t >> 6] = b; }
+    __syncthreads();
+    if (t == 0) {
+      const double ta = (s_fa[0] + s_fa[1]) + (s_fa[2] + s_fa[3]), tb = (s_fb[0] + s_fb[1]) + (s_fb[2] + s_fb[3]);
+      const float sm = (float)(ta * fwd_inv_n), lm = (float)(tb * fwd_inv_n);
+      *loss = (1.0f - lambda_dssim) * lm + lambda_dssim * (1.0f - sm);  // reference train.py:176
+    }
+  }
   __shared__ float s_a[TH][TH + 1];
   __shared__ float s_b[TH][TH + 1];
   __shared__ float s_c[TH][TH + 1];
@@ -215,7 +233,8 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
   const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
   const float inv_n = (float)(1.0 / ((double)B * C * H * W));
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
-                     ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1);
+                     ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1,
+                     (const float*)nullptr, 0, 0.0, 0.f, (float*)nullptr);
   GS_CHECK_LAUNCH("ssim_bwd");
   return MI355GS_OK;
 }
@@ -224,25 +243,24 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
 
 // internal entry for the fused train step: loss = (1-l)*L1 + l*(1-SSIM) forward, its gradient backward (d loss = 1)
 int gs_loss_forward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, float* dm1, float* dm2, float* dm3,
-                    void* scratch, float lambda_dssim, float* loss) {
+                    void* scratch) {
   const int debug = 0;
   const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
   hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm1, dm2, dm3, (float*)scratch);
   GS_CHECK_LAUNCH("ssim_fwd");
-  const double inv_n = 1.0 / ((double)C * H * W);
-  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(1, C, H, W), inv_n, (const float*)scratch,
-                     (float*)nullptr, (float*)nullptr, loss, lambda_dssim);
-  GS_CHECK_LAUNCH("ssim_finish");
   return MI355GS_OK;
 }
 
+// also writes *loss from the forward's partial sums in `scratch` (see k_ssim_bwd)
 int gs_loss_backward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, const float* dm1,
-                     const float* dm2, const float* dm3, float lambda_dssim, float* dL_dimg1) {
+                     const float* dm2, const float* dm3, float lambda_dssim, float* dL_dimg1, const void* scratch, float* loss) {
   const int debug = 0;
   const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
-  const float inv_n = (float)(1.0 / ((double)C * H * W));
+  const double inv_n_d = 1.0 / ((double)C * H * W);
+  const float inv_n = (float)inv_n_d;
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm1, dm2, dm3, (const float*)nullptr,
-                     (const float*)nullptr, -lambda_dssim, 1.0f - lambda_dssim, dL_dimg1);
+                     (const float*)nullptr, -lambda_dssim, 1.0f - lambda_dssim, dL_dimg1, (const float*)scratch, ssim_nblocks(1, C, H, W),
+                     inv_n_d, lambda_dssim, loss);
   GS_CHECK_LAUNCH("ssim_bwd");
   return MI355GS_OK;
 }

@@ -15,8 +15,9 @@
 #include <string.h>
 #include "common.h"
 
-int gs_loss_forward(hipStream_t, int, int, int, const float*, const float*, float*, float*, float*, void*, float, float*);
-int gs_loss_backward(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, float, float*);
+int gs_loss_forward(hipStream_t, int, int, int, const float*, const float*, float*, float*, float*, void*);
+int gs_loss_backward(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, float, float*,
+                     const void*, float*);
 
 namespace {
 
@@ -65,21 +66,8 @@ size_t carve(Trainer& t, void* workspace) {
   t.g_scales = c.take<float>(3 * P); t.g_rot_cam = c.take<float>(4 * P); t.g_colors = c.take<float>(3 * P);
   t.g_xyz = c.take<float>(3 * P); t.g_rot = c.take<float>(4 * P); t.g_scaling = c.take<float>(3 * P); t.g_opacity = c.take<float>(P);
   t.g_fdc = c.take<float>(3 * P); t.g_frest = c.take<float>(45 * P); t.g_poses = c.take<float>(7 * (size_t)t.V);
-  t.pose_scratch = c.take<float>(16); t.adam_scratch = c.take<float>(8); t.consts = c.take<float>(32);
+  t.pose_scratch = c.take<float>(32); t.adam_scratch = c.take<float>(8); t.consts = c.take<float>(32);
   return c.off;
-}
-
-// one launch zeroes every counter / accumulator of the iteration (grid-stride over the 48-byte gradient records)
-__global__ __launch_bounds__(256) void k_trainer_prologue(float4* __restrict__ grad_records, size_t n_vec, uint32_t* __restrict__ tile_counters,
-                                                          int n_counters, float* __restrict__ g_poses, int n_pose, float* __restrict__ pose_scratch,
-                                                          float* __restrict__ adam_scratch) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (size_t i = gid; i < n_vec; i += stride) grad_records[i] = z;
-  for (size_t i = gid; i < (size_t)n_counters; i += stride) tile_counters[i] = 0u;
-  if (gid < (size_t)n_pose) g_poses[gid] = 0.f;
-  if (gid < 16) pose_scratch[gid] = 0.f;
-  if (gid < 8) adam_scratch[gid] = 0.f;
 }
 
 int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t* step, float beta1, float beta2, float eps) {
@@ -148,20 +136,21 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     if (hipMemsetAsync(t->g_frest, 0, (size_t)P * 45 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
     t->consts_ready = true;
   }
-  {
-    const TilesLayout tl(W, H);
-    hipLaunchKernelGGL(k_trainer_prologue, dim3(1024), dim3(256), 0, stream, (float4*)t->grad_scratch, (size_t)P * 3,
-                       (uint32_t*)(t->tiles + tl.count), (int)((tl.start - tl.count) / 4), t->g_poses, 7 * t->V, t->pose_scratch,
-                       t->adam_scratch);
-    GS_CHECK_LAUNCH("trainer_prologue");
-  }
   struct HookScope {
-    HookScope(float* gate) {
-      g_fused.skip_memsets = true; g_fused.gate = gate;
+    HookScope(float* gate, const GsPrologue& pro) {
+      g_fused.skip_memsets = true; g_fused.gate = gate; g_fused.prologue = pro;
       g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_sh_rest = 2; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5; g_fused.gate_pose = 6;
     }
     ~HookScope() { g_fused = GsFusedStepHooks(); }
-  } hook_scope(t->adam_scratch);
+  };
+  GsPrologue pro;  // the step's accumulators are cleared by its first kernel (k_pose_fwd)
+  {
+    const TilesLayout tl(W, H);
+    pro.grad_records = (float4*)t->grad_scratch; pro.n_vec = (size_t)P * 3;
+    pro.tile_counters = (uint32_t*)(t->tiles + tl.count); pro.n_counters = (int)((tl.start - tl.count) / 4);
+    pro.g_poses = t->g_poses; pro.n_pose = 7 * t->V; pro.pose_scratch = t->pose_scratch; pro.adam_scratch = t->adam_scratch;
+  }
+  HookScope hook_scope(t->adam_scratch, pro);
   const float* view_m = t->consts;
   const float* campos = t->consts + 16;
   const float* pose = t->poses + 7 * (size_t)view;
@@ -179,10 +168,11 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
                                               t->geom, t->tiles, num_rendered_out, 0)))
     return rc;
   if ((rc = mi355gs_raster_forward_render(stream, P, W, H, t->capacity, bg, t->geom, t->tiles, t->binning, t->image, 0))) return rc;
-  if ((rc = gs_loss_forward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, t->ssim_scratch, lambda_dssim, loss_out)))
-    return rc;
+  if ((rc = gs_loss_forward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, t->ssim_scratch))) return rc;
   // ---- backward
-  if ((rc = gs_loss_backward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, lambda_dssim, t->dL_dimg))) return rc;
+  if ((rc = gs_loss_backward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, lambda_dssim, t->dL_dimg, t->ssim_scratch,
+                             loss_out)))
+    return rc;
   if ((rc = mi355gs_raster_backward(stream, P, D, M, W, H, bg, t->means_cam, t->f_dc, rest, nullptr, t->opac, t->scales, 1.0f, t->rot_cam,
                                     nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, t->geom, t->tiles, t->binning,
                                     t->capacity, t->radii, t->dL_dimg, t->grad_scratch, t->g_means3D, t->g_means2D, t->g_fdc,

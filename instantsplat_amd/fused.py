@@ -40,7 +40,7 @@ class _PoseActivations(torch.autograd.Function):
         g_means, g_rot, g_scales, g_opac = z(g_means, xyz), z(g_rot, rot), z(g_scales, scales), z(g_opac, opac)
         d_xyz, d_rot, d_scaling, d_opl = torch.empty_like(xyz), torch.empty_like(rot), torch.empty_like(scales), torch.empty_like(opac)
         d_pose = torch.empty(7, dtype=torch.float32, device=dev)
-        scratch = torch.empty(16, dtype=torch.float32, device=dev)
+        scratch = torch.empty(32, dtype=torch.float32, device=dev)
         _lib.check(L.mi355gs_pose_backward(_lib.stream_ptr(dev), P, _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(scales), _lib.ptr(opac),
                                            _lib.ptr(pose), _lib.ptr(g_means), _lib.ptr(g_rot), _lib.ptr(g_scales), _lib.ptr(g_opac),
                                            _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(d_scaling), _lib.ptr(d_opl), _lib.ptr(d_pose),
