@@ -8,34 +8,9 @@
 // Semantics kept: the pose quaternion is NORMALISED for the rotation of the means but used RAW in
 // the Hamilton product with the (raw) Gaussian quaternions.
 // HBM-bound: 44 B read + 44 B written per Gaussian forward; 88 B read + 44 B written backward.
-#include "common.h"
+#include "pose_math.h"
 
 namespace {
-
-struct PoseMat {
-  float R[9];   // rotation from the normalised quaternion, row-major
-  float t[3];
-  float q[4];   // raw pose quaternion (w,x,y,z)
-  float qn[4];  // normalised
-  float inv_norm;
-};
-
-__device__ __forceinline__ PoseMat load_pose(const float* __restrict__ pose) {
-  PoseMat m;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) m.q[k] = pose[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) m.t[k] = pose[4 + k];
-  const float n = sqrtf(m.q[0] * m.q[0] + m.q[1] * m.q[1] + m.q[2] * m.q[2] + m.q[3] * m.q[3]);
-  m.inv_norm = 1.0f / n;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) m.qn[k] = m.q[k] / n;
-  const float r = m.qn[0], x = m.qn[1], y = m.qn[2], z = m.qn[3];
-  m.R[0] = 1.f - 2.f * (y * y + z * z); m.R[1] = 2.f * (x * y - r * z); m.R[2] = 2.f * (x * z + r * y);
-  m.R[3] = 2.f * (x * y + r * z); m.R[4] = 1.f - 2.f * (x * x + z * z); m.R[5] = 2.f * (y * z - r * x);
-  m.R[6] = 2.f * (x * z - r * y); m.R[7] = 2.f * (y * z + r * x); m.R[8] = 1.f - 2.f * (x * x + y * y);
-  return m;
-}
 
 __global__ __launch_bounds__(256) void k_pose_fwd(int P, const float* __restrict__ xyz, const float* __restrict__ rot,
                                                    const float* __restrict__ scaling, const float* __restrict__ opacity_logit,
@@ -54,21 +29,12 @@ __global__ __launch_bounds__(256) void k_pose_fwd(int P, const float* __restrict
     if (gid < 8) pro.adam_scratch[gid] = 0.f;
   }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
-    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-    means_cam[3 * (size_t)i] = m.R[0] * x + m.R[1] * y + m.R[2] * z + m.t[0];
-    means_cam[3 * (size_t)i + 1] = m.R[3] * x + m.R[4] * y + m.R[5] * z + m.t[1];
-    means_cam[3 * (size_t)i + 2] = m.R[6] * x + m.R[7] * y + m.R[8] * z + m.t[2];
-    const float4 g = *reinterpret_cast<const float4*>(rot + 4 * (size_t)i);  // (w2,x2,y2,z2)
-    const float w1 = m.q[0], x1 = m.q[1], y1 = m.q[2], z1 = m.q[3];
-    float4 o;
-    o.x = w1 * g.x - x1 * g.y - y1 * g.z - z1 * g.w;
-    o.y = w1 * g.y + x1 * g.x + y1 * g.w - z1 * g.z;
-    o.z = w1 * g.z - x1 * g.w + y1 * g.x + z1 * g.y;
-    o.w = w1 * g.w + x1 * g.z - y1 * g.y + z1 * g.x;
-    *reinterpret_cast<float4*>(rot_cam + 4 * (size_t)i) = o;
+    const float3 mc = pose_mean(m, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+    means_cam[3 * (size_t)i] = mc.x; means_cam[3 * (size_t)i + 1] = mc.y; means_cam[3 * (size_t)i + 2] = mc.z;
+    *reinterpret_cast<float4*>(rot_cam + 4 * (size_t)i) = pose_rot(m, *reinterpret_cast<const float4*>(rot + 4 * (size_t)i));
 #pragma unroll
-    for (int k = 0; k < 3; ++k) scales[3 * (size_t)i + k] = expf(scaling[3 * (size_t)i + k]);
-    opac[i] = 1.0f / (1.0f + expf(-opacity_logit[i]));
+    for (int k = 0; k < 3; ++k) scales[3 * (size_t)i + k] = pose_scale(scaling[3 * (size_t)i + k]);
+    opac[i] = pose_opacity(opacity_logit[i]);
   }
 }
 
@@ -119,52 +85,23 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
   bool nz_xyz = false, nz_rot = false, nz_sc = false, nz_op = false;
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
-    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-    const float gx = g_means[3 * (size_t)i], gy = g_means[3 * (size_t)i + 1], gz = g_means[3 * (size_t)i + 2];
-    const float dx0 = m.R[0] * gx + m.R[3] * gy + m.R[6] * gz, dx1 = m.R[1] * gx + m.R[4] * gy + m.R[7] * gz,
-                dx2 = m.R[2] * gx + m.R[5] * gy + m.R[8] * gz;
-    d_xyz[3 * (size_t)i] = dx0; d_xyz[3 * (size_t)i + 1] = dx1; d_xyz[3 * (size_t)i + 2] = dx2;
-    nz_xyz = nz_xyz || dx0 != 0.f || dx1 != 0.f || dx2 != 0.f;
-    a[0] += gx; a[1] += gy; a[2] += gz;
-    a[3] += gx * x; a[4] += gx * y; a[5] += gx * z;
-    a[6] += gy * x; a[7] += gy * y; a[8] += gy * z;
-    a[9] += gz * x; a[10] += gz * y; a[11] += gz * z;
-    const float4 q2 = *reinterpret_cast<const float4*>(rot + 4 * (size_t)i);
-    const float4 gr = *reinterpret_cast<const float4*>(g_rot + 4 * (size_t)i);  // grads of (rw, rx, ry, rz)
-    const float w1 = m.q[0], x1 = m.q[1], y1 = m.q[2], z1 = m.q[3];
-    float4 d2;
-    d2.x = w1 * gr.x + x1 * gr.y + y1 * gr.z + z1 * gr.w;
-    d2.y = -x1 * gr.x + w1 * gr.y + z1 * gr.z - y1 * gr.w;
-    d2.z = -y1 * gr.x - z1 * gr.y + w1 * gr.z + x1 * gr.w;
-    d2.w = -z1 * gr.x + y1 * gr.y - x1 * gr.z + w1 * gr.w;
-    *reinterpret_cast<float4*>(d_rot + 4 * (size_t)i) = d2;
-    nz_rot = nz_rot || d2.x != 0.f || d2.y != 0.f || d2.z != 0.f || d2.w != 0.f;
-    a[12] += q2.x * gr.x + q2.y * gr.y + q2.z * gr.z + q2.w * gr.w;
-    a[13] += -q2.y * gr.x + q2.x * gr.y - q2.w * gr.z + q2.z * gr.w;
-    a[14] += -q2.z * gr.x + q2.w * gr.y + q2.x * gr.z - q2.y * gr.w;
-    a[15] += -q2.w * gr.x - q2.z * gr.y + q2.y * gr.z + q2.x * gr.w;
+    const PoseGradOut r = pose_backward_one(
+        m, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], *reinterpret_cast<const float4*>(rot + 4 * (size_t)i),
+        scales + 3 * (size_t)i, opac[i], g_means[3 * (size_t)i], g_means[3 * (size_t)i + 1], g_means[3 * (size_t)i + 2],
+        *reinterpret_cast<const float4*>(g_rot + 4 * (size_t)i), g_scales + 3 * (size_t)i, g_opac[i], a);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float v = g_scales[3 * (size_t)i + k] * scales[3 * (size_t)i + k];
-      d_scaling[3 * (size_t)i + k] = v;
-      nz_sc = nz_sc || v != 0.f;
+      d_xyz[3 * (size_t)i + k] = r.d_xyz[k];
+      d_scaling[3 * (size_t)i + k] = r.d_scaling[k];
+      nz_xyz = nz_xyz || r.d_xyz[k] != 0.f;
+      nz_sc = nz_sc || r.d_scaling[k] != 0.f;
     }
-    const float o = opac[i];
-    const float dol = g_opac[i] * o * (1.f - o);
-    d_opacity_logit[i] = dol;
-    nz_op = nz_op || dol != 0.f;
+    *reinterpret_cast<float4*>(d_rot + 4 * (size_t)i) = r.d_rot;
+    nz_rot = nz_rot || r.d_rot.x != 0.f || r.d_rot.y != 0.f || r.d_rot.z != 0.f || r.d_rot.w != 0.f;
+    d_opacity_logit[i] = r.d_opacity_logit;
+    nz_op = nz_op || r.d_opacity_logit != 0.f;
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const float v = gs_wave_sum_row3(a[k]);
-    if (lane == 63) s_red[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    const int k = threadIdx.x;
-    atomicAdd(&acc[k], (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]));
-  }
+  pose_accumulate(a, acc, s_red);
   if (gate) {  // PerPointAdam's whole-tensor gate: any non-zero gradient element (benign same-value store race)
     if (gi_xyz >= 0 && nz_xyz) gate[gi_xyz] = 1.0f;
     if (gi_rot >= 0 && nz_rot) gate[gi_rot] = 1.0f;
