@@ -210,6 +210,9 @@ int mi355gs_trainer_step(void* trainer, void* stream, int view, int sh_degree, c
 int mi355gs_trainer_optimizer_step(void* trainer, void* stream, const float* lr, const int32_t* step, float beta1, float beta2,
                                    float eps);
 void mi355gs_trainer_destroy(void* trainer);
+/* Device pointer of the gradient buffer of parameter group k (0..6: xyz, f_dc, f_rest, opacity, scaling, rotation, poses)
+ * as left by the last mi355gs_trainer_step — for tests and diagnostics (gradient parity of the fused step). */
+const float* mi355gs_trainer_grad(void* trainer, int k);
 
 #ifdef __cplusplus
 }

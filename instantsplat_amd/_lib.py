@@ -51,6 +51,7 @@ _SIGNATURES = {
                                      c_int, _P, _P]),
     "mi355gs_trainer_optimizer_step": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float]),
     "mi355gs_trainer_destroy": (None, [_P]),
+    "mi355gs_trainer_grad": (_P, [_P, c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -312,9 +312,18 @@ struct GsPrologue {  // accumulators of one train step, zeroed by the step's fir
   float* pose_scratch = nullptr;                           // 32 floats
   float* adam_scratch = nullptr;                           // 8 gate flags
 };
+// One-call train step: the projection kernels take the RAW parameters (xyz, raw quaternion, log-scale, opacity logit) plus
+// the camera pose and apply InstantSplat's camera-frame transform / activations themselves (pose_math.h), and their
+// backward goes all the way to the raw-parameter gradients and the 16 pose sums — no k_pose_fwd / k_pose_bwd launches
+// and no camera-frame intermediates in HBM.
+struct GsPosed {
+  const float* pose = nullptr;  // [7] (qw,qx,qy,qz,tx,ty,tz); null = inputs are already in the camera frame
+  float* acc = nullptr;         // backward: 16 pose sums (see pose_math.h), zeroed by the caller
+};
 struct GsFusedStepHooks {
   bool skip_memsets = false;
   GsPrologue prologue;
+  GsPosed posed;
   float* gate = nullptr;   // device float[8] or null
   int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_sh_rest = -1, gate_pose = -1;
 };

@@ -112,6 +112,12 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
 
 }  // namespace
 
+// dL/dpose from the 16 pose sums (internal entry for the one-call train step, whose projection kernels accumulate them)
+int gs_launch_pose_finish(hipStream_t stream, const float* pose, const float* acc, float* d_pose, float* pose_gate) {
+  hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, acc, d_pose, pose_gate);
+  return 0;
+}
+
 extern "C" {
 
 int mi355gs_pose_forward(void* stream_, int P, const float* xyz, const float* rot, const float* scaling,

@@ -2,7 +2,7 @@
 // One thread per Gaussian, 256-thread blocks; HBM-bound (131 B/Gaussian at SH
 // degree 0, 311 B at degree 3 forward).  Semantics: SURVEY.md Appendix A.1 / A.5; the operator
 // being replaced is reached at reference gaussian_renderer/__init__.py:126-135.
-#include "common.h"
+#include "pose_math.h"
 
 namespace {
 
@@ -101,19 +101,35 @@ __device__ __forceinline__ float3 sh_eval(const float* sh /*[M,3]*/, float x, fl
 // ------------------------------------------------------------------------------------------------
 // K1 forward: projection + per-tile instance counting
 // ------------------------------------------------------------------------------------------------
+// POSED (one-call train step, see GsPosed): means3D / rotations / scales / opacities are the RAW parameters (xyz, raw
+// quaternion, log-scale, opacity logit); the camera-frame transform and the activations are applied here, and the step's
+// accumulators are cleared on the way (this is then the first kernel of the step).
+template <bool POSED>
 __global__ __launch_bounds__(256) void k_preprocess_fwd(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, CamParams cp,
     int32_t* __restrict__ radii, GsRec* __restrict__ recs, float* __restrict__ cov3Ds, uint2* __restrict__ rects,
-    uint8_t* __restrict__ clamped) {
+    uint8_t* __restrict__ clamped, GsPosed posed, GsPrologue pro) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (POSED && pro.grad_records) {
+    const size_t gid = (size_t)i, stride = (size_t)gridDim.x * blockDim.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t k = gid; k < pro.n_vec; k += stride) pro.grad_records[k] = z;
+    for (size_t k = gid; k < (size_t)pro.n_counters; k += stride) pro.tile_counters[k] = 0u;
+    if (gid < (size_t)pro.n_pose) pro.g_poses[gid] = 0.f;
+    if (gid < 32) pro.pose_scratch[gid] = 0.f;
+    if (gid < 8) pro.adam_scratch[gid] = 0.f;
+  }
   if (i >= P) return;
   radii[i] = 0;
   rects[i] = make_uint2(0u, 0u);
   const float* view = cp.view;
   const float* proj = cp.proj;
-  const float3 m = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+  PoseMat pm;
+  if (POSED) pm = load_pose(posed.pose);
+  float3 m = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+  if (POSED) m = pose_mean(pm, m.x, m.y, m.z);
   const float3 pv = gs_tp43(view, m);
   if (pv.z <= 0.2f) return;
   const float4 ph = gs_tp44(proj, m);
@@ -125,11 +141,16 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
 #pragma unroll
     for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[6 * (size_t)i + k];
   } else {
-    const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+    float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+    float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+    if (POSED) {
+      q = pose_rot(pm, q);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sc[k] = pose_scale(sc[k]);
+    }
     float R[9];
     quat_to_R(q.x, q.y, q.z, q.w, R);
-    const float s0 = cp.scale_modifier * scales[3 * (size_t)i], s1 = cp.scale_modifier * scales[3 * (size_t)i + 1],
-                s2 = cp.scale_modifier * scales[3 * (size_t)i + 2];
+    const float s0 = cp.scale_modifier * sc[0], s1 = cp.scale_modifier * sc[1], s2 = cp.scale_modifier * sc[2];
     float L[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r) { L[3 * r] = R[3 * r] * s0; L[3 * r + 1] = R[3 * r + 1] * s1; L[3 * r + 2] = R[3 * r + 2] * s2; }
@@ -196,7 +217,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   // by the alpha test anyway, so the composite kernels use the box to skip whole 8x8 pixel groups.
   // Computed from the conic actually used; 1% + 0.5 px slack; disabled (inf) when the conic is too
   // ill-conditioned for the bound to be trusted.
-  const float opac = opacities[i];
+  const float opac = POSED ? pose_opacity(opacities[i]) : opacities[i];
   float hx, hy;
   const float tau = __logf(255.0f * opac);
   const float cdet = ca * cc - cb * cb;
@@ -267,16 +288,25 @@ __device__ __forceinline__ void sh_backward(const float* sh, float* gsh, float x
   gd[0] = gx; gd[1] = gy; gd[2] = gz;
 }
 
+// POSED: see k_preprocess_fwd; the outputs named dL_dmeans3D / dL_drots / dL_dscales / dL_dopac then receive the gradients
+// of the RAW parameters (xyz, raw quaternion, log-scale, opacity logit) and the 16 pose sums are accumulated.
+template <bool POSED>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ scales, const float* __restrict__ rotations, int use_shs, int use_cov_precomp, CamParams cp, const int32_t* __restrict__ radii,
     const GsRec* __restrict__ recs, const float* __restrict__ cov3Ds, const uint8_t* __restrict__ clamped, const GsGrad* __restrict__ grads,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ sh_gate, float* __restrict__ sh_rest_gate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const bool vis = radii[i] > 0;
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ sh_gate, float* __restrict__ sh_rest_gate,
+    GsPosed posed, float* __restrict__ gate, int gi_xyz, int gi_rot, int gi_scaling, int gi_opacity) {
+  __shared__ float s_red[POSED ? 4 : 1][16];
+  const int i_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!POSED && i_raw >= P) return;
+  const bool live = i_raw < P;          // POSED: every thread stays for the workgroup reduction of the pose sums
+  const int i = live ? i_raw : 0;
+  const bool vis = live && radii[i] > 0;
+  PoseMat pm;
+  if (POSED) pm = load_pose(posed.pose);
   GsGrad g;
   g.g0 = make_float4(0, 0, 0, 0); g.g1 = g.g0; g.g2 = g.g0;
   if (vis) {
@@ -305,7 +335,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   if (vis) {
     const float* view = cp.view;
     const float* proj = cp.proj;
-    const float3 m = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+    float3 m = make_float3(means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]);
+    if (POSED) m = pose_mean(pm, m.x, m.y, m.z);
     float cov[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) cov[k] = cov3Ds[6 * (size_t)i + k];
@@ -389,11 +420,17 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     }
     // ---- cov3D -> scale, rotation
     if (!use_cov_precomp) {
-      const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+      float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+      float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+      if (POSED) {
+        q = pose_rot(pm, q);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc[k] = pose_scale(sc[k]);
+      }
       float R[9];
       quat_to_R(q.x, q.y, q.z, q.w, R);
       const float mod = cp.scale_modifier;
-      const float s[3] = {mod * scales[3 * (size_t)i], mod * scales[3 * (size_t)i + 1], mod * scales[3 * (size_t)i + 2]};
+      const float s[3] = {mod * sc[0], mod * sc[1], mod * sc[2]};
       float L[9];
 #pragma unroll
       for (int r = 0; r < 3; ++r) { L[3 * r] = R[3 * r] * s[0]; L[3 * r + 1] = R[3 * r + 1] * s[1]; L[3 * r + 2] = R[3 * r + 2] * s[2]; }
@@ -420,38 +457,76 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   }
 
   // ---- write every output row (zeros for culled Gaussians: callers get fully-defined tensors)
-  dL_dmeans3D[3 * (size_t)i] = gm[0]; dL_dmeans3D[3 * (size_t)i + 1] = gm[1]; dL_dmeans3D[3 * (size_t)i + 2] = gm[2];
-  dL_dmeans2D[3 * (size_t)i] = g.g0.x; dL_dmeans2D[3 * (size_t)i + 1] = g.g0.y; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
-  dL_dopac[i] = g.g1.y;
-  if (dL_dcolors) { dL_dcolors[3 * (size_t)i] = gcol.x; dL_dcolors[3 * (size_t)i + 1] = gcol.y; dL_dcolors[3 * (size_t)i + 2] = gcol.z; }
-  if (gsh) {
-    const int first = (vis && use_shs) ? nb : 0;  // coefficients [0,nb) were written by sh_backward
-    if (!split) {
-      for (int k = first * 3; k < M * 3; ++k) gsh[k] = 0.f;
-      if (sh_gate && first) {  // benign race: every writer stores the same value
-        bool nz = false;
-        for (int k = 0; k < first * 3; ++k) nz = nz || gsh[k] != 0.f;
-        if (nz) *sh_gate = 1.0f;
+  if (live) {
+    if (!POSED) {
+      dL_dmeans3D[3 * (size_t)i] = gm[0]; dL_dmeans3D[3 * (size_t)i + 1] = gm[1]; dL_dmeans3D[3 * (size_t)i + 2] = gm[2];
+      dL_dopac[i] = g.g1.y;
+      if (dL_dscales) { dL_dscales[3 * (size_t)i] = gs[0]; dL_dscales[3 * (size_t)i + 1] = gs[1]; dL_dscales[3 * (size_t)i + 2] = gs[2]; }
+      if (dL_drots) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+    }
+    dL_dmeans2D[3 * (size_t)i] = g.g0.x; dL_dmeans2D[3 * (size_t)i + 1] = g.g0.y; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
+    if (dL_dcolors) { dL_dcolors[3 * (size_t)i] = gcol.x; dL_dcolors[3 * (size_t)i + 1] = gcol.y; dL_dcolors[3 * (size_t)i + 2] = gcol.z; }
+    if (gsh) {
+      const int first = (vis && use_shs) ? nb : 0;  // coefficients [0,nb) were written by sh_backward
+      if (!split) {
+        for (int k = first * 3; k < M * 3; ++k) gsh[k] = 0.f;
+        if (sh_gate && first) {  // benign race: every writer stores the same value
+          bool nz = false;
+          for (int k = 0; k < first * 3; ++k) nz = nz || gsh[k] != 0.f;
+          if (nz) *sh_gate = 1.0f;
+        }
+      } else {
+        // scatter the local gradient to the two parameter tensors; untouched coefficients get explicit zeros
+        float* gdc = dL_dshs + 3 * (size_t)i;
+        bool nz_dc = false, nz_rest = false;
+        for (int c = 0; c < 3; ++c) { const float v = first ? gsh_local[c] : 0.f; gdc[c] = v; nz_dc = nz_dc || v != 0.f; }
+        if (dL_dshs_rest) {
+          float* grest = dL_dshs_rest + (size_t)i * (M - 1) * 3;
+          for (int k = 3; k < M * 3; ++k) { const float v = k < first * 3 ? gsh_local[k] : 0.f; grest[k - 3] = v; nz_rest = nz_rest || v != 0.f; }
+        }
+        if (sh_gate && nz_dc) *sh_gate = 1.0f;
+        if (sh_rest_gate && nz_rest) *sh_rest_gate = 1.0f;
       }
-    } else {
-      // scatter the local gradient to the two parameter tensors; untouched coefficients get explicit zeros
-      float* gdc = dL_dshs + 3 * (size_t)i;
-      bool nz_dc = false, nz_rest = false;
-      for (int c = 0; c < 3; ++c) { const float v = first ? gsh_local[c] : 0.f; gdc[c] = v; nz_dc = nz_dc || v != 0.f; }
-      if (dL_dshs_rest) {
-        float* grest = dL_dshs_rest + (size_t)i * (M - 1) * 3;
-        for (int k = 3; k < M * 3; ++k) { const float v = k < first * 3 ? gsh_local[k] : 0.f; grest[k - 3] = v; nz_rest = nz_rest || v != 0.f; }
-      }
-      if (sh_gate && nz_dc) *sh_gate = 1.0f;
-      if (sh_rest_gate && nz_rest) *sh_rest_gate = 1.0f;
+    }
+    if (dL_dcov3D) {
+      const bool on = vis && use_cov_precomp;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = on ? gcov[k] : 0.f;
     }
   }
-  if (dL_dscales) { dL_dscales[3 * (size_t)i] = gs[0]; dL_dscales[3 * (size_t)i + 1] = gs[1]; dL_dscales[3 * (size_t)i + 2] = gs[2]; }
-  if (dL_drots) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
-  if (dL_dcov3D) {
-    const bool on = vis && use_cov_precomp;
+  if (POSED) {
+    // camera-frame gradients -> raw-parameter gradients and the pose sums (what k_pose_bwd does on the autograd path)
+    float a[16];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = on ? gcov[k] : 0.f;
+    for (int k = 0; k < 16; ++k) a[k] = 0.f;
+    bool nz_xyz = false, nz_rot = false, nz_sc = false, nz_op = false;
+    if (live) {
+      float act[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) act[k] = pose_scale(scales[3 * (size_t)i + k]);
+      const float o = vis ? recs[i].q1.w : 0.5f;  // the activated opacity of the forward (its gradient is zero when culled)
+      const PoseGradOut r = pose_backward_one(pm, means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2],
+                                              *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i), act, o, gm[0], gm[1], gm[2],
+                                              make_float4(gq[0], gq[1], gq[2], gq[3]), gs, g.g1.y, a);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dL_dmeans3D[3 * (size_t)i + k] = r.d_xyz[k];
+        dL_dscales[3 * (size_t)i + k] = r.d_scaling[k];
+        nz_xyz = nz_xyz || r.d_xyz[k] != 0.f;
+        nz_sc = nz_sc || r.d_scaling[k] != 0.f;
+      }
+      *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = r.d_rot;
+      nz_rot = nz_rot || r.d_rot.x != 0.f || r.d_rot.y != 0.f || r.d_rot.z != 0.f || r.d_rot.w != 0.f;
+      dL_dopac[i] = r.d_opacity_logit;
+      nz_op = nz_op || r.d_opacity_logit != 0.f;
+    }
+    pose_accumulate(a, posed.acc, s_red);
+    if (gate) {  // PerPointAdam's whole-tensor gate: any non-zero gradient element (benign same-value store race)
+      if (gi_xyz >= 0 && nz_xyz) gate[gi_xyz] = 1.0f;
+      if (gi_rot >= 0 && nz_rot) gate[gi_rot] = 1.0f;
+      if (gi_scaling >= 0 && nz_sc) gate[gi_scaling] = 1.0f;
+      if (gi_opacity >= 0 && nz_op) gate[gi_opacity] = 1.0f;
+    }
   }
 }
 
@@ -471,8 +546,14 @@ int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const floa
                              const float* rotations, const float* cov3D_precomp, const CamParams& cp, int32_t* radii,
                              GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped) {
   if (P <= 0) return 0;
-  hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, colors_precomp,
-                     opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped);
+  if (g_fused.posed.pose)
+    hipLaunchKernelGGL(k_preprocess_fwd<true>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped,
+                       g_fused.posed, g_fused.prologue);
+  else
+    hipLaunchKernelGGL(k_preprocess_fwd<false>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, GsPosed(),
+                       GsPrologue());
   return 0;
 }
 
@@ -483,9 +564,16 @@ int gs_launch_preprocess_bwd(hipStream_t stream, int P, int D, int M, const floa
                              float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D, float* sh_gate,
                              float* sh_rest_gate) {
   if (P <= 0) return 0;
-  hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, scales, rotations,
-                     use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dshs_rest,
-                     dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate, sh_rest_gate);
+  if (g_fused.posed.pose)
+    hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, scales,
+                       rotations, use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                       dL_dshs_rest, dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate, sh_rest_gate, g_fused.posed,
+                       g_fused.gate, g_fused.gate_xyz, g_fused.gate_rot, g_fused.gate_scaling, g_fused.gate_opacity);
+  else
+    hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, scales,
+                       rotations, use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                       dL_dshs_rest, dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate, sh_rest_gate, GsPosed(),
+                       (float*)nullptr, -1, -1, -1, -1);
   return 0;
 }
 

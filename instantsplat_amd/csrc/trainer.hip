@@ -16,6 +16,7 @@
 #include "common.h"
 
 int gs_loss_forward(hipStream_t, int, int, int, const float*, const float*, float*, float*, float*, void*);
+int gs_launch_pose_finish(hipStream_t, const float*, const float*, float*, float*);
 int gs_loss_backward(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, float, float*,
                      const void*, float*);
 
@@ -32,9 +33,8 @@ struct Trainer {
   // workspace slices
   char *geom, *tiles, *binning, *grad_scratch, *ssim_scratch;
   float *image, *dm1, *dm2, *dm3, *dL_dimg;
-  float *means_cam, *rot_cam, *scales, *opac;
   int32_t* radii;
-  float *g_means3D, *g_means2D, *g_opac, *g_scales, *g_rot_cam, *g_colors;
+  float *g_means2D, *g_colors;
   float *g_xyz, *g_rot, *g_scaling, *g_opacity, *g_fdc, *g_frest, *g_poses;
   float *pose_scratch, *adam_scratch, *consts;  // consts: identity view [16], campos [3]
   bool consts_ready;
@@ -60,10 +60,8 @@ size_t carve(Trainer& t, void* workspace) {
   t.ssim_scratch = c.take<char>(mi355gs_ssim_scratch_bytes(1, 3, t.H, t.W));
   t.image = c.take<float>(3 * npix); t.dm1 = c.take<float>(3 * npix); t.dm2 = c.take<float>(3 * npix);
   t.dm3 = c.take<float>(3 * npix); t.dL_dimg = c.take<float>(3 * npix);
-  t.means_cam = c.take<float>(3 * P); t.rot_cam = c.take<float>(4 * P); t.scales = c.take<float>(3 * P); t.opac = c.take<float>(P);
   t.radii = c.take<int32_t>(P);
-  t.g_means3D = c.take<float>(3 * P); t.g_means2D = c.take<float>(3 * P); t.g_opac = c.take<float>(P);
-  t.g_scales = c.take<float>(3 * P); t.g_rot_cam = c.take<float>(4 * P); t.g_colors = c.take<float>(3 * P);
+  t.g_means2D = c.take<float>(3 * P); t.g_colors = c.take<float>(3 * P);
   t.g_xyz = c.take<float>(3 * P); t.g_rot = c.take<float>(4 * P); t.g_scaling = c.take<float>(3 * P); t.g_opacity = c.take<float>(P);
   t.g_fdc = c.take<float>(3 * P); t.g_frest = c.take<float>(45 * P); t.g_poses = c.take<float>(7 * (size_t)t.V);
   t.pose_scratch = c.take<float>(32); t.adam_scratch = c.take<float>(8); t.consts = c.take<float>(32);
@@ -119,6 +117,13 @@ void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float
 
 void mi355gs_trainer_destroy(void* handle) { free(handle); }
 
+const float* mi355gs_trainer_grad(void* handle, int k) {
+  Trainer* t = (Trainer*)handle;
+  if (!t || k < 0 || k > 6) return nullptr;
+  const float* g[7] = {t->g_xyz, t->g_fdc, t->g_frest, t->g_opacity, t->g_scaling, t->g_rot, t->g_poses};
+  return g[k];
+}
+
 int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, const float* gt_image, const float* projmatrix,
                          float tanfovx, float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
                          float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out) {
@@ -137,8 +142,8 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     t->consts_ready = true;
   }
   struct HookScope {
-    HookScope(float* gate, const GsPrologue& pro) {
-      g_fused.skip_memsets = true; g_fused.gate = gate; g_fused.prologue = pro;
+    HookScope(float* gate, const GsPrologue& pro, const GsPosed& posed) {
+      g_fused.skip_memsets = true; g_fused.gate = gate; g_fused.prologue = pro; g_fused.posed = posed;
       g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_sh_rest = 2; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5; g_fused.gate_pose = 6;
     }
     ~HookScope() { g_fused = GsFusedStepHooks(); }
@@ -150,21 +155,20 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     pro.tile_counters = (uint32_t*)(t->tiles + tl.count); pro.n_counters = (int)((tl.start - tl.count) / 4);
     pro.g_poses = t->g_poses; pro.n_pose = 7 * t->V; pro.pose_scratch = t->pose_scratch; pro.adam_scratch = t->adam_scratch;
   }
-  HookScope hook_scope(t->adam_scratch, pro);
+  GsPosed posed;
+  posed.pose = t->poses + 7 * (size_t)view; posed.acc = t->pose_scratch;
+  HookScope hook_scope(t->adam_scratch, pro, posed);
   const float* view_m = t->consts;
   const float* campos = t->consts + 16;
   const float* pose = t->poses + 7 * (size_t)view;
   int rc;
-  // ---- forward
-  if ((rc = mi355gs_pose_forward(stream, P, t->xyz, t->rotation, t->scaling, t->opacity, pose, t->means_cam, t->rot_cam, t->scales,
-                                 t->opac)))
-    return rc;
+  // ---- forward: the projection kernel applies the camera-frame transform and the activations itself (GsPosed)
   // degree 0 reads only the DC coefficient; higher degrees read f_dc + f_rest in place (split storage)
   const int D = sh_degree, M = D == 0 ? 1 : 16;
   const float* rest = D == 0 ? nullptr : t->f_rest;
   float* g_rest = D == 0 ? nullptr : t->g_frest;
-  if ((rc = mi355gs_raster_forward_preprocess(stream, P, D, M, W, H, t->means_cam, t->f_dc, rest, nullptr, t->opac, t->scales, 1.0f,
-                                              t->rot_cam, nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, 0, t->radii,
+  if ((rc = mi355gs_raster_forward_preprocess(stream, P, D, M, W, H, t->xyz, t->f_dc, rest, nullptr, t->opacity, t->scaling, 1.0f,
+                                              t->rotation, nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, 0, t->radii,
                                               t->geom, t->tiles, num_rendered_out, 0)))
     return rc;
   if ((rc = mi355gs_raster_forward_render(stream, P, W, H, t->capacity, bg, t->geom, t->tiles, t->binning, t->image, 0))) return rc;
@@ -173,15 +177,14 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   if ((rc = gs_loss_backward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, lambda_dssim, t->dL_dimg, t->ssim_scratch,
                              loss_out)))
     return rc;
-  if ((rc = mi355gs_raster_backward(stream, P, D, M, W, H, bg, t->means_cam, t->f_dc, rest, nullptr, t->opac, t->scales, 1.0f, t->rot_cam,
+  // ---- backward: down to the raw-parameter gradients and the pose sums in one kernel, then the 7 pose gradients
+  if ((rc = mi355gs_raster_backward(stream, P, D, M, W, H, bg, t->xyz, t->f_dc, rest, nullptr, t->opacity, t->scaling, 1.0f, t->rotation,
                                     nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, t->geom, t->tiles, t->binning,
-                                    t->capacity, t->radii, t->dL_dimg, t->grad_scratch, t->g_means3D, t->g_means2D, t->g_fdc,
-                                    g_rest, t->g_colors, t->g_opac, t->g_scales, t->g_rot_cam, nullptr, 0)))
+                                    t->capacity, t->radii, t->dL_dimg, t->grad_scratch, t->g_xyz, t->g_means2D, t->g_fdc,
+                                    g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0)))
     return rc;
-  if ((rc = mi355gs_pose_backward(stream, P, t->xyz, t->rotation, t->scales, t->opac, pose, t->g_means3D, t->g_rot_cam, t->g_scales,
-                                  t->g_opac, t->g_xyz, t->g_rot, t->g_scaling, t->g_opacity, t->g_poses + 7 * (size_t)view,
-                                  t->pose_scratch)))
-    return rc;
+  gs_launch_pose_finish(stream, pose, t->pose_scratch, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6);
+  GS_CHECK_LAUNCH("pose_finish");
   // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
   if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps);
   return MI355GS_OK;

@@ -229,9 +229,20 @@ class FusedTrainer:
         self.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and _lib is not None:
             _lib.lib().mi355gs_trainer_destroy(ctypes.c_void_p(self.handle))
             self.handle = None
+
+    def gradients(self) -> dict:
+        """Copies of the gradients the last `step` left in the workspace, keyed like the GaussianModel attributes
+        (what `.grad` holds on the autograd path) — for tests and diagnostics."""
+        L, base, out = _lib.lib(), self.workspace.data_ptr(), {}
+        for k, (name, p) in enumerate(zip(self.ORDER, self.params)):
+            addr = L.mi355gs_trainer_grad(ctypes.c_void_p(self.handle), k)
+            off, nbytes = int(addr) - base, 4 * p.numel()
+            assert addr and 0 <= off and off + nbytes <= self.workspace.numel(), (name, off)
+            out[name] = self.workspace[off:off + nbytes].view(torch.float32).view(p.shape).clone()
+        return out
 
     __del__ = close
 

@@ -275,11 +275,60 @@ def check_fused_train_step_equals_autograd_path(dev, iters=6, Wm=12, W=32):
             BinningPolicy.reset("exact")
         cuda = torch.device(dev).type == "cuda"
         assert abs(res[True][0] - res[False][0]) <= (1e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
-        tol = 2e-2 if cuda else 1e-5
+        # Under the emulator (deterministic atomics) the two paths agree to rounding.  On the GPU the float atomics of the
+        # composite backward land in a different order every run and Adam amplifies that over the iterations; the second
+        # moments (sums of squared gradients) are the most sensitive quantity compared here.
         for n in names:
             for k in (1, 2):
+                tol = (2e-2 if k == 1 else 5e-2) if cuda else 1e-5
                 a, b = res[True][k][n], res[False][k][n]
                 assert float((a - b).norm() / (b.norm() + 1e-12)) <= tol, (n, k, float((a - b).norm() / (b.norm() + 1e-12)))
+    finally:
+        BinningPolicy.reset("exact")
+
+
+def check_fused_step_gradients_equal_autograd(dev, degree, Wm=10, W=24):
+    """One step from the same state: the gradients the one-call step leaves in its workspace vs `.grad` on the autograd
+    path.  This is the parity statement for the fused step (its projection kernels apply the pose transform themselves,
+    so they are different instruction sequences from the autograd path's: equal to rounding, not bit for bit, on the GPU;
+    trajectories then drift apart because Adam turns the rounding-noise gradients of the rotations — exactly zero in
+    exact arithmetic for isotropic Gaussians — into +-lr steps, as it does from run to run in the reference)."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import FusedTrainer, _forward_backward_step, setup_training
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=13)
+    mk = lambda: setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True))
+    a, b = mk(), mk()
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
+    try:
+        BinningPolicy.reset("exact")
+        for st in (a, b):
+            st.gaussians.active_sh_degree = degree
+            if degree:  # something for the higher-order coefficients to differentiate through
+                g = torch.Generator().manual_seed(3)
+                with torch.no_grad():
+                    st.gaussians._features_rest.copy_(0.05 * torch.randn(st.gaussians._features_rest.shape, generator=g).to(dev))
+        loss_a = _forward_backward_step(a, True)
+        ref = {n: getattr(a.gaussians, n).grad.detach().cpu() for n in names}
+        tr = FusedTrainer(b, 200000)
+        slot = torch.zeros(1, device=dev)
+        tr.step(slot, defer_optimizer=True, verify_async=False)
+        got = {n: v.cpu() for n, v in tr.gradients().items()}
+        tr.close()
+        cuda = torch.device(dev).type == "cuda"
+        assert abs(float(slot) - float(loss_a)) <= (1e-6 if cuda else 0.0) * max(1.0, abs(float(loss_a)))
+        for n in names:
+            d = (got[n] - ref[n]).abs().max()
+            if not cuda:
+                assert float(d) == 0.0, (n, float(d))      # the emulator runs both paths with the same arithmetic
+            else:
+                # rounding-level relative to the tensor's own size.  The rotation gradient of an isotropic Gaussian is
+                # exactly zero; what is computed is the cancellation residue of terms the size of the scale gradient,
+                # so that is the yardstick for it.
+                yard = float(ref["_scaling"].abs().max()) * 0.1 if n == "_rotation" else float(ref[n].abs().max())
+                assert float(d) <= 1e-5 * yard, (n, float(d), yard)
+        assert float(ref["_features_rest"].abs().max()) > 0 if degree else float(got["_features_rest"].abs().max()) == 0
     finally:
         BinningPolicy.reset("exact")
 
@@ -320,6 +369,10 @@ def check_run_ahead_crosses_sh_degree_step(dev, Wm=10, W=24):
         for n in names:
             a_, b_ = res[True][1][n], res[False][1][n]
             rel = float((a_ - b_).norm() / (b_.norm() + 1e-12))
+            # GPU: f_rest has had three sign-like Adam steps from zero by now, on gradients whose rounding differs between
+            # the two paths (see check_fused_step_gradients_equal_autograd) — only the emulator can compare it
+            if cuda and n == "_features_rest":
+                continue
             assert rel <= (5e-2 if cuda else 1e-5), (n, rel)
     finally:
         BinningPolicy.reset("exact")

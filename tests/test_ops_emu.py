@@ -97,3 +97,8 @@ def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
 @pytest.mark.parametrize("degree", [1, 3])
 def test_split_sh_equals_concatenated(emu, degree):
     ops_util.check_split_sh_equals_concatenated(emu, degree=degree)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 3])
+def test_fused_step_gradients_equal_autograd(emu, degree):
+    ops_util.check_fused_step_gradients_equal_autograd(emu, degree)

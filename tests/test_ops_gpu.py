@@ -73,3 +73,8 @@ def test_training_improves_psnr(gpu):
 @pytest.mark.parametrize("degree", [1, 3])
 def test_split_sh_equals_concatenated(gpu, degree):
     ops_util.check_split_sh_equals_concatenated(gpu, degree=degree)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 3])
+def test_fused_step_gradients_equal_autograd(gpu, degree):
+    ops_util.check_fused_step_gradients_equal_autograd(gpu, degree)
