@@ -54,6 +54,7 @@ struct MultiAdamArgs {
   float* v[MT_MAX];
   const float* pplr[MT_MAX];
   float step_size[MT_MAX];
+  int vec4[MT_MAX];  // numel % 4 == 0 and all four arrays 16-byte aligned: 128-bit loads/stores
 };
 
 __device__ __forceinline__ int mt_find(const MultiAdamArgs& a, int b) {
@@ -70,7 +71,14 @@ __global__ __launch_bounds__(256) void k_adam_sumsq(MultiAdamArgs a, float* __re
   const long long hi = min(a.numel[t], lo + MT_CHUNK);
   const float* g = a.grad[t];
   float acc = 0.f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) { const float x = g[i]; acc += x * x; }
+  if (a.vec4[t]) {
+    for (long long j = (lo >> 2) + threadIdx.x; j < (hi >> 2); j += 256) {
+      const float4 x = reinterpret_cast<const float4*>(g)[j];
+      acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) { const float x = g[i]; acc += x * x; }
+  }
   acc = gs_wave_sum_row3(acc);
   if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -93,23 +101,43 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
   const float* __restrict__ pplr = a.pplr[t];
   const int row = a.row[t];
   const float step_size = a.step_size[t];
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    float m = mm[i];
-    // A tensor whose gradient is all zero keeps its moments but still takes the parameter step (the reference's
-    // whole-tensor gate).  Where the first moment is zero that step is p - s * (0 / denom) == p bit for bit, so only
-    // exp_avg is read: f_rest before the SH degree is raised costs 4 B per element instead of 16.
-    if (!update && m == 0.f) continue;
-    float v = vv[i];
+  auto one = [&](float& pv, float gi, float& m, float& v, long long i) {
     if (update) {
-      const float gi = g[i];
       m = m * beta1 + gi * (1.f - beta1);
       v = v * beta2 + gi * gi * (1.f - beta2);
-      mm[i] = m;
-      vv[i] = v;
     }
     const float denom = sqrtf(v) + eps;
     const float s = pplr ? step_size * pplr[i / row] : step_size;
-    p[i] = p[i] - s * (m / denom);
+    pv = pv - s * (m / denom);
+  };
+  if (a.vec4[t]) {
+    // 16 bytes per lane and access: a quarter of the memory instructions of the scalar loop for the same bytes
+    const long long vlo = lo >> 2, vhi = hi >> 2;  // MT_CHUNK and numel are multiples of 4
+    for (long long j = vlo + threadIdx.x; j < vhi; j += 256) {
+      float4 m4 = reinterpret_cast<const float4*>(mm)[j];
+      // A tensor whose gradient is all zero keeps its moments but still takes the parameter step (the reference's
+      // whole-tensor gate).  Where the first moment is zero that step is p - s * (0 / denom) == p bit for bit, so only
+      // exp_avg is read: f_rest before the SH degree is raised costs 4 B per element instead of 16.
+      if (!update && m4.x == 0.f && m4.y == 0.f && m4.z == 0.f && m4.w == 0.f) continue;
+      float4 v4 = reinterpret_cast<const float4*>(vv)[j];
+      float4 p4 = reinterpret_cast<const float4*>(p)[j];
+      float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (update) g4 = reinterpret_cast<const float4*>(g)[j];
+      one(p4.x, g4.x, m4.x, v4.x, 4 * j); one(p4.y, g4.y, m4.y, v4.y, 4 * j + 1);
+      one(p4.z, g4.z, m4.z, v4.z, 4 * j + 2); one(p4.w, g4.w, m4.w, v4.w, 4 * j + 3);
+      if (update) { reinterpret_cast<float4*>(mm)[j] = m4; reinterpret_cast<float4*>(vv)[j] = v4; }
+      reinterpret_cast<float4*>(p)[j] = p4;
+    }
+    return;
+  }
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    float m = mm[i];
+    if (!update && m == 0.f) continue;  // see the vector path
+    float v = vv[i], pv = p[i];
+    const float gi = update ? g[i] : 0.f;
+    one(pv, gi, m, v, i);
+    if (update) { mm[i] = m; vv[i] = v; }
+    p[i] = pv;
   }
 }
 
@@ -136,10 +164,11 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
       a.param[t] = params[t]; a.grad[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.pplr[t] = per_point_lr[t];
       const double bc1 = 1.0 - pow((double)beta1, (double)step[t]), bc2 = 1.0 - pow((double)beta2, (double)step[t]);
       a.step_size[t] = (float)((double)lr[t] * (sqrt(bc2) / bc1));
+      a.vec4[t] = (numel[t] % 4 == 0 && (((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avg[t] | (uintptr_t)exp_avg_sq[t]) & 15) == 0) ? 1 : 0;
       blocks += (int)((numel[t] + MT_CHUNK - 1) / MT_CHUNK);
     } else {
       a.numel[t] = 0; a.row[t] = 1; a.param[t] = nullptr; a.grad[t] = nullptr; a.m[t] = nullptr; a.v[t] = nullptr; a.pplr[t] = nullptr;
-      a.step_size[t] = 0.f;
+      a.step_size[t] = 0.f; a.vec4[t] = 0;
     }
   }
   a.first_block[MT_MAX] = blocks;
