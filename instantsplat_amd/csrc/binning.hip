@@ -503,7 +503,7 @@ int gs_launch_count_tiles(hipStream_t stream, int P, int T, int gx, const uint2*
 }
 
 int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const GsRec* recs, const uint2* rects, const uint32_t* start,
-                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity, const uint32_t* order, GsSched* sched,
+                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity, const uint32_t* order,
                       const uint32_t* meta) {
   if (P <= 0 || capacity == 0) return 0;
   if (T <= BIN_MAX_LDS_TILES)

@@ -95,13 +95,6 @@ struct BinningLayout {
   }
 };
 
-// XCD-aware block -> tile map: hardware places block b on XCD b % 8 (observed, speed only); give
-// each XCD one contiguous band of tile rows so neighbouring tiles (which share Gaussians) share an L2.
-__device__ __forceinline__ int gs_tile_of_block(int b, int T) {
-  const int per = (T + 7) >> 3;
-  return (b & 7) * per + (b >> 3);
-}
-static inline int gs_grid_for_tiles(int T) { return ((T + 7) >> 3) << 3; }
 int gs_num_cus();  // api.hip: compute units of the current device (cached)
 // persistent per-tile kernels: at most six workgroups per CU (LDS-limited residency of the composite kernels)
 static inline int gs_grid_persistent(int T, int NB) { return T < 6 * NB ? T : 6 * NB; }
