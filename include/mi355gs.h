@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 2
+#define MI355GS_ABI_VERSION 3
 
 /* error codes */
 #define MI355GS_OK 0
@@ -46,14 +46,15 @@ const char* mi355gs_error_string(int code);
  * Scratch layout (caller allocates `bytes` from the *_bytes() queries, 256-byte aligned):
  *   geom    : per-Gaussian records written by preprocess, read by render and backward
  *   tiles   : per-tile counters / offsets; per-pixel final transmittance and contributor counts
- *   binning : per-instance sort keys and the depth-sorted per-tile Gaussian index lists
+ *   binning : per-instance sort keys and the depth-sorted per-tile Gaussian index lists; the backward's work units
+ *             (segments of 256 instances of a tile's list) and the per-pixel state the forward leaves at their boundaries
  * The forward is split in two so the caller can size `binning` exactly (one 4-byte D2H read of
  * *num_rendered between the calls, as the reference operator does internally) or skip the read
  * and pass a capacity bound (no host sync; overflow is reported through *num_rendered > capacity).
  * ---------------------------------------------------------------------------------------------- */
 size_t mi355gs_raster_geom_bytes(int P);
 size_t mi355gs_raster_tiles_bytes(int W, int H);
-size_t mi355gs_raster_binning_bytes(int64_t num_instances);
+size_t mi355gs_raster_binning_bytes(int64_t num_instances, int W, int H);
 
 /* Stage 1: per-Gaussian projection (frustum cull, EWA 2-D covariance, conic, radius, tile rect,
  * SH -> RGB), per-tile instance counts and their exclusive scan.
@@ -85,7 +86,7 @@ int mi355gs_raster_forward_render(
  *   dL_dmeans3D[P,3] dL_dmeans2D[P,3] (x,y in the reference's NDC-scaled screen units, z = 0)
  *   dL_dshs[P,M,3] (split storage: dL_dshs[P,1,3] + dL_dshs_rest[P,M-1,3]) or dL_dcolors[P,3], dL_dopacities[P],
  *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
- *   geom/tiles/binning/capacity/radii: exactly what the forward of this frame used and produced
+ *   geom/tiles/binning/capacity/radii/out_color: exactly what the forward of this frame used and produced
  *   (`tiles` also holds the tile scheduler's counters, which the kernels consume and re-arm: not const)
  *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes */
 size_t mi355gs_raster_grad_scratch_bytes(int P);
@@ -96,7 +97,7 @@ int mi355gs_raster_backward(
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tanfovx, float tanfovy,
     const void* geom, void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
-    const float* dL_dpix, void* grad_scratch,
+    const float* out_color, const float* dL_dpix, void* grad_scratch,
     float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities,
     float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int debug);
 

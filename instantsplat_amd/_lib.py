@@ -23,13 +23,13 @@ _SIGNATURES = {
     "mi355gs_error_string": (ctypes.c_char_p, [c_int]),
     "mi355gs_raster_geom_bytes": (c_size_t, [c_int]),
     "mi355gs_raster_tiles_bytes": (c_size_t, [c_int, c_int]),
-    "mi355gs_raster_binning_bytes": (c_size_t, [c_int64]),
+    "mi355gs_raster_binning_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mi355gs_raster_grad_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_raster_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P,
                                                   _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_forward_render": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
-                                        _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                        _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                         c_int]),
     "mi355gs_raster_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),

@@ -11,14 +11,14 @@ int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const flo
                              const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
                              float*, float*, float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
-int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, GsSched*, uint32_t*);
+int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, GsSched*, uint32_t*, uint32_t*);
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t,
                       const uint32_t*, const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            float*, float*, uint32_t*, const uint32_t*, GsSched*);
-int gs_launch_composite_bwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            const float*, const uint32_t*, const float*, GsGrad*, const uint32_t*, GsSched*);
-
+                            float*, float*, uint32_t*, const uint32_t*, GsSched*, const uint32_t*, uint32_t*, float4*, uint32_t);
+int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
+                            const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint32_t*, const uint32_t*,
+                            const float4*, const uint32_t*, uint32_t);
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
 // ---- optional per-kernel timing (HIP events on the launch stream)
@@ -94,7 +94,10 @@ const char* mi355gs_error_string(int code) {
 
 size_t mi355gs_raster_geom_bytes(int P) { return GeomLayout(P).total; }
 size_t mi355gs_raster_tiles_bytes(int W, int H) { return (W > 0 && H > 0) ? TilesLayout(W, H).total : 0; }
-size_t mi355gs_raster_binning_bytes(int64_t n) { return BinningLayout(n).total; }
+size_t mi355gs_raster_binning_bytes(int64_t n, int W, int H) {
+  if (W <= 0 || H <= 0) return 0;
+  return BinningLayout(n, TilesLayout(W, H).T).total;
+}
 size_t mi355gs_raster_grad_scratch_bytes(int P) { return gs_align((size_t)(P > 0 ? P : 1) * sizeof(GsGrad)); }
 
 int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
@@ -125,7 +128,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
   GS_CHECK_LAUNCH("count_tiles");
   gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered,
-                       (uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched), (uint32_t*)(t + tl.meta));
+                       (uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched), (uint32_t*)(t + tl.meta), (uint32_t*)(t + tl.seg_first));
   GS_CHECK_LAUNCH("scan_tiles");
   return MI355GS_OK;
 }
@@ -138,7 +141,7 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
   if (cap > 0 && !binning) return MI355GS_EINVAL;
   const GeomLayout gl(P);
   const TilesLayout tl(W, H);
-  const BinningLayout bl(capacity);
+  const BinningLayout bl(capacity, tl.T);
   const char* g = (const char*)geom;
   char* t = (char*)tiles;
   char* b = (char*)binning;
@@ -150,7 +153,8 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
     ProfScope prof(0, stream);
     gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
-                            (const uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched));
+                            (const uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched), (const uint32_t*)(t + tl.seg_first),
+                            (uint32_t*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units);
   }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;
@@ -160,14 +164,14 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                             const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
                             float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                             const float* projmatrix, const float* campos, float tanfovx, float tanfovy, const void* geom,
-                            void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
+                            void* tiles, const void* binning, int64_t capacity, const int32_t* radii, const float* out_color,
                             const float* dL_dpix, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                             float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                             int debug) {
   (void)opacities; (void)colors_precomp;
   hipStream_t stream = (hipStream_t)stream_;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return MI355GS_EINVAL;
-  if (!geom || !tiles || !dL_dpix || !grad_scratch || !bg || !viewmatrix || !projmatrix || !campos) return MI355GS_EINVAL;
+  if (!geom || !tiles || !dL_dpix || !out_color || !grad_scratch || !bg || !viewmatrix || !projmatrix || !campos) return MI355GS_EINVAL;
   if (P > 0 && (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities)) return MI355GS_EINVAL;
   const int use_shs = shs != nullptr, use_cov = cov3D_precomp != nullptr;
   if (P > 0 && use_shs && !dL_dshs) return MI355GS_EINVAL;
@@ -180,7 +184,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   if (cap > 0 && !binning) return MI355GS_EINVAL;
   const GeomLayout gl(P);
   const TilesLayout tl(W, H);
-  const BinningLayout bl(capacity);
+  const BinningLayout bl(capacity, tl.T);
   const char* g = (const char*)geom;
   char* t = (char*)tiles;  // geometry of the frame is read-only here; the tile scheduler's words are consumed and re-armed
   const char* b = (const char*)binning;
@@ -189,9 +193,10 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   if (cap > 0) {
     {
       ProfScope prof(1, stream);
-      gs_launch_composite_bwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
+      gs_launch_composite_bwd(stream, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                               (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
-                              dL_dpix, grads, (const uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched));
+                              dL_dpix, grads, out_color, (const uint32_t*)(t + tl.seg_first), (const uint32_t*)(b + bl.unit_tile),
+                              (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units);
     }
     GS_CHECK_LAUNCH("composite_bwd");
   }

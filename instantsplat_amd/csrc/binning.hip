@@ -27,7 +27,8 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 // words are cleared.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ sched_words,
-                                                               int n_sched_words, uint32_t* __restrict__ meta) {
+                                                               int n_sched_words, uint32_t* __restrict__ meta,
+                                                               uint32_t* __restrict__ seg_first) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -95,6 +96,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     __syncthreads();
     for (int i = lo; i < hi; ++i) order[atomicAdd(&hist[bucket(count[i])], 1u)] = (uint32_t)i;
     __syncthreads();
+  }
+  if (seg_first) {
+    // first backward unit of every tile: exclusive scan of ceil(count / GS_SEG) (same two-level scan as below)
+    uint32_t lseg = 0;
+    for (int i = lo; i < hi; ++i) lseg += (count[i] + GS_SEG - 1) / GS_SEG;
+    uint32_t iseg = lseg;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(iseg, d);
+      if (lane >= d) iseg += o;
+    }
+    __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
+    if (lane == 63) seg_wave[wave] = iseg;
+    __syncthreads();
+    uint32_t soff = 0, stot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w) {
+      if (w < wave) soff += seg_wave[w];
+      stot += seg_wave[w];
+    }
+    uint32_t srun = soff + iseg - lseg;
+    for (int i = lo; i < hi; ++i) {
+      seg_first[i] = srun;
+      srun += (count[i] + GS_SEG - 1) / GS_SEG;
+    }
+    if (tid == 0) { seg_first[T] = stot; meta[1] = stot; }
   }
   uint32_t run = wave_off + incl - local;
   for (int i = lo; i < hi; ++i) {
@@ -477,9 +504,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_large(int T, const 
 }  // namespace
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
-                         GsSched* sched, uint32_t* meta) {
+                         GsSched* sched, uint32_t* meta, uint32_t* seg_first) {
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order,
-                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4), meta);
+                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4), meta, seg_first);
   return 0;
 }
 
@@ -488,7 +515,7 @@ int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
-                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0, (uint32_t*)nullptr);  // in place
+                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr);  // in place
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
 }

@@ -64,11 +64,11 @@ struct GsSched {
   uint32_t claimed, pad_a[15];
   uint32_t done, pad_b[15];
 };
-enum { GS_SCHED_FWD = 0, GS_SCHED_BWD = 1, GS_SCHED_COUNT = 2 };
+enum { GS_SCHED_FWD = 0, GS_SCHED_COUNT = 1 };
 constexpr int GS_SORT_SMALL_CAP = 2048;  // tiles above this many instances are sorted by the large-tile kernel; k_scan_tiles puts them first in `order`
 
 struct TilesLayout {
-  size_t count, start, cursor, final_T, n_contrib, order, sched, meta, total;
+  size_t count, start, cursor, final_T, n_contrib, order, seg_first, sched, meta, total;
   int gx, gy, T;
   __host__ TilesLayout(int W, int H) {
     gx = (W + GS_TILE - 1) / GS_TILE; gy = (H + GS_TILE - 1) / GS_TILE; T = gx * gy;
@@ -79,18 +79,30 @@ struct TilesLayout {
     final_T = o; o += gs_align(npix * 4);
     n_contrib = o; o += gs_align(npix * 4);
     order = o; o += gs_align((size_t)T * 4);
+    seg_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of ceil(count / GS_SEG): first unit of a tile
     sched = o; o += gs_align(GS_SCHED_COUNT * sizeof(GsSched));
-    meta = o; o += gs_align(16);   // [0]: number of tiles with more than GS_SORT_SMALL_CAP instances
+    meta = o; o += gs_align(16);   // [0]: number of tiles with more than GS_SORT_SMALL_CAP instances, [1]: number of units
     total = o;
   }
 };
 
+// Backward work units: a tile's depth-ordered list is cut into segments of GS_SEG instances.  The forward composite
+// leaves each pixel's (transmittance, accumulated colour) at every segment boundary, so the backward can replay the
+// segments independently: thousands of equal-sized workgroups that the hardware balances, instead of one workgroup per
+// tile that lasts as long as the tile is deep (composite.hip).
+constexpr int GS_SEG = 64;
+constexpr int GS_UNIT_TILE_BITS = 20;  // unit table entry = tile | segment << 20
+
 struct BinningLayout {
-  size_t keys, list, total;
-  __host__ explicit BinningLayout(int64_t R) {
+  size_t keys, list, unit_tile, bstate, total;
+  uint32_t max_units;  // table / boundary slots available: ceil(R / GS_SEG) + T
+  __host__ BinningLayout(int64_t R, int T) {
     size_t n = R > 0 ? (size_t)R : 1, o = 0;
     keys = o; o += gs_align(n * 8);
     list = o; o += gs_align(n * 4);
+    max_units = (uint32_t)((n + GS_SEG - 1) / GS_SEG + (size_t)(T > 0 ? T : 1));
+    unit_tile = o; o += gs_align((size_t)max_units * 4);
+    bstate = o; o += gs_align((size_t)max_units * 256 * sizeof(float4));  // per boundary: 256 pixels x (T, C0, C1, C2)
     total = o;
   }
 };

@@ -82,7 +82,8 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
                                                    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                    const GsRec* __restrict__ recs, const float* __restrict__ bg,
                                                    float* __restrict__ out_color, float* __restrict__ final_T,
-                                                   uint32_t* __restrict__ n_contrib) {
+                                                   uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_first,
+                                                   uint32_t* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
   __shared__ float4 s_q0[BATCH];
   __shared__ float4 s_q1[BATCH];
   __shared__ float4 s_q2[BATCH];
@@ -90,6 +91,12 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  // Backward units of this tile (segments of GS_SEG instances, see common.h): publish them, and leave every pixel's
+  // (transmittance after the last blended Gaussian, accumulated colour) at each segment boundary for the backward.
+  const uint32_t seg0 = seg_first[tile], nseg = seg_first[tile + 1] - seg0;
+  for (uint32_t sg = tid; sg < nseg; sg += 256)
+    if (seg0 + sg < max_units) unit_tile[seg0 + sg] = (uint32_t)tile | (sg << GS_UNIT_TILE_BITS);
+  uint32_t next_boundary = 0;  // boundaries [0, next_boundary) of this tile have been stored by this wave
 
   // Tr: live transmittance, forced to 0 once the pixel is finished (T < 1e-4 reached, or outside the image);
   // Tfin: transmittance after the last blended Gaussian (the value the reference stores as final_T)
@@ -154,9 +161,17 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
           if (!moreA) break;
         }
       }
+      const uint32_t pos = (base - start) + (uint32_t)k + 64u;  // instances of the tile blended so far
+      if (pos % GS_SEG == 0u) {
+        next_boundary = pos / GS_SEG;
+        if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(Tfin, C0, C1, C2);
+      }
       if (__all(Tr == 0.0f)) break;
     }
   }
+  // boundaries this wave never reached (all its pixels were finished, or the tile ended): the state no longer changes
+  for (uint32_t sg = next_boundary; sg + 1u < nseg; ++sg)
+    if (seg0 + sg < max_units) bstate[(size_t)(seg0 + sg) * 256 + tid] = make_float4(Tfin, C0, C1, C2);
   if (q.inside) {
     const size_t pix = (size_t)q.py * W + q.px, plane = (size_t)W * H;
     final_T[pix] = Tfin;
@@ -172,9 +187,11 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
                                                         float* __restrict__ out_color, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order,
-                                                        GsSched* sched, int NB) {
+                                                        GsSched* sched, int NB, const uint32_t* __restrict__ seg_first,
+                                                        uint32_t* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
   GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
-                          composite_fwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T, n_contrib))
+                          composite_fwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T, n_contrib,
+                                             seg_first, unit_tile, bstate, max_units))
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,19 +201,32 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
 // them per pixel).  Gaussians whose box misses the wave's quadrant, or that lie behind every
 // pixel's last contributor, are skipped wave-wide.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void composite_bwd_tile(int tile, int gx, int W, int H, uint32_t capacity,
-                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
-                                                   const GsRec* __restrict__ recs, const float* __restrict__ bg,
-                                                   const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                                                   const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads) {
+// One workgroup = one UNIT: segment `seg` (GS_SEG instances) of one tile's list.  The state a back-to-front replay would
+// carry into the segment comes from the forward's boundary record instead: T is the forward's own product, and the colour
+// behind is dL/dC . (final colour - colour accumulated in front of the boundary).
+__global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
+                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
+                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
+                                                        const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                                        const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
+                                                        const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
+                                                        const uint32_t* __restrict__ unit_tile, const float4* __restrict__ bstate,
+                                                        const uint32_t* __restrict__ meta, uint32_t max_units) {
+  constexpr int BATCH = GS_SEG;
   __shared__ float4 s_q0[BATCH];
   __shared__ float4 s_q1[BATCH];
   __shared__ float4 s_q2[BATCH];
   __shared__ uint32_t s_max[4];
+  const uint32_t unit = blockIdx.x;
+  if (unit >= min(meta[1], max_units)) return;
+  const uint32_t entry = unit_tile[unit];
+  const int tile = (int)(entry & ((1u << GS_UNIT_TILE_BITS) - 1u));
+  const uint32_t seg = entry >> GS_UNIT_TILE_BITS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  if (end <= start) return;
+  const uint32_t boff = seg * GS_SEG;  // contributor index (0-based) of this unit's first instance
+  if (end <= start + boff) return;
 
   const size_t pix = (size_t)q.py * W + q.px, plane = (size_t)W * H;
   const float T_final = q.inside ? final_T[pix] : 0.f;
@@ -212,20 +242,27 @@ __device__ __forceinline__ void composite_bwd_tile(int tile, int gx, int W, int 
   for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m));
   if (lane == 0) s_max[wave] = wmax;
   __syncthreads();
-  const uint32_t tile_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-  if (tile_max == 0) return;
+  const uint32_t tile_max = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), end - start);
+  if (tile_max <= boff) return;  // every pixel's last contributor lies in front of this segment
 
   const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
   const bool out_lane = (lane & 14) == 0 || lane == 2;                 // the nine lanes that hold a finished sum
   const int out_comp = lane == 2 ? 8 : (lane >> 4) + 4 * (lane & 1);   // ... and which of the nine it is
   float Tr = T_final;
   float behind = T_final * bg_dot;  // dL/dC . (everything composited behind the current Gaussian, background included)
+  if (boff + GS_SEG < tile_max) {
+    // not the deepest active segment: resume from the forward's record at this segment's far boundary
+    const uint32_t slot = seg_first[tile] + seg;
+    if (slot < max_units) {
+      const float4 b = bstate[(size_t)slot * 256 + tid];
+      Tr = b.x;
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      if (q.inside) { c0 = out_color[pix]; c1 = out_color[plane + pix]; c2 = out_color[2 * plane + pix]; }
+      behind = (c0 - b.y) * g0 + (c1 - b.z) * g1 + (c2 - b.w) * g2;
+    }
+  }
 
-  // batches are aligned to the list start so that batch boundaries match contributor numbering
-  const uint32_t nb = (tile_max + BATCH - 1) / BATCH;
-  for (uint32_t bi = nb; bi-- > 0;) {
-    const uint32_t boff = bi * BATCH;  // contributor index (0-based) of this batch's first instance
-    __syncthreads();
+  {
 #pragma unroll
     for (int sl = tid; sl < BATCH; sl += 256) {
       if (boff + sl < tile_max) {
@@ -236,7 +273,7 @@ __device__ __forceinline__ void composite_bwd_tile(int tile, int gx, int W, int 
       }
     }
     __syncthreads();
-    if (boff >= wmax) continue;  // nothing in this batch is in front of any of this wave's pixels' last contributor
+    if (boff >= wmax) return;  // nothing in this segment is in front of any of this wave's pixels' last contributor
     const int cnt = (int)min((uint32_t)BATCH, tile_max - boff);
     for (int k = ((cnt - 1) >> 6) << 6; k >= 0; k -= 64) {
       if (boff + (uint32_t)k >= wmax) continue;
@@ -323,16 +360,6 @@ __device__ __forceinline__ void composite_bwd_tile(int tile, int gx, int W, int 
   }
 }
 
-__global__ __launch_bounds__(256) void k_composite_bwd(int T, int gx, int W, int H, uint32_t capacity,
-                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
-                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
-                                                        const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                                                        const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
-                                                        const uint32_t* __restrict__ order, GsSched* sched, int NB) {
-  GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
-                          composite_bwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, final_T, n_contrib, dL_dpix, grads))
-}
-
 // per-tile max of n_contrib -> R_eff (roofline accounting only)
 __global__ __launch_bounds__(256) void k_frame_stats(int T, int gx, int W, int H, const uint32_t* __restrict__ tile_start,
                                                       const uint32_t* __restrict__ n_contrib, int64_t* __restrict__ stats) {
@@ -362,18 +389,21 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
 
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
-                            uint32_t* n_contrib, const uint32_t* order, GsSched* sched) {
+                            uint32_t* n_contrib, const uint32_t* order, GsSched* sched, const uint32_t* seg_first, uint32_t* unit_tile,
+                            float4* bstate, uint32_t max_units) {
   const int NB = gs_num_cus();
   hipLaunchKernelGGL(k_composite_fwd, dim3(gs_grid_persistent(T, NB)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
-                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB);
+                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB, seg_first, unit_tile, bstate, max_units);
   return 0;
 }
 
-int gs_launch_composite_bwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
+// one workgroup per backward unit; the grid covers every unit the buffers can hold, workgroups past the frame's count exit
+int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
-                            const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const uint32_t* order, GsSched* sched) {
-  const int NB = gs_num_cus();
-  hipLaunchKernelGGL(k_composite_bwd, dim3(gs_grid_persistent(T, NB)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
-                     recs, bg, final_T, n_contrib, dL_dpix, grads, order, sched + GS_SCHED_BWD, NB);
+                            const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
+                            const uint32_t* seg_first, const uint32_t* unit_tile, const float4* bstate, const uint32_t* meta,
+                            uint32_t max_units) {
+  hipLaunchKernelGGL(k_composite_bwd, dim3(max_units), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,
+                     n_contrib, dL_dpix, grads, out_color, seg_first, unit_tile, bstate, meta, max_units);
   return 0;
 }

@@ -55,7 +55,7 @@ size_t carve(Trainer& t, void* workspace) {
   const size_t P = (size_t)(t.P > 0 ? t.P : 1), npix = (size_t)t.W * t.H;
   t.geom = c.take<char>(mi355gs_raster_geom_bytes(t.P));
   t.tiles = c.take<char>(mi355gs_raster_tiles_bytes(t.W, t.H));
-  t.binning = c.take<char>(mi355gs_raster_binning_bytes(t.capacity));
+  t.binning = c.take<char>(mi355gs_raster_binning_bytes(t.capacity, t.W, t.H));
   t.grad_scratch = c.take<char>(mi355gs_raster_grad_scratch_bytes(t.P));
   t.ssim_scratch = c.take<char>(mi355gs_ssim_scratch_bytes(1, 3, t.H, t.W));
   t.image = c.take<float>(3 * npix); t.dm1 = c.take<float>(3 * npix); t.dm2 = c.take<float>(3 * npix);
@@ -180,7 +180,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   // ---- backward: down to the raw-parameter gradients and the pose sums in one kernel, then the 7 pose gradients
   if ((rc = mi355gs_raster_backward(stream, P, D, M, W, H, bg, t->xyz, t->f_dc, rest, nullptr, t->opacity, t->scaling, 1.0f, t->rotation,
                                     nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, t->geom, t->tiles, t->binning,
-                                    t->capacity, t->radii, t->dL_dimg, t->grad_scratch, t->g_xyz, t->g_means2D, t->g_fdc,
+                                    t->capacity, t->radii, t->image, t->dL_dimg, t->grad_scratch, t->g_xyz, t->g_means2D, t->g_fdc,
                                     g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0)))
     return rc;
   gs_launch_pose_finish(stream, pose, t->pose_scratch, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6);

@@ -171,7 +171,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 R = int(num_rendered.item())  # the reference operator's own blocking read-back
                 if key is not None:
                     BinningPolicy.known[key] = R
-            binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R), dev)
+            binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R, W, H), dev)
             _lib.check(L.mi355gs_raster_forward_render(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
                                                        _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render")
             return R, binning
@@ -194,7 +194,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.sh_rest = shr_
         ctx.save_for_backward(means3D, sh_ if sh_ is not None else torch.empty(0), col_ if col_ is not None else torch.empty(0),
                               opac, sc_ if sc_ is not None else torch.empty(0), rot_ if rot_ is not None else torch.empty(0),
-                              cov_ if cov_ is not None else torch.empty(0), radii, geom, tiles, binning, bg, view, proj, campos)
+                              cov_ if cov_ is not None else torch.empty(0), radii, geom, tiles, binning, bg, view, proj, campos, color)
         ctx.mark_non_differentiable(radii)
         ctx.opacity_shape = opacities.shape
         return color, radii
@@ -204,7 +204,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.raster_settings
         L = _lib.lib()
         P, D, M, W, H = ctx.dims
-        (means3D, sh_, col_, opac, sc_, rot_, cov_, radii, geom, tiles, binning, bg, view, proj, campos) = ctx.saved_tensors
+        (means3D, sh_, col_, opac, sc_, rot_, cov_, radii, geom, tiles, binning, bg, view, proj, campos, color) = ctx.saved_tensors
         opt = lambda t: None if t.numel() == 0 else t
         sh_, col_, sc_, rot_, cov_ = opt(sh_), opt(col_), opt(sc_), opt(rot_), opt(cov_)
         dev = means3D.device
@@ -227,7 +227,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 stream, P, D, M, W, H, _lib.ptr(bg), _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(shr_), _lib.ptr(col_), _lib.ptr(opac),
                 _lib.ptr(sc_), float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj),
                 _lib.ptr(campos), float(s.tanfovx), float(s.tanfovy), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(binning),
-                int(ctx.num_rendered), _lib.ptr(radii), _lib.ptr(g), _lib.ptr(scratch), _lib.ptr(dL_dmeans3D),
+                int(ctx.num_rendered), _lib.ptr(radii), _lib.ptr(color), _lib.ptr(g), _lib.ptr(scratch), _lib.ptr(dL_dmeans3D),
                 _lib.ptr(dL_dmeans2D), _lib.ptr(dL_dsh), _lib.ptr(dL_dshr), _lib.ptr(dL_dcol), _lib.ptr(dL_dopac), _lib.ptr(dL_dscales),
                 _lib.ptr(dL_drot), _lib.ptr(dL_dcov), 1 if s.debug else 0), "raster_backward")
 
