@@ -104,9 +104,9 @@ __device__ __forceinline__ float3 sh_eval(const float* sh /*[M,3]*/, float x, fl
 // POSED (one-call train step, see GsPosed): means3D / rotations / scales / opacities are the RAW parameters (xyz, raw
 // quaternion, log-scale, opacity logit); the camera-frame transform and the activations are applied here, and the step's
 // accumulators are cleared on the way (this is then the first kernel of the step).
-template <bool POSED>
+template <bool POSED, int D>
 __global__ __launch_bounds__(256) void k_preprocess_fwd(
-    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+    int P, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, CamParams cp,
     int32_t* __restrict__ radii, GsRec* __restrict__ recs, float* __restrict__ cov3Ds, uint2* __restrict__ rects,
@@ -189,24 +189,18 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     dx *= inv; dy *= inv; dz *= inv;
     float3 v;
+    constexpr int NBF = (D + 1) * (D + 1);
     if (shs_rest == nullptr) {
-      const float* sh = shs + (size_t)i * M * 3;
-      if (D == 0) v = sh_eval<1>(sh, dx, dy, dz);
-      else if (D == 1) v = sh_eval<4>(sh, dx, dy, dz);
-      else if (D == 2) v = sh_eval<9>(sh, dx, dy, dz);
-      else v = sh_eval<16>(sh, dx, dy, dz);
+      v = sh_eval<NBF>(shs + (size_t)i * M * 3, dx, dy, dz);
     } else {
       // split storage (the reference's own parameter layout: _features_dc [P,1,3] + _features_rest [P,M-1,3]):
       // no cat(f_dc, f_rest) has to be materialised for the rasterizer
-      float shl[48];
-      const int nbl = (D + 1) * (D + 1);
+      float shl[NBF * 3];
       shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
       const float* rest = shs_rest + (size_t)i * (M - 1) * 3;
-      for (int k = 3; k < nbl * 3; ++k) shl[k] = rest[k - 3];
-      if (D == 0) v = sh_eval<1>(shl, dx, dy, dz);
-      else if (D == 1) v = sh_eval<4>(shl, dx, dy, dz);
-      else if (D == 2) v = sh_eval<9>(shl, dx, dy, dz);
-      else v = sh_eval<16>(shl, dx, dy, dz);
+#pragma unroll
+      for (int k = 3; k < NBF * 3; ++k) shl[k] = rest[k - 3];
+      v = sh_eval<NBF>(shl, dx, dy, dz);
     }
     v.x += 0.5f; v.y += 0.5f; v.z += 0.5f;
     clamp_bits = (uint8_t)((v.x < 0.f ? 1 : 0) | (v.y < 0.f ? 2 : 0) | (v.z < 0.f ? 4 : 0));
@@ -290,9 +284,9 @@ __device__ __forceinline__ void sh_backward(const float* sh, float* gsh, float x
 
 // POSED: see k_preprocess_fwd; the outputs named dL_dmeans3D / dL_drots / dL_dscales / dL_dopac then receive the gradients
 // of the RAW parameters (xyz, raw quaternion, log-scale, opacity logit) and the 16 pose sums are accumulated.
-template <bool POSED>
+template <bool POSED, int D>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
-    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+    int P, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ scales, const float* __restrict__ rotations, int use_shs, int use_cov_precomp, CamParams cp, const int32_t* __restrict__ radii,
     const GsRec* __restrict__ recs, const float* __restrict__ cov3Ds, const uint8_t* __restrict__ clamped, const GsGrad* __restrict__ grads,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest,
@@ -327,10 +321,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
   const float3 gcol = make_float3(g.g1.z, g.g1.w, g.g2.x);
-  const int nb = (D + 1) * (D + 1);
+  constexpr int nb = (D + 1) * (D + 1);
   const bool split = shs_rest != nullptr;
-  float gsh_local[48];
-  float* gsh = dL_dshs ? (split ? gsh_local : dL_dshs + (size_t)i * M * 3) : nullptr;
+  float gsh_local[nb * 3];  // SH gradient of the active bands, in registers; stored (and zero-padded) at the end
 
   if (vis) {
     const float* view = cp.view;
@@ -402,19 +395,19 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       dx *= inv; dy *= inv; dz *= inv;
       const uint8_t cl = clamped[i];
       const float3 gr = make_float3((cl & 1) ? 0.f : gcol.x, (cl & 2) ? 0.f : gcol.y, (cl & 4) ? 0.f : gcol.z);
-      float shl[48];
-      const float* sh = shs + (size_t)i * M * 3;
+      float shl[nb * 3];  // the active coefficients, in registers (from one [P,M,3] tensor or from f_dc + f_rest)
       if (split) {
         shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
         const float* rest = shs_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
         for (int k = 3; k < nb * 3; ++k) shl[k] = rest[k - 3];
-        sh = shl;
+      } else {
+        const float* src = shs + (size_t)i * M * 3;
+#pragma unroll
+        for (int k = 0; k < nb * 3; ++k) shl[k] = src[k];
       }
       float gd[3];
-      if (D == 0) sh_backward<1>(sh, gsh, dx, dy, dz, gr, gd);
-      else if (D == 1) sh_backward<4>(sh, gsh, dx, dy, dz, gr, gd);
-      else if (D == 2) sh_backward<9>(sh, gsh, dx, dy, dz, gr, gd);
-      else sh_backward<16>(sh, gsh, dx, dy, dz, gr, gd);
+      sh_backward<nb>(shl, gsh_local, dx, dy, dz, gr, gd);
       const float dot = dx * gd[0] + dy * gd[1] + dz * gd[2];
       gm[0] += (gd[0] - dx * dot) * inv; gm[1] += (gd[1] - dy * dot) * inv; gm[2] += (gd[2] - dz * dot) * inv;
     }
@@ -466,27 +459,29 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     }
     dL_dmeans2D[3 * (size_t)i] = g.g0.x; dL_dmeans2D[3 * (size_t)i + 1] = g.g0.y; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
     if (dL_dcolors) { dL_dcolors[3 * (size_t)i] = gcol.x; dL_dcolors[3 * (size_t)i + 1] = gcol.y; dL_dcolors[3 * (size_t)i + 2] = gcol.z; }
-    if (gsh) {
-      const int first = (vis && use_shs) ? nb : 0;  // coefficients [0,nb) were written by sh_backward
+    if (dL_dshs) {
+      const bool have = vis && use_shs;  // gsh_local was written by sh_backward
+      bool nz_dc = false, nz_rest = false;
       if (!split) {
-        for (int k = first * 3; k < M * 3; ++k) gsh[k] = 0.f;
-        if (sh_gate && first) {  // benign race: every writer stores the same value
-          bool nz = false;
-          for (int k = 0; k < first * 3; ++k) nz = nz || gsh[k] != 0.f;
-          if (nz) *sh_gate = 1.0f;
-        }
+        float* gdst = dL_dshs + (size_t)i * M * 3;
+#pragma unroll
+        for (int k = 0; k < nb * 3; ++k) { const float v = have ? gsh_local[k] : 0.f; gdst[k] = v; nz_dc = nz_dc || v != 0.f; }
+        for (int k = nb * 3; k < M * 3; ++k) gdst[k] = 0.f;  // bands above the active degree
       } else {
-        // scatter the local gradient to the two parameter tensors; untouched coefficients get explicit zeros
+        // the two parameter tensors of the split storage; untouched coefficients get explicit zeros
         float* gdc = dL_dshs + 3 * (size_t)i;
-        bool nz_dc = false, nz_rest = false;
-        for (int c = 0; c < 3; ++c) { const float v = first ? gsh_local[c] : 0.f; gdc[c] = v; nz_dc = nz_dc || v != 0.f; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float v = have ? gsh_local[c] : 0.f; gdc[c] = v; nz_dc = nz_dc || v != 0.f; }
         if (dL_dshs_rest) {
           float* grest = dL_dshs_rest + (size_t)i * (M - 1) * 3;
-          for (int k = 3; k < M * 3; ++k) { const float v = k < first * 3 ? gsh_local[k] : 0.f; grest[k - 3] = v; nz_rest = nz_rest || v != 0.f; }
+#pragma unroll
+          for (int k = 3; k < nb * 3; ++k) { const float v = have ? gsh_local[k] : 0.f; grest[k - 3] = v; nz_rest = nz_rest || v != 0.f; }
+          for (int k = nb * 3; k < M * 3; ++k) grest[k - 3] = 0.f;  // bands above the active degree
         }
-        if (sh_gate && nz_dc) *sh_gate = 1.0f;
-        if (sh_rest_gate && nz_rest) *sh_rest_gate = 1.0f;
       }
+      // Adam's whole-tensor gate flags (benign race: every writer stores the same value)
+      if (sh_gate && nz_dc) *sh_gate = 1.0f;
+      if (sh_rest_gate && nz_rest) *sh_rest_gate = 1.0f;
     }
     if (dL_dcov3D) {
       const bool on = vis && use_cov_precomp;
@@ -546,14 +541,16 @@ int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const floa
                              const float* rotations, const float* cov3D_precomp, const CamParams& cp, int32_t* radii,
                              GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped) {
   if (P <= 0) return 0;
-  if (g_fused.posed.pose)
-    hipLaunchKernelGGL(k_preprocess_fwd<true>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped,
-                       g_fused.posed, g_fused.prologue);
-  else
-    hipLaunchKernelGGL(k_preprocess_fwd<false>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, GsPosed(),
-                       GsPrologue());
+  const bool posed = g_fused.posed.pose != nullptr;
+  const GsPosed pa = posed ? g_fused.posed : GsPosed();
+  const GsPrologue pro = posed ? g_fused.prologue : GsPrologue();
+#define GS_FWD(POSED, DEG)                                                                                                              \
+  hipLaunchKernelGGL((k_preprocess_fwd<POSED, DEG>), dim3((P + 255) / 256), dim3(256), 0, stream, P, M, means3D, shs, shs_rest,         \
+                     colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, pa, pro)
+  const int deg = shs ? D : 0;  // one instantiation per active SH degree: coefficient arrays stay in registers
+  if (posed) { if (deg == 0) GS_FWD(true, 0); else if (deg == 1) GS_FWD(true, 1); else if (deg == 2) GS_FWD(true, 2); else GS_FWD(true, 3); }
+  else { if (deg == 0) GS_FWD(false, 0); else if (deg == 1) GS_FWD(false, 1); else if (deg == 2) GS_FWD(false, 2); else GS_FWD(false, 3); }
+#undef GS_FWD
   return 0;
 }
 
@@ -564,16 +561,20 @@ int gs_launch_preprocess_bwd(hipStream_t stream, int P, int D, int M, const floa
                              float* dL_dcolors, float* dL_dopac, float* dL_dscales, float* dL_drots, float* dL_dcov3D, float* sh_gate,
                              float* sh_rest_gate) {
   if (P <= 0) return 0;
-  if (g_fused.posed.pose)
-    hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, scales,
-                       rotations, use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
-                       dL_dshs_rest, dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate, sh_rest_gate, g_fused.posed,
-                       g_fused.gate, g_fused.gate_xyz, g_fused.gate_rot, g_fused.gate_scaling, g_fused.gate_opacity);
-  else
-    hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, means3D, shs, shs_rest, scales,
-                       rotations, use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,
-                       dL_dshs_rest, dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate, sh_rest_gate, GsPosed(),
-                       (float*)nullptr, -1, -1, -1, -1);
+  const bool posed = g_fused.posed.pose != nullptr;
+  const GsPosed pa = posed ? g_fused.posed : GsPosed();
+  float* gate = posed ? g_fused.gate : nullptr;
+  const int gi[4] = {posed ? g_fused.gate_xyz : -1, posed ? g_fused.gate_rot : -1, posed ? g_fused.gate_scaling : -1,
+                     posed ? g_fused.gate_opacity : -1};
+#define GS_BWD(POSED, DEG)                                                                                                              \
+  hipLaunchKernelGGL((k_preprocess_bwd<POSED, DEG>), dim3((P + 255) / 256), dim3(256), 0, stream, P, M, means3D, shs, shs_rest, scales, \
+                     rotations, use_shs, use_cov_precomp, cp, radii, recs, cov3Ds, clamped, grads, dL_dmeans3D, dL_dmeans2D, dL_dshs,  \
+                     dL_dshs_rest, dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, sh_gate, sh_rest_gate, pa, gate, gi[0],     \
+                     gi[1], gi[2], gi[3])
+  const int deg = use_shs ? D : 0;
+  if (posed) { if (deg == 0) GS_BWD(true, 0); else if (deg == 1) GS_BWD(true, 1); else if (deg == 2) GS_BWD(true, 2); else GS_BWD(true, 3); }
+  else { if (deg == 0) GS_BWD(false, 0); else if (deg == 1) GS_BWD(false, 1); else if (deg == 2) GS_BWD(false, 2); else GS_BWD(false, 3); }
+#undef GS_BWD
   return 0;
 }
 
