@@ -323,7 +323,8 @@ struct GsPrologue {  // accumulators of one train step, zeroed by the step's fir
 // and no camera-frame intermediates in HBM.
 struct GsPosed {
   const float* pose = nullptr;  // [7] (qw,qx,qy,qz,tx,ty,tz); null = inputs are already in the camera frame
-  float* acc = nullptr;         // backward: 16 pose sums (see pose_math.h), zeroed by the caller
+  float* acc = nullptr;         // backward: 16 pose sums (see pose_math.h), zeroed by the caller ...
+  float* partial = nullptr;     // ... or, if set, one row of 16 per workgroup of the backward projection kernel (no atomics)
 };
 struct GsFusedStepHooks {
   bool skip_memsets = false;

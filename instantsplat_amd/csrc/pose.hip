@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
     d_opacity_logit[i] = r.d_opacity_logit;
     nz_op = nz_op || r.d_opacity_logit != 0.f;
   }
-  pose_accumulate(a, acc, s_red);
+  pose_accumulate(a, acc, nullptr, s_red);
   if (gate) {  // PerPointAdam's whole-tensor gate: any non-zero gradient element (benign same-value store race)
     if (gi_xyz >= 0 && nz_xyz) gate[gi_xyz] = 1.0f;
     if (gi_rot >= 0 && nz_rot) gate[gi_rot] = 1.0f;
@@ -110,11 +110,42 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
   }
 }
 
+__global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __restrict__ pose, const float* __restrict__ partial, int nrows,
+                                                               float* __restrict__ d_pose, float* __restrict__ pose_gate) {
+  __shared__ float s_sum[64][17];
+  __shared__ float s_tot[16];
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;  // 64 row groups x 16 sums; a wave reads 4 consecutive rows (256 B)
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;           // independent loads in flight: this kernel is pure latency
+  int r = g;
+  for (; r + 192 < nrows; r += 256) {
+    v0 += partial[(size_t)r * 16 + k]; v1 += partial[(size_t)(r + 64) * 16 + k];
+    v2 += partial[(size_t)(r + 128) * 16 + k]; v3 += partial[(size_t)(r + 192) * 16 + k];
+  }
+  for (; r < nrows; r += 64) v0 += partial[(size_t)r * 16 + k];
+  s_sum[g][k] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) t += s_sum[q][threadIdx.x];
+    s_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float total[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) total[c] = s_tot[c];
+    pose_finish(pose, total, d_pose, pose_gate);
+  }
+}
+
 }  // namespace
 
-// dL/dpose from the 16 pose sums (internal entry for the one-call train step, whose projection kernels accumulate them)
-int gs_launch_pose_finish(hipStream_t stream, const float* pose, const float* acc, float* d_pose, float* pose_gate) {
-  hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, acc, d_pose, pose_gate);
+// dL/dpose from per-workgroup rows of the 16 pose sums (internal entry for the one-call train step, whose backward
+// projection kernel stores one row per workgroup instead of issuing atomics): deterministic tree sum, then pose_finish
+int gs_launch_pose_finish_partials(hipStream_t stream, const float* pose, const float* partial, int nrows, float* d_pose,
+                                   float* pose_gate) {
+  hipLaunchKernelGGL(k_pose_finish_partials, dim3(1), dim3(1024), 0, stream, pose, partial, nrows, d_pose, pose_gate);
   return 0;
 }
 

@@ -81,8 +81,11 @@ __device__ __forceinline__ PoseGradOut pose_backward_one(const PoseMat& m, float
   return r;
 }
 
-// 256-thread workgroup: sum the 16 accumulators over the workgroup and add them to acc[16] (device float atomics)
-__device__ __forceinline__ void pose_accumulate(float (&a)[16], float* __restrict__ acc, float (*s_red)[16] /*[4][16]*/) {
+// 256-thread workgroup: sum the 16 accumulators over the workgroup, then either add them to acc[16] with device float
+// atomics, or (partial != null) store them as this workgroup's row of partial[gridDim.x][16] for a later reduction — hundreds
+// of workgroups adding to the same 16 addresses serialise at the memory side (that was most of this stage's time).
+__device__ __forceinline__ void pose_accumulate(float (&a)[16], float* __restrict__ acc, float* __restrict__ partial,
+                                                float (*s_red)[16] /*[4][16]*/) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -92,6 +95,8 @@ __device__ __forceinline__ void pose_accumulate(float (&a)[16], float* __restric
   __syncthreads();
   if (threadIdx.x < 16) {
     const int k = threadIdx.x;
-    atomicAdd(&acc[k], (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]));
+    const float v = (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]);
+    if (partial) partial[(size_t)blockIdx.x * 16 + k] = v;
+    else atomicAdd(&acc[k], v);
   }
 }

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       dL_dopac[i] = r.d_opacity_logit;
       nz_op = nz_op || r.d_opacity_logit != 0.f;
     }
-    pose_accumulate(a, posed.acc, s_red);
+    pose_accumulate(a, posed.acc, posed.partial, s_red);
     if (gate) {  // PerPointAdam's whole-tensor gate: any non-zero gradient element (benign same-value store race)
       if (gi_xyz >= 0 && nz_xyz) gate[gi_xyz] = 1.0f;
       if (gi_rot >= 0 && nz_rot) gate[gi_rot] = 1.0f;

@@ -16,7 +16,7 @@
 #include "common.h"
 
 int gs_loss_forward(hipStream_t, int, int, int, const float*, const float*, float*, float*, float*, void*);
-int gs_launch_pose_finish(hipStream_t, const float*, const float*, float*, float*);
+int gs_launch_pose_finish_partials(hipStream_t, const float*, const float*, int, float*, float*);
 int gs_loss_backward(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, float, float*,
                      const void*, float*);
 
@@ -36,7 +36,7 @@ struct Trainer {
   int32_t* radii;
   float *g_means2D, *g_colors;
   float *g_xyz, *g_rot, *g_scaling, *g_opacity, *g_fdc, *g_frest, *g_poses;
-  float *pose_scratch, *adam_scratch, *consts;  // consts: identity view [16], campos [3]
+  float *pose_scratch, *pose_partial, *adam_scratch, *consts;  // consts: identity view [16], campos [3]
   bool consts_ready;
 };
 
@@ -64,7 +64,7 @@ size_t carve(Trainer& t, void* workspace) {
   t.g_means2D = c.take<float>(3 * P); t.g_colors = c.take<float>(3 * P);
   t.g_xyz = c.take<float>(3 * P); t.g_rot = c.take<float>(4 * P); t.g_scaling = c.take<float>(3 * P); t.g_opacity = c.take<float>(P);
   t.g_fdc = c.take<float>(3 * P); t.g_frest = c.take<float>(45 * P); t.g_poses = c.take<float>(7 * (size_t)t.V);
-  t.pose_scratch = c.take<float>(32); t.adam_scratch = c.take<float>(8); t.consts = c.take<float>(32);
+  t.pose_scratch = c.take<float>(32); t.pose_partial = c.take<float>(16 * ((P + 255) / 256)); t.adam_scratch = c.take<float>(8); t.consts = c.take<float>(32);
   return c.off;
 }
 
@@ -156,7 +156,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     pro.g_poses = t->g_poses; pro.n_pose = 7 * t->V; pro.pose_scratch = t->pose_scratch; pro.adam_scratch = t->adam_scratch;
   }
   GsPosed posed;
-  posed.pose = t->poses + 7 * (size_t)view; posed.acc = t->pose_scratch;
+  posed.pose = t->poses + 7 * (size_t)view; posed.acc = t->pose_scratch; posed.partial = t->pose_partial;
   HookScope hook_scope(t->adam_scratch, pro, posed);
   const float* view_m = t->consts;
   const float* campos = t->consts + 16;
@@ -183,7 +183,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
                                     t->capacity, t->radii, t->image, t->dL_dimg, t->grad_scratch, t->g_xyz, t->g_means2D, t->g_fdc,
                                     g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0)))
     return rc;
-  gs_launch_pose_finish(stream, pose, t->pose_scratch, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6);
+  gs_launch_pose_finish_partials(stream, pose, t->pose_partial, (P + 255) / 256, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6);
   GS_CHECK_LAUNCH("pose_finish");
   // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
   if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps);
