@@ -62,3 +62,31 @@ def test_image_is_linear_in_precomputed_colours(gpu):
         b = r(means2D=z, colors_precomp=c2, **t)[0]
         c = r(means2D=z, colors_precomp=c1 + c2, **t)[0]
     assert float((c - (a + b)).abs().max()) <= 2e-5
+
+
+def test_largest_config_1M_gaussians_1080p(gpu):
+    """BASELINE config C4 (1 M Gaussians, 1920x1080, ~7 M instances): forward run-to-run identical, backward linear in
+    dL/dpixel and finite — the same size-independent properties, at the largest size the reference quotes."""
+    Pn, Wn, Hn = 1000000, 1920, 1080
+    sc = syn_blob(Pn, Wn, Hn, seed=3)
+    st = settings_for(sc.camera, 0, GaussianRasterizationSettings, sc.bg, device=gpu)
+    t = dict(means3D=sc.means3D.to(gpu), opacities=torch.sigmoid(sc.opacity_logit).to(gpu), scales=torch.exp(sc.scaling_logit).to(gpu),
+             rotations=sc.rotation.to(gpu))
+    r = GaussianRasterizer(st)
+    z = torch.zeros(Pn, 3, device=gpu)
+    with torch.no_grad():
+        a, ra = r(means2D=z, shs=sc.shs.to(gpu), **t)
+        b, rb = r(means2D=z, shs=sc.shs.to(gpu), **t)
+    assert torch.equal(a, b) and torch.equal(ra, rb)
+    assert int((ra > 0).sum()) > Pn // 2
+    leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    img, _ = r(means2D=z, shs=sc.shs.to(gpu), **leaves)
+    g = torch.Generator().manual_seed(9)
+    g1 = torch.randn(3, Hn, Wn, generator=g).to(gpu)
+    tens = list(leaves.values())
+    ga = torch.autograd.grad(img, tens, g1, retain_graph=True)
+    gb = torch.autograd.grad(img, tens, -0.5 * g1)
+    for n, x, y in zip(leaves, ga, gb):
+        assert bool(torch.isfinite(x).all()), n
+        ref = -0.5 * x
+        assert float((y - ref).norm() / (ref.norm() + 1e-30)) <= 1e-4, n
