@@ -136,11 +136,12 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
           // a skipped Gaussian is a transparent one; a finished pixel carries Tr == 0, so `stop` (and nothing else)
           // also covers "already done" and no separate flag is tested here
           const float al = (power2 <= 0.0f && alpha >= ALPHA_MIN) ? alpha : 0.0f;
-          const float test_T = Tr * (1.0f - al);
+          const float w0 = al * Tr;
+          const float test_T = Tr - w0;  // T (1 - alpha)
           const bool stop = test_T < T_MIN;
-          const float w = stop ? 0.0f : al * Tr;
+          const float w = stop ? 0.0f : w0;
           C0 += a2.x * w; C1 += a2.y * w; C2 += a2.z * w;
-          last = (al > 0.0f && !stop) ? (base - start) + (uint32_t)i2 + 1u : last;
+          last = (w > 0.0f) ? (base - start) + (uint32_t)i2 + 1u : last;  // blended: alpha > 0 and not the stopping one
           Tfin = stop ? Tfin : test_T;
           Tr = stop ? 0.0f : test_T;
         };
