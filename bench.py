@@ -233,8 +233,10 @@ def main():
             "roofline": {"kernel": "k_composite_bwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": bwd_ms, "launches": bwd_n,
                          "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs), "valu": valu,
-                         "note": "VALU-issue-bound in practice (SURVEY.md 8d): HBM fraction is reported as the contract asks; "
-                                 "see DESIGN.md for the instruction-count roofline",
+                         "note": "VALU-issue-bound (SURVEY.md 8d; valu.simd_issue_busy_frac): the HBM fraction is reported as the contract "
+                                 "asks, DESIGN.md 4.2 has the instruction-count roofline.  traffic > algorithmic bytes is deliberate: "
+                                 "the backward runs in 64-instance segment units (DESIGN.md 4.2b) that re-read a 16 B/pixel boundary record "
+                                 "and 32 B/pixel of pixel state per unit, L2 / Infinity-Cache resident",
                          "composite_fwd": {"avg_kernel_ms": fwd_ms, "launches": fwd_n, "algorithmic_bytes_per_launch": fwd_bytes,
                                            "achieved": fwd_bytes / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0}},
             "cpu_baseline": cpu_baseline,
