@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/mi355gs.h"
+#include <type_traits>
 
 #define GS_LOG2E 1.4426950408889634f
 #define GS_TILE 16
@@ -91,7 +92,6 @@ struct TilesLayout {
 // segments independently: thousands of equal-sized workgroups that the hardware balances, instead of one workgroup per
 // tile that lasts as long as the tile is deep (composite.hip).
 constexpr int GS_SEG = 64;
-constexpr int GS_UNIT_TILE_BITS = 20;  // unit table entry = tile | segment << 20
 
 struct BinningLayout {
   size_t keys, list, unit_tile, bstate, total;
@@ -101,7 +101,7 @@ struct BinningLayout {
     keys = o; o += gs_align(n * 8);
     list = o; o += gs_align(n * 4);
     max_units = (uint32_t)((n + GS_SEG - 1) / GS_SEG + (size_t)(T > 0 ? T : 1));
-    unit_tile = o; o += gs_align((size_t)max_units * 4);
+    unit_tile = o; o += gs_align((size_t)max_units * 8);  // uint2 per unit: (tile x | tile y << 16, segment)
     bstate = o; o += gs_align((size_t)max_units * 256 * sizeof(float4));  // per boundary: 256 pixels x (T, C0, C1, C2)
     total = o;
   }
@@ -161,6 +161,19 @@ typedef float gs_v2f __attribute__((vector_size(8)));
 __device__ __forceinline__ float gs_opaque(float v) {
   asm volatile("" : "+v"(v));
   return v;
+}
+
+// wave64 maximum, in every lane: four DPP steps inside the rows, then the two row swaps (no LDS crossbar)
+__device__ __forceinline__ uint32_t gs_wave_max_u32(uint32_t v) {
+  auto dpp = [](uint32_t x, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, 0xF, 0xF, true); };
+  v = max(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+  v = max(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+  v = max(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  v = max(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = max(a[0], a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return max(b[0], b[1]);
 }
 
 // Transposed pair step of a multi-value wave reduction: lanes whose `bit` is clear keep `a`, the others keep

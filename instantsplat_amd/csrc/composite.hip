@@ -22,9 +22,8 @@ struct Quad {
   bool inside;
 };
 
-__device__ __forceinline__ Quad make_quad(int tile, int gx, int W, int H) {
+__device__ __forceinline__ Quad make_quad_xy(int tx, int ty, int W, int H) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tx = tile % gx, ty = tile / gx;
   const int bx = tx * GS_TILE + (wave & 1) * 8, by = ty * GS_TILE + (wave >> 1) * 8;
   Quad q;
   q.px = bx + (lane & 7);
@@ -34,6 +33,7 @@ __device__ __forceinline__ Quad make_quad(int tile, int gx, int W, int H) {
   q.inside = q.px < W && q.py < H;
   return q;
 }
+__device__ __forceinline__ Quad make_quad(int tile, int gx, int W, int H) { return make_quad_xy(tile % gx, tile / gx, W, H); }
 
 __device__ __forceinline__ bool box_hit(const float4& q0, const Quad& q) {
   return (q0.x + q0.z >= q.x0) && (q0.x - q0.z <= q.x1) && (q0.y + q0.w >= q.y0) && (q0.y - q0.w <= q.y1);
@@ -83,7 +83,7 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
                                                    const GsRec* __restrict__ recs, const float* __restrict__ bg,
                                                    float* __restrict__ out_color, float* __restrict__ final_T,
                                                    uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_first,
-                                                   uint32_t* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
+                                                   uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
   __shared__ float4 s_q0[BATCH];
   __shared__ float4 s_q1[BATCH];
   __shared__ float4 s_q2[BATCH];
@@ -95,7 +95,8 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
   // (transmittance after the last blended Gaussian, accumulated colour) at each segment boundary for the backward.
   const uint32_t seg0 = seg_first[tile], nseg = seg_first[tile + 1] - seg0;
   for (uint32_t sg = tid; sg < nseg; sg += 256)
-    if (seg0 + sg < max_units) unit_tile[seg0 + sg] = (uint32_t)tile | (sg << GS_UNIT_TILE_BITS);
+    if (seg0 + sg < max_units)  // (tile x | tile y << 16, segment): the backward needs no division to place itself
+      unit_tile[seg0 + sg] = make_uint2((uint32_t)(tile % gx) | ((uint32_t)(tile / gx) << 16), sg);
   uint32_t next_boundary = 0;  // boundaries [0, next_boundary) of this tile have been stored by this wave
 
   // Tr: live transmittance, forced to 0 once the pixel is finished (T < 1e-4 reached, or outside the image);
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
                                                         float* __restrict__ out_color, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order,
                                                         GsSched* sched, int NB, const uint32_t* __restrict__ seg_first,
-                                                        uint32_t* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
+                                                        uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
   GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
                           composite_fwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T, n_contrib,
                                              seg_first, unit_tile, bstate, max_units))
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
                                                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
                                                         const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
-                                                        const uint32_t* __restrict__ unit_tile, const float4* __restrict__ bstate,
+                                                        const uint2* __restrict__ unit_tile, const float4* __restrict__ bstate,
                                                         const uint32_t* __restrict__ meta, uint32_t max_units) {
   constexpr int BATCH = GS_SEG;
   __shared__ float4 s_q0[BATCH];
@@ -220,11 +221,12 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
   __shared__ uint32_t s_max[4];
   const uint32_t unit = blockIdx.x;
   if (unit >= min(meta[1], max_units)) return;
-  const uint32_t entry = unit_tile[unit];
-  const int tile = (int)(entry & ((1u << GS_UNIT_TILE_BITS) - 1u));
-  const uint32_t seg = entry >> GS_UNIT_TILE_BITS;
+  const uint2 entry = unit_tile[unit];
+  const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
+  const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
+  const int tile = ty * gx + tx;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const Quad q = make_quad(tile, gx, W, H);
+  const Quad q = make_quad_xy(tx, ty, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t boff = seg * GS_SEG;  // contributor index (0-based) of this unit's first instance
   if (end <= start + boff) return;
@@ -238,9 +240,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
   const gs_v2f g01 = {g0, g1};
 
   // the tile only needs instances [0, max over pixels of last)
-  uint32_t wmax = last;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m));
+  const uint32_t wmax = gs_wave_max_u32(last);
   if (lane == 0) s_max[wave] = wmax;
   __syncthreads();
   const uint32_t tile_max = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), end - start);
@@ -390,7 +390,7 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
 
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
-                            uint32_t* n_contrib, const uint32_t* order, GsSched* sched, const uint32_t* seg_first, uint32_t* unit_tile,
+                            uint32_t* n_contrib, const uint32_t* order, GsSched* sched, const uint32_t* seg_first, uint2* unit_tile,
                             float4* bstate, uint32_t max_units) {
   const int NB = gs_num_cus();
   hipLaunchKernelGGL(k_composite_fwd, dim3(gs_grid_persistent(T, NB)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
@@ -402,7 +402,7 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
 int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
-                            const uint32_t* seg_first, const uint32_t* unit_tile, const float4* bstate, const uint32_t* meta,
+                            const uint32_t* seg_first, const uint2* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units) {
   hipLaunchKernelGGL(k_composite_bwd, dim3(max_units), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,
                      n_contrib, dL_dpix, grads, out_color, seg_first, unit_tile, bstate, meta, max_units);
