@@ -439,66 +439,99 @@ __device__ __forceinline__ void sort_merge_from(uint64_t (&k)[E], uint64_t* __re
   }
 }
 
+// keys_out == null: the sorted Gaussian indices go to list[s ...]; otherwise the sorted KEYS go to keys_out[s ...]
+// (one sorted run of a tile too long for the workgroup's registers, see sort_long_tile)
 template <int E>
-__device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
-                                               uint32_t s, int n) {
+__device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, const uint64_t* keys, uint32_t* __restrict__ list,
+                                               uint32_t s, int n, uint64_t* keys_out = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int base = wave * (64 * E) + lane * E;
   uint64_t k[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) k[e] = (base + e < n) ? keys[s + base + e] : ~0ull;
   sort_merge_from<E, 2, SORT_THREADS * E>(k, s_keys, base);
+  if (keys_out) {
 #pragma unroll
-  for (int e = 0; e < E; ++e)
-    if (base + e < n) list[s + base + e] = (uint32_t)k[e];
+    for (int e = 0; e < E; ++e)
+      if (base + e < n) keys_out[s + base + e] = k[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (base + e < n) list[s + base + e] = (uint32_t)k[e];
+  }
 }
 
-// Two launches per frame: the small-tile kernel keeps its register and LDS footprint low so 8 workgroups fit a CU
-// (a single kernel with the 32-keys-per-thread path compiled in needs 134 VGPRs and ran one workgroup per CU);
-// the large-tile kernel exits at once for every tile the small one handled.
-__device__ __forceinline__ void sort_small_tile(int tile, const uint32_t* __restrict__ start, const uint64_t* __restrict__ keys,
-                                                uint32_t* __restrict__ list, uint32_t capacity) {
+// Tiles longer than SORT_SMALL_CAP (rare: the C3 maximum is under 1100): sort runs of SORT_SMALL_CAP keys with the register
+// network (keys rewritten in place), then place every key by RANK — its index in its own run plus, for every other run staged
+// in LDS, the number of keys below it (keys are distinct, so the ranks are a permutation).  Same registers and LDS as the
+// short-tile path, so the kernel keeps its occupancy and no second kernel is launched for the long tiles.
+__device__ __forceinline__ void sort_long_tile(uint64_t* __restrict__ s_keys, uint64_t* keys, uint32_t* __restrict__ list, uint32_t s, int n) {
+  constexpr int RUN = SORT_SMALL_CAP, E = RUN / SORT_THREADS;
+  const int nrun = (n + RUN - 1) / RUN, tid = threadIdx.x;
+  for (int r = 0; r < nrun; ++r) {
+    __syncthreads();  // the previous run's LDS stages are done
+    sort_tile_regs<E>(s_keys, keys, list, s + (uint32_t)r * RUN, min(RUN, n - r * RUN), keys);
+  }
+  for (int r = 0; r < nrun; ++r) {
+    const int rn = min(RUN, n - r * RUN);
+    uint64_t k[E];
+    uint32_t rank[E];
+    __syncthreads();  // this workgroup's sorted runs are in global memory (visible to the workgroup after the barrier)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = tid * E + e;
+      k[e] = i < rn ? keys[s + (uint32_t)r * RUN + i] : ~0ull;
+      rank[e] = (uint32_t)i;  // position inside the own (sorted) run; the other runs' contributions are added below
+    }
+    for (int r2 = 0; r2 < nrun; ++r2) {
+      if (r2 == r) continue;
+      const int n2 = min(RUN, n - r2 * RUN);
+      __syncthreads();
+      for (int i = tid; i < n2; i += SORT_THREADS) s_keys[i] = keys[s + (uint32_t)r2 * RUN + i];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        int lo = 0, hi = n2;  // number of keys of run r2 below k[e]
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_keys[mid] < k[e]) lo = mid + 1; else hi = mid;
+        }
+        rank[e] += (uint32_t)lo;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (tid * E + e < rn) list[s + rank[e]] = (uint32_t)k[e];
+  }
+}
+
+// One kernel for every tile length: the register network up to SORT_SMALL_CAP keys, sorted runs + rank placement up to
+// SORT_LDS_CAP (sort_long_tile), the in-place global-memory network beyond.  (A second kernel with 16/32 keys per thread
+// for the long tiles cost a 4.6 us launch per frame that almost never had anything to do.)
+__device__ __forceinline__ void sort_one_tile(int tile, const uint32_t* __restrict__ start, uint64_t* keys,
+                                              uint32_t* __restrict__ list, uint32_t capacity) {
   __shared__ uint64_t s_keys[SORT_SMALL_CAP];
-  if (start[tile + 1] - start[tile] > (uint32_t)SORT_SMALL_CAP) return;  // the large-tile kernel's (same test there)
   const uint32_t s = min(start[tile], capacity), e = min(start[tile + 1], capacity);
   const int n = (int)(e - s);
   if (n <= 0) return;
   if (n <= SORT_THREADS) sort_tile_regs<1>(s_keys, keys, list, s, n);
   else if (n <= SORT_THREADS * 2) sort_tile_regs<2>(s_keys, keys, list, s, n);
   else if (n <= SORT_THREADS * 4) sort_tile_regs<4>(s_keys, keys, list, s, n);
-  else sort_tile_regs<8>(s_keys, keys, list, s, n);
+  else if (n <= SORT_SMALL_CAP) sort_tile_regs<8>(s_keys, keys, list, s, n);
+  else if (n <= SORT_LDS_CAP) sort_long_tile(s_keys, keys, list, s, n);
+  else {
+    uint64_t* seg = keys + s;
+    bitonic_sort_any(seg, n, (int)threadIdx.x, SORT_THREADS);
+    for (int i = threadIdx.x; i < n; i += SORT_THREADS) list[s + i] = (uint32_t)seg[i];
+  }
 }
 
 // One workgroup per tile, heaviest tiles first (order[] from k_scan_tiles).  No persistent scheduling here: a tile's sort is
 // short and latency-bound, so the ~9 us of scheduler round trips cost more than CU balance gains (22 vs 13 us on C3).
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_small(int T, const uint32_t* __restrict__ start,
-                                                                    const uint64_t* __restrict__ keys, uint32_t* __restrict__ list,
-                                                                    uint32_t capacity, const uint32_t* __restrict__ order) {
-  sort_small_tile((int)order[blockIdx.x], start, keys, list, capacity);
-}
-
-// the tiles with more than SORT_SMALL_CAP instances are the first meta[0] entries of order[] (usually none)
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles_large(int T, const uint32_t* __restrict__ start, uint64_t* __restrict__ keys,
-                                                                    uint32_t* __restrict__ list, uint32_t capacity,
-                                                                    const uint32_t* __restrict__ order, const uint32_t* __restrict__ meta) {
-  __shared__ uint64_t s_keys[SORT_LDS_CAP];
-  const int n_large = (int)min(meta[0], (uint32_t)T);
-  const int tid = threadIdx.x;
-  for (int idx = blockIdx.x; idx < n_large; idx += gridDim.x) {
-    const int tile = (int)order[idx];
-    const uint32_t s = min(start[tile], capacity), e = min(start[tile + 1], capacity);
-    const int n = (int)(e - s);
-    if (n > 0) {
-      if (n <= SORT_THREADS * 16) sort_tile_regs<16>(s_keys, keys, list, s, n);
-      else if (n <= SORT_THREADS * 32) sort_tile_regs<32>(s_keys, keys, list, s, n);
-      else {
-        uint64_t* seg = keys + s;
-        bitonic_sort_any(seg, n, tid, SORT_THREADS);
-        for (int i = tid; i < n; i += SORT_THREADS) list[s + i] = (uint32_t)seg[i];
-      }
-    }
-    __syncthreads();
-  }
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles(int T, const uint32_t* __restrict__ start, uint64_t* keys,
+                                                              uint32_t* __restrict__ list, uint32_t capacity,
+                                                              const uint32_t* __restrict__ order) {
+  sort_one_tile((int)order[blockIdx.x], start, keys, list, capacity);
 }
 
 }  // namespace
@@ -538,8 +571,7 @@ int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const GsRec* rec
                        start, cursor, keys, capacity);
   else
     hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, recs, rects, start, cursor, keys, capacity);
-  const int NB = gs_num_cus();
-  hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(SORT_THREADS), 0, stream, T, start, (const uint64_t*)keys, list, capacity, order);
-  hipLaunchKernelGGL(k_sort_tiles_large, dim3(T < NB ? T : NB), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order, meta);
+  (void)meta;
+  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order);
   return 0;
 }

@@ -104,3 +104,76 @@ def check_create_from_pcd_scales(dev):
     assert torch.allclose(gm._scaling.detach().cpu(), ref, rtol=1e-5, atol=1e-6)
     assert gm._features_dc.shape == (500, 1, 3) and gm._features_rest.shape == (500, 15, 3)
     assert torch.allclose(gm.get_opacity.detach().cpu(), torch.full((500, 1), 0.1), atol=1e-6)
+
+
+def check_long_tile_lists(dev, n):
+    """n faint Gaussians stacked on a few tiles: per-tile lists longer than the sort kernel's register network (2048 keys:
+    sorted runs + rank placement) and, for n > 8192, than its LDS window (in-place global network); also dozens of backward
+    segments per tile.  Everything still has to match the oracle."""
+    g = torch.Generator().manual_seed(11)
+    z = 2.0 + 4.0 * torch.rand(n, generator=g)
+    means = torch.stack([0.12 * (2 * torch.rand(n, generator=g) - 1) * z, 0.12 * (2 * torch.rand(n, generator=g) - 1) * z, z], dim=1)
+    q = torch.randn(n, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    scales = 0.01 + 0.02 * torch.rand(n, 3, generator=g)
+    opac = torch.full((n, 1), 0.01) + 0.02 * torch.rand(n, 1, generator=g)   # faint: nothing saturates, every instance counts
+    col = torch.rand(n, 3, generator=g)
+    out = run_custom_case(dev, means, scales, q, opac, col, 48, 32)
+    # Thousands of fp32 additions per pixel in a different order than the oracle, and alphas of 0.00-0.03 around the 1/255
+    # cut: a (pixel, Gaussian) pair whose alpha rounds to the other side of the threshold moves that pixel by ~4e-4 and
+    # the gradients by ~1e-3 (seen for n = 12000: one such pair).  Ordering itself is checked exactly by
+    # check_tile_lists_sorted.
+    assert_raster_parity(dict(ref=out["ref"], dut=out["dut"]), fwd_tol=5e-4, grad_tol=3e-3)
+
+
+def check_tile_lists_sorted(dev, n):
+    """Exact property of the binning stage, straight through the C ABI: every per-tile list is a duplicate-free set of
+    Gaussian indices in ascending (depth bits, index) order — for list lengths on both sides of the sort kernel's
+    2048-key register network and 8192-key rank-placement window."""
+    from instantsplat_amd import _lib
+    from instantsplat_amd.camera import Camera
+    import numpy as np
+    dev = torch.device(dev)
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    z = 2.0 + 4.0 * torch.rand(n, generator=g)
+    z[: n // 50] = z[n // 50: 2 * (n // 50)]   # exact depth ties: the index has to break them
+    means = torch.stack([0.12 * (2 * torch.rand(n, generator=g) - 1) * z, 0.12 * (2 * torch.rand(n, generator=g) - 1) * z, z], dim=1)
+    q = torch.randn(n, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    scales = 0.01 + 0.02 * torch.rand(n, 3, generator=g)
+    opac = (torch.full((n, 1), 0.02) + 0.02 * torch.rand(n, 1, generator=g)).reshape(-1)
+    col = torch.rand(n, 3, generator=g)
+    W, H = 48, 32
+    tanx = math.tan(math.radians(60) / 2)
+    tany = tanx * H / W
+    cam = Camera(0, torch.eye(4), math.radians(60), 2 * math.atan(tany), W, H)
+    t = lambda x: x.float().contiguous().to(dev)
+    means, q, scales, opac, col = map(t, (means, q, scales, opac, col))
+    view, proj, campos = t(torch.eye(4).reshape(-1)), t(cam.projection_matrix.reshape(-1)), t(torch.zeros(3))
+    geom = torch.zeros(L.mi355gs_raster_geom_bytes(n), dtype=torch.uint8, device=dev)
+    tiles = torch.zeros(L.mi355gs_raster_tiles_bytes(W, H), dtype=torch.uint8, device=dev)
+    radii = torch.zeros(n, dtype=torch.int32, device=dev)
+    nr = torch.zeros(1, dtype=torch.int32, device=dev)
+    p, stream = _lib.ptr, _lib.stream_ptr(dev)
+    _lib.check(L.mi355gs_raster_forward_preprocess(stream, n, 0, 0, W, H, p(means), None, None, p(col), p(opac), p(scales), 1.0, p(q), None,
+                                                   p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles), p(nr), 0), "preprocess")
+    R = int(nr.item())
+    binning = torch.zeros(L.mi355gs_raster_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+    img, bg = torch.zeros(3, H, W, device=dev), torch.zeros(3, device=dev)
+    _lib.check(L.mi355gs_raster_forward_render(stream, n, W, H, R, p(bg), p(geom), p(tiles), p(binning), p(img), 0), "render")
+    T, al = 6, (lambda x: (x + 255) & ~255)
+    # scratch layouts (csrc/common.h): tiles = count | cursor | start[T+1] ...; binning = keys[R] (8 B) | list[R] (4 B) ...
+    start = tiles[2 * al(T * 4): 2 * al(T * 4) + (T + 1) * 4].cpu().view(torch.int32).numpy()
+    lst = binning[al(R * 8): al(R * 8) + R * 4].cpu().view(torch.int32).numpy()
+    depth = geom[: n * 48].cpu().view(torch.float32).reshape(n, 12).numpy()[:, 11]
+    assert start[0] == 0 and start[T] == R and R > 0
+    longest = 0
+    for tile in range(T):
+        seg = lst[start[tile]:start[tile + 1]]
+        longest = max(longest, len(seg))
+        assert len(np.unique(seg)) == len(seg), tile
+        key = (depth[seg].view(np.uint32).astype(np.uint64) << np.uint64(32)) | seg.astype(np.uint64)
+        assert bool((key[1:] > key[:-1]).all()), (tile, len(seg))
+    return longest
+

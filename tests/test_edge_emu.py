@@ -1,4 +1,6 @@
 """CPU tier: edge cases on the emulated kernels."""
+import pytest
+
 from tests import edge_cases
 
 
@@ -24,3 +26,13 @@ def test_python_flag_paths(emu):
 
 def test_create_from_pcd_scales(emu):
     edge_cases.check_create_from_pcd_scales(emu)
+
+
+@pytest.mark.parametrize("n", [2500, 8500, 12000])
+def test_long_tile_lists(emu, n):
+    edge_cases.check_long_tile_lists(emu, n)
+
+
+@pytest.mark.parametrize("n,longer_than", [(600, 0), (3000, 2048), (12000, 8192)])
+def test_tile_lists_sorted(emu, n, longer_than):
+    assert edge_cases.check_tile_lists_sorted(emu, n) > longer_than

@@ -27,3 +27,13 @@ def test_python_flag_paths(gpu):
 
 def test_create_from_pcd_scales(gpu):
     edge_cases.check_create_from_pcd_scales(gpu)
+
+
+@pytest.mark.parametrize("n", [2500, 9000, 20000])
+def test_long_tile_lists(gpu, n):
+    edge_cases.check_long_tile_lists(gpu, n)
+
+
+@pytest.mark.parametrize("n,longer_than", [(600, 0), (3000, 2048), (12000, 8192), (40000, 8192)])
+def test_tile_lists_sorted(gpu, n, longer_than):
+    assert edge_cases.check_tile_lists_sorted(gpu, n) > longer_than
