@@ -13,7 +13,7 @@ int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const flo
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
 int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, GsSched*, uint32_t*, uint32_t*);
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t,
-                      const uint32_t*, const uint32_t*);
+                      const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             float*, float*, uint32_t*, const uint32_t*, GsSched*, const uint32_t*, uint2*, float4*, uint32_t);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
@@ -147,7 +147,7 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
   char* b = (char*)binning;
   gs_launch_binning(stream, P, tl.T, tl.gx, (const GsRec*)(g + gl.rec), (const uint2*)(g + gl.rect),
                     (const uint32_t*)(t + tl.start), (uint32_t*)(t + tl.cursor), (uint64_t*)(b + bl.keys),
-                    (uint32_t*)(b + bl.list), cap, (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.meta));
+                    (uint32_t*)(b + bl.list), cap, (const uint32_t*)(t + tl.order));
   GS_CHECK_LAUNCH("binning");
   {
     ProfScope prof(0, stream);

@@ -66,14 +66,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     if (lane == 0) atomicMax(&s_max, mx);
     __syncthreads();
     const uint32_t cmax = max(s_max, 1u);
-    // buckets 0..511: tiles for the large-tile sort kernel (count > SORT_SMALL_CAP), 512..1023: the others — so the
-    // large tiles are exactly the first meta[0] entries of order[]
-    constexpr uint32_t HALF = SCAN_THREADS / 2;
-    auto bucket = [&](uint32_t c) {
-      if (c > (uint32_t)SORT_SMALL_CAP)
-        return (HALF - 1) - (uint32_t)(((uint64_t)(c - SORT_SMALL_CAP - 1) * (HALF - 1)) / max(cmax - SORT_SMALL_CAP - 1, 1u));
-      return (SCAN_THREADS - 1) - (uint32_t)(((uint64_t)c * (HALF - 1)) / min(cmax, (uint32_t)SORT_SMALL_CAP));
-    };
+    auto bucket = [&](uint32_t c) { return (uint32_t)(SCAN_THREADS - 1) - (uint32_t)(((uint64_t)c * (SCAN_THREADS - 1)) / cmax); };
     for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(count[i])], 1u);
     __syncthreads();
     // exclusive scan of the 1024 bucket sizes (one per thread)
@@ -92,7 +85,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w)
       if (w < wave) hoff += hist_wave[w];
     hist[tid] = hoff + hi_ - h;
-    if (tid == (int)HALF) meta[0] = hoff + hi_ - h;  // tiles in buckets [0, HALF)
     __syncthreads();
     for (int i = lo; i < hi; ++i) order[atomicAdd(&hist[bucket(count[i])], 1u)] = (uint32_t)i;
     __syncthreads();
@@ -563,15 +555,13 @@ int gs_launch_count_tiles(hipStream_t stream, int P, int T, int gx, const uint2*
 }
 
 int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const GsRec* recs, const uint2* rects, const uint32_t* start,
-                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity, const uint32_t* order,
-                      const uint32_t* meta) {
+                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity, const uint32_t* order) {
   if (P <= 0 || capacity == 0) return 0;
   if (T <= BIN_MAX_LDS_TILES)
     hipLaunchKernelGGL(k_scatter_lds, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), (size_t)T * 4, stream, P, T, gx, recs, rects,
                        start, cursor, keys, capacity);
   else
     hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, recs, rects, start, cursor, keys, capacity);
-  (void)meta;
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order);
   return 0;
 }

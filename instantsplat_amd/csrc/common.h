@@ -66,7 +66,7 @@ struct GsSched {
   uint32_t done, pad_b[15];
 };
 enum { GS_SCHED_FWD = 0, GS_SCHED_COUNT = 1 };
-constexpr int GS_SORT_SMALL_CAP = 2048;  // tiles above this many instances are sorted by the large-tile kernel; k_scan_tiles puts them first in `order`
+constexpr int GS_SORT_SMALL_CAP = 2048;  // keys the tile sort's register network takes in one go (binning.hip)
 
 struct TilesLayout {
   size_t count, start, cursor, final_T, n_contrib, order, seg_first, sched, meta, total;
@@ -82,7 +82,7 @@ struct TilesLayout {
     order = o; o += gs_align((size_t)T * 4);
     seg_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of ceil(count / GS_SEG): first unit of a tile
     sched = o; o += gs_align(GS_SCHED_COUNT * sizeof(GsSched));
-    meta = o; o += gs_align(16);   // [0]: number of tiles with more than GS_SORT_SMALL_CAP instances, [1]: number of units
+    meta = o; o += gs_align(16);   // [1]: number of backward units of the frame
     total = o;
   }
 };
