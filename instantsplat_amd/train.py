@@ -229,9 +229,12 @@ class FusedTrainer:
         self.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def close(self):
-        if getattr(self, "handle", None) and _lib is not None:
-            _lib.lib().mi355gs_trainer_destroy(ctypes.c_void_p(self.handle))
-            self.handle = None
+        handle, self.handle = getattr(self, "handle", None), None
+        if handle:
+            try:
+                _lib.lib().mi355gs_trainer_destroy(ctypes.c_void_p(handle))
+            except Exception:  # interpreter shutdown: module globals may already be gone (the handle is host memory only)
+                pass
 
     def gradients(self) -> dict:
         """Copies of the gradients the last `step` left in the workspace, keyed like the GaussianModel attributes
