@@ -3,7 +3,7 @@
 // reference's own fallback utils/loss_utils.py:55-85 (11-tap Gaussian, sigma 1.5, zero "same"
 // padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements).  L1 is reference utils/loss_utils.py:39-40.
 //
-// One workgroup = one 16x16 output tile of one (batch, channel) plane.  The 26x26 input halo of both
+// One workgroup = one 32x16 output tile of one (batch, channel) plane.  The 42x26 input halo of both
 // images is staged in LDS once; the 11x11 window is applied separably (row pass into LDS, column
 // pass in registers) for the five moments x, y, x^2, y^2, xy.  HBM-bound: forward reads 8 B and
 // writes 12 B per element (+ halo re-reads served by L2), backward reads 20 B and writes 4 B.
@@ -11,9 +11,12 @@
 
 namespace {
 
-constexpr int TS = 16;          // output tile edge
+constexpr int TS = 16;          // thread block edge (16 x 16 threads) and output tile HEIGHT
+constexpr int TSX = 32;         // output tile WIDTH: two columns (lx, lx + 16) per thread, so that a 512^2 x 3 image is 1536
+                                // workgroups = 6 per CU = one resident round (16 x 16 tiles were 3072 = 1.5 rounds of 8)
 constexpr int HALO = 5;         // window radius
-constexpr int TH = TS + 2 * HALO;  // 26
+constexpr int TH = TS + 2 * HALO;    // 26 input rows per tile
+constexpr int THX = TSX + 2 * HALO;  // 42 input columns per tile
 constexpr float C1 = 0.01f * 0.01f;
 constexpr float C2 = 0.03f * 0.03f;
 
@@ -28,25 +31,25 @@ __device__ __forceinline__ float gw(int k) {
 __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                    float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                                                    float* __restrict__ dm_dsigma12, float* __restrict__ partial /*[nblocks,2]*/) {
-  __shared__ float s_x[TH][TH + 1];
-  __shared__ float s_y[TH][TH + 1];
-  __shared__ float s_h[5][TH][TS + 1];
+  __shared__ float s_x[TH][THX + 1];
+  __shared__ float s_y[TH][THX + 1];
+  __shared__ float s_h[5][TH][TSX + 1];
   __shared__ float s_red[2][4];
   const int tid = threadIdx.y * TS + threadIdx.x;
   const int plane = blockIdx.z;
-  const int ox = blockIdx.x * TS, oy = blockIdx.y * TS;
+  const int ox = blockIdx.x * TSX, oy = blockIdx.y * TS;
   const float* p1 = img1 + (size_t)plane * H * W;
   const float* p2 = img2 + (size_t)plane * H * W;
-  for (int i = tid; i < TH * TH; i += 256) {
-    const int r = i / TH, c = i - r * TH;
+  for (int i = tid; i < TH * THX; i += 256) {
+    const int r = i / THX, c = i - r * THX;
     const int gy = oy + r - HALO, gx = ox + c - HALO;
     const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
     s_x[r][c] = in ? p1[(size_t)gy * W + gx] : 0.f;
     s_y[r][c] = in ? p2[(size_t)gy * W + gx] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < TH * TS; i += 256) {
-    const int r = i / TS, c = i - r * TS;
+  for (int i = tid; i < TH * TSX; i += 256) {
+    const int r = i / TSX, c = i - r * TSX;
     float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
@@ -56,30 +59,33 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __r
     s_h[0][r][c] = sx; s_h[1][r][c] = sy; s_h[2][r][c] = sxx; s_h[3][r][c] = syy; s_h[4][r][c] = sxy;
   }
   __syncthreads();
-  const int lx = threadIdx.x, ly = threadIdx.y;
-  float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
-#pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float w = gw(k);
-    mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx]; exx += w * s_h[2][ly + k][lx];
-    eyy += w * s_h[3][ly + k][lx]; exy += w * s_h[4][ly + k][lx];
-  }
-  const int gx = ox + lx, gy = oy + ly;
-  const bool in = gx < W && gy < H;
+  const int ly = threadIdx.y;
   float val = 0.f, l1 = 0.f;
-  if (in) {
-    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
-    const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu12 + C1, Dd = 2.f * s12 + C2;
-    const float invAB = 1.f / (A * B);
-    val = Cc * Dd * invAB;
-    const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
-    if (dm_dmu1) {
-      dm_dmu1[o] = (mu2 * 2.f * Dd) * invAB - (mu2 * 2.f * Cc) * invAB - (mu1 * 2.f * Cc * Dd) * invAB / A + (mu1 * 2.f * Cc * Dd) * invAB / B;
-      dm_dsigma1_sq[o] = -Cc * Dd * invAB / B;
-      dm_dsigma12[o] = 2.f * Cc * invAB;
+#pragma unroll
+  for (int half = 0; half < TSX / TS; ++half) {
+    const int lx = threadIdx.x + half * TS;
+    float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = gw(k);
+      mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx]; exx += w * s_h[2][ly + k][lx];
+      eyy += w * s_h[3][ly + k][lx]; exy += w * s_h[4][ly + k][lx];
     }
-    l1 = fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
+    const int gx = ox + lx, gy = oy + ly;
+    if (gx < W && gy < H) {
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+      const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu12 + C1, Dd = 2.f * s12 + C2;
+      const float invAB = 1.f / (A * B);
+      val += Cc * Dd * invAB;
+      const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
+      if (dm_dmu1) {
+        dm_dmu1[o] = (mu2 * 2.f * Dd) * invAB - (mu2 * 2.f * Cc) * invAB - (mu1 * 2.f * Cc * Dd) * invAB / A + (mu1 * 2.f * Cc * Dd) * invAB / B;
+        dm_dsigma1_sq[o] = -Cc * Dd * invAB / B;
+        dm_dsigma12[o] = 2.f * Cc * invAB;
+      }
+      l1 += fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
+    }
   }
   val = gs_wave_sum(val);
   l1 = gs_wave_sum(l1);
@@ -138,20 +144,20 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
       *loss = (1.0f - lambda_dssim) * lm + lambda_dssim * (1.0f - sm);  // reference train.py:176
     }
   }
-  __shared__ float s_a[TH][TH + 1];
-  __shared__ float s_b[TH][TH + 1];
-  __shared__ float s_c[TH][TH + 1];
-  __shared__ float s_h[3][TH][TS + 1];
+  __shared__ float s_a[TH][THX + 1];
+  __shared__ float s_b[TH][THX + 1];
+  __shared__ float s_c[TH][THX + 1];
+  __shared__ float s_h[3][TH][TSX + 1];
   const int tid = threadIdx.y * TS + threadIdx.x;
   const int plane = blockIdx.z;
-  const int ox = blockIdx.x * TS, oy = blockIdx.y * TS;
+  const int ox = blockIdx.x * TSX, oy = blockIdx.y * TS;
   const size_t po = (size_t)plane * H * W;
   // scale = (device scalar, if given) x (host scalar)
   const float ks = (ssim_scale ? *ssim_scale : 1.f) * ssim_scale_host * inv_n;
   const float kl = (l1_scale ? *l1_scale : 1.f) * l1_scale_host * inv_n;
   if (ks != 0.f) {
-    for (int i = tid; i < TH * TH; i += 256) {
-      const int r = i / TH, c = i - r * TH;
+    for (int i = tid; i < TH * THX; i += 256) {
+      const int r = i / THX, c = i - r * THX;
       const int gy = oy + r - HALO, gx = ox + c - HALO;
       const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
       const size_t o = po + (size_t)gy * W + gx;
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
       s_c[r][c] = in ? dm_dsigma12[o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < TH * TS; i += 256) {
-      const int r = i / TS, c = i - r * TS;
+    for (int i = tid; i < TH * TSX; i += 256) {
+      const int r = i / TSX, c = i - r * TSX;
       float a = 0.f, b = 0.f, cc = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
@@ -172,31 +178,35 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
     }
     __syncthreads();
   }
-  const int lx = threadIdx.x, ly = threadIdx.y;
-  const int gx = ox + lx, gy = oy + ly;
-  if (gx >= W || gy >= H) return;
-  const size_t o = po + (size_t)gy * W + gx;
-  const float x = img1[o], y = img2[o];
-  float g = 0.f;
-  if (ks != 0.f) {
-    float a = 0.f, b = 0.f, cc = 0.f;
+  const int ly = threadIdx.y;
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = gw(k);
-      a += w * s_h[0][ly + k][lx]; b += w * s_h[1][ly + k][lx]; cc += w * s_h[2][ly + k][lx];
+  for (int half = 0; half < TSX / TS; ++half) {
+    const int lx = threadIdx.x + half * TS;
+    const int gx = ox + lx, gy = oy + ly;
+    if (gx >= W || gy >= H) continue;
+    const size_t o = po + (size_t)gy * W + gx;
+    const float x = img1[o], y = img2[o];
+    float g = 0.f;
+    if (ks != 0.f) {
+      float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float w = gw(k);
+        a += w * s_h[0][ly + k][lx]; b += w * s_h[1][ly + k][lx]; cc += w * s_h[2][ly + k][lx];
+      }
+      g = ks * (a + 2.f * x * b + y * cc);
     }
-    g = ks * (a + 2.f * x * b + y * cc);
+    if (kl != 0.f) {
+      const float d = x - y;
+      g += kl * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+    dL_dimg1[o] = g;
   }
-  if (kl != 0.f) {
-    const float d = x - y;
-    g += kl * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-  }
-  dL_dimg1[o] = g;
 }
 
 }  // namespace
 
-static inline int ssim_nblocks(int B, int C, int H, int W) { return B * C * ((H + TS - 1) / TS) * ((W + TS - 1) / TS); }
+static inline int ssim_nblocks(int B, int C, int H, int W) { return B * C * ((H + TS - 1) / TS) * ((W + TSX - 1) / TSX); }
 
 extern "C" {
 
@@ -212,7 +222,7 @@ int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float*
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch) return MI355GS_EINVAL;
   if ((dm_dmu1 == nullptr) != (dm_dsigma1_sq == nullptr) || (dm_dmu1 == nullptr) != (dm_dsigma12 == nullptr)) return MI355GS_EINVAL;
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
-  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
+  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
   hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch);
   GS_CHECK_LAUNCH("ssim_fwd");
   const double inv_n = 1.0 / ((double)B * C * H * W);
@@ -230,7 +240,7 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dL_dimg1) return MI355GS_EINVAL;
   if (ssim_grad_scale && (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)) return MI355GS_EINVAL;
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
-  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
+  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
   const float inv_n = (float)(1.0 / ((double)B * C * H * W));
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
                      ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1,
@@ -245,7 +255,7 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
 int gs_loss_forward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, float* dm1, float* dm2, float* dm3,
                     void* scratch) {
   const int debug = 0;
-  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
+  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, C);
   hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm1, dm2, dm3, (float*)scratch);
   GS_CHECK_LAUNCH("ssim_fwd");
   return MI355GS_OK;
@@ -255,7 +265,7 @@ int gs_loss_forward(hipStream_t stream, int C, int H, int W, const float* img1, 
 int gs_loss_backward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, const float* dm1,
                      const float* dm2, const float* dm3, float lambda_dssim, float* dL_dimg1, const void* scratch, float* loss) {
   const int debug = 0;
-  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
+  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, C);
   const double inv_n_d = 1.0 / ((double)C * H * W);
   const float inv_n = (float)inv_n_d;
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm1, dm2, dm3, (const float*)nullptr,
