@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cpu-iters", type=int, default=2, help="CPU-baseline iterations (bounded sample); 0 disables")
+    ap.add_argument("--cpu-iters", type=int, default=30, help="CPU-baseline iterations (bounded sample, ~10 s of CPU work); 0 disables")
     ap.add_argument("--pointmap", type=int, default=256, help="pointmap edge (Gaussians = 3 * edge^2)")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--sh-degree", type=int, default=0,
