@@ -254,7 +254,7 @@ __device__ __forceinline__ int gs_sched_pop(GsSched* s, int bin, int NB, int T, 
   };
   if (bin < NB) {
     const int idx = take(bin);
-    if (idx >= 0) return (int)order[idx];
+    if (idx >= 0) return idx;
   }
   // Only the first eight workgroups of the grid (one per XCD) look for unclaimed bins: a thousand workgroups reading this
   // line when they finish cost more than the kernel they schedule (measured: +28 us on a 21 us kernel).
@@ -271,7 +271,7 @@ __device__ __forceinline__ int gs_sched_pop(GsSched* s, int bin, int NB, int T, 
       const int l = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       const int idx = take(base + l);
-      if (idx >= 0) return (int)order[idx];
+      if (idx >= 0) return idx;
     }
   }
   return -1;
@@ -288,6 +288,15 @@ __device__ __forceinline__ void gs_sched_finish(GsSched* s) {
 }
 
 // Persistent workgroups over the CU-balanced tile bins (common.h, GsSched).
+// Wave priority by the tile's rank inside its bin (rank 0 = the bin's longest list).  The workgroups of a CU run their
+// tiles side by side and share each SIMD's issue slots; the longest list is the CU's critical path, so its waves issue
+// first and the shorter lists fill the slots it leaves.
+__device__ __forceinline__ void gs_rank_priority(int rank) {
+  if (rank == 0) __builtin_amdgcn_s_setprio(3);
+  else if (rank == 1) __builtin_amdgcn_s_setprio(2);
+  else if (rank == 2) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
 #define GS_PERSISTENT_TILE_LOOP(sched, NB, T, order, CALL)                     \
   __shared__ int s_tile;                                                        \
   const int wave_ = threadIdx.x >> 6;                                           \
@@ -299,8 +308,10 @@ __device__ __forceinline__ void gs_sched_finish(GsSched* s) {
       if ((threadIdx.x & 63) == 0) s_tile = t_;                                 \
     }                                                                           \
     __syncthreads();                                                            \
-    const int tile = s_tile;                                                    \
-    if (tile < 0) break;                                                        \
+    const int pos_ = s_tile;                                                    \
+    if (pos_ < 0) break;                                                        \
+    const int tile = (int)order[pos_];                                          \
+    gs_rank_priority(pos_ / NB);                                                \
     CALL;                                                                       \
     __syncthreads(); /* s_tile and the tile's LDS staging are reused */         \
   }                                                                             \
