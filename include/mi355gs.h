@@ -195,6 +195,8 @@ int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* ro
  *   f_dc[P,1,3], f_rest[P,15,3], opacity[P,1], scaling[P,3], rotation[P,4], poses[V,7]; exp_avg/exp_avg_sq: host
  *   arrays of 7 device pointers in the optimizer's group order (xyz, f_dc, f_rest, opacity, scaling, rotation, pose).
  *   workspace: mi355gs_trainer_workspace_bytes() bytes, owned by the caller, must outlive the handle.
+ *   The handle is the only writer of the parameter and moment tensors while it is alive (it remembers across steps that
+ *   a tensor without gradients has an all-zero first moment and then skips it; create a new handle after changing them).
  *   capacity: instance capacity of the binning buffers; *num_rendered (device) receives the true count of every
  *   step — a step with num_rendered > capacity dropped instances and must be discarded by the caller.
  *   lr[7], step[7] (1-based Adam step of each group): host arrays.  loss_out: device float[1].

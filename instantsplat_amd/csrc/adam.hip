@@ -55,6 +55,13 @@ struct MultiAdamArgs {
   const float* pplr[MT_MAX];
   float step_size[MT_MAX];
   int vec4[MT_MAX];  // numel % 4 == 0 and all four arrays 16-byte aligned: 128-bit loads/stores
+  // Optional memory of gated-off tensors across launches (fused trainer only).  live[2t] = sequence number of the last
+  // launch that scanned tensor t's first moment while gated off (0: none since the last update), live[2t+1] = 1 if any
+  // scan since then met a non-zero first moment.  A gated-off tensor that an EARLIER launch scanned completely without
+  // meeting one is a no-op element for element (p - s * (0 / denom) == p) and is skipped without reading anything:
+  // f_rest before the SH degree is raised costs nothing instead of 4 B per element.
+  uint32_t* live;
+  uint32_t seq;
 };
 
 __device__ __forceinline__ int mt_find(const MultiAdamArgs& a, int b) {
@@ -94,6 +101,17 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
   const long long lo = (long long)(blockIdx.x - a.first_block[t]) * MT_CHUNK;
   const long long hi = min(a.numel[t], lo + MT_CHUNK);
   const bool update = sumsq[t] > 0.f;
+  if (a.live) {
+    const bool first = blockIdx.x == (unsigned)a.first_block[t] && threadIdx.x == 0;
+    if (update) {
+      if (first) { a.live[2 * t] = 0u; a.live[2 * t + 1] = 0u; }
+    } else {
+      const uint32_t scanned = a.live[2 * t], nonzero = a.live[2 * t + 1];
+      if (scanned != 0u && scanned != a.seq && nonzero == 0u) return;  // written by an earlier launch: complete
+      if (first) a.live[2 * t] = a.seq;
+    }
+  }
+  bool met_nonzero = false;
   float* __restrict__ p = a.param[t];
   const float* __restrict__ g = a.grad[t];
   float* __restrict__ mm = a.m[t];
@@ -119,6 +137,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
       // whole-tensor gate).  Where the first moment is zero that step is p - s * (0 / denom) == p bit for bit, so only
       // exp_avg is read: f_rest before the SH degree is raised costs 4 B per element instead of 16.
       if (!update && m4.x == 0.f && m4.y == 0.f && m4.z == 0.f && m4.w == 0.f) continue;
+      met_nonzero = true;
       float4 v4 = reinterpret_cast<const float4*>(vv)[j];
       float4 p4 = reinterpret_cast<const float4*>(p)[j];
       float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -128,17 +147,20 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
       if (update) { reinterpret_cast<float4*>(mm)[j] = m4; reinterpret_cast<float4*>(vv)[j] = v4; }
       reinterpret_cast<float4*>(p)[j] = p4;
     }
+    if (a.live && !update && met_nonzero) a.live[2 * t + 1] = 1u;
     return;
   }
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     float m = mm[i];
     if (!update && m == 0.f) continue;  // see the vector path
+    met_nonzero = true;
     float v = vv[i], pv = p[i];
     const float gi = update ? g[i] : 0.f;
     one(pv, gi, m, v, i);
     if (update) { mm[i] = m; vv[i] = v; }
     p[i] = pv;
   }
+  if (a.live && !update && met_nonzero) a.live[2 * t + 1] = 1u;
 }
 
 }  // namespace
@@ -172,7 +194,9 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
     }
   }
   a.first_block[MT_MAX] = blocks;
+  a.live = nullptr; a.seq = 0;
   if (blocks == 0) return MI355GS_OK;
+  if (g_fused.gate == scratch) { a.live = g_fused.adam_live; a.seq = g_fused.adam_seq; }
   if (g_fused.gate == scratch) {
     // fused train step: the gate flags were written by the kernels that produced the gradients
   } else {

@@ -355,6 +355,8 @@ struct GsFusedStepHooks {
   GsPrologue prologue;
   GsPosed posed;
   float* gate = nullptr;   // device float[8] or null
+  uint32_t* adam_live = nullptr;  // device uint32[16] persisting across steps (see k_adam_multi) or null
+  uint32_t adam_seq = 0;          // launch sequence number (never 0) for adam_live
   int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_sh_rest = -1, gate_pose = -1;
 };
 extern thread_local GsFusedStepHooks g_fused;

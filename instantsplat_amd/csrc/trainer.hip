@@ -37,6 +37,8 @@ struct Trainer {
   float *g_means2D, *g_colors;
   float *g_xyz, *g_rot, *g_scaling, *g_opacity, *g_fdc, *g_frest, *g_poses;
   float *pose_scratch, *pose_partial, *adam_scratch, *consts;  // consts: identity view [16], campos [3]
+  uint32_t* adam_live;  // see MultiAdamArgs::live
+  uint32_t adam_seq;
   bool consts_ready;
 };
 
@@ -65,6 +67,7 @@ size_t carve(Trainer& t, void* workspace) {
   t.g_xyz = c.take<float>(3 * P); t.g_rot = c.take<float>(4 * P); t.g_scaling = c.take<float>(3 * P); t.g_opacity = c.take<float>(P);
   t.g_fdc = c.take<float>(3 * P); t.g_frest = c.take<float>(45 * P); t.g_poses = c.take<float>(7 * (size_t)t.V);
   t.pose_scratch = c.take<float>(32); t.pose_partial = c.take<float>(16 * ((P + 255) / 256)); t.adam_scratch = c.take<float>(8); t.consts = c.take<float>(32);
+  t.adam_live = c.take<uint32_t>(16);
   return c.off;
 }
 
@@ -75,6 +78,8 @@ int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t*
   float* params[7] = {t->xyz, t->f_dc, t->f_rest, t->opacity, t->scaling, t->rotation, t->poses};
   const float* grads[7] = {t->g_xyz, t->g_fdc, t->g_frest, t->g_opacity, t->g_scaling, t->g_rot, t->g_poses};
   const float* pplr[7] = {t->pplr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (++t->adam_seq == 0u) t->adam_seq = 1u;
+  g_fused.adam_live = t->adam_live; g_fused.adam_seq = t->adam_seq;
   return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch);
 }
 
@@ -139,6 +144,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     // at SH degree 0 f_rest receives no gradient: its (all-zero) gradient buffer is written once here and first
     // touched again when the degree is raised (the backward then rewrites every element each step)
     if (hipMemsetAsync(t->g_frest, 0, (size_t)P * 45 * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+    if (hipMemsetAsync(t->adam_live, 0, 16 * sizeof(uint32_t), stream) != hipSuccess) return MI355GS_ELAUNCH;
     t->consts_ready = true;
   }
   struct HookScope {
@@ -193,7 +199,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
 int mi355gs_trainer_optimizer_step(void* handle, void* stream_, const float* lr, const int32_t* step, float beta1, float beta2,
                                    float eps) {
   Trainer* t = (Trainer*)handle;
-  if (!t || !lr || !step) return MI355GS_EINVAL;
+  if (!t || !lr || !step || !t->consts_ready) return MI355GS_EINVAL;  // needs the gradients of a preceding step
   // gate flags of the gradients produced by the preceding mi355gs_trainer_step(..., do_optimizer_step = 0) are still in place
   g_fused.gate = t->adam_scratch;
   const int rc = trainer_adam(t, (hipStream_t)stream_, lr, step, beta1, beta2, eps);

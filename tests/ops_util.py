@@ -378,6 +378,54 @@ def check_run_ahead_crosses_sh_degree_step(dev, Wm=10, W=24):
         BinningPolicy.reset("exact")
 
 
+def check_gated_off_tensor_keeps_moving(dev, Wm=10, W=24):
+    """PerPointAdam's whole-tensor gate (reference scene/per_point_adam.py:62-69) freezes the MOMENTS of a tensor whose
+    gradient is all zero but still applies the parameter step.  The one-call step remembers across launches that a
+    gated-off tensor's first moment is all zero and then skips it without reading (adam.hip, MultiAdamArgs::live); that
+    memory must be dropped as soon as the tensor has been updated.  Degree 0 (scan, skip, skip) -> degree 1 (f_rest
+    trained) -> degree 0 again (f_rest gated off with live moments: it must keep moving exactly as on the autograd path)."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import RunAhead, setup_training
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=17)
+    cuda = torch.device(dev).type == "cuda"
+    try:
+        res = {}
+        for fused in (False, True):
+            st = setup_training(sc, dev, opt=OptimizationParams(iterations=500, pp_optimizer=True, optim_pose=True))
+            ra = RunAhead(st, window=2, fused_step=fused)
+            g = st.gaussians
+            track = []
+            for degree in (0, 0, 0, 1, 1, 0, 0, 0):
+                g.active_sh_degree = degree
+                ra.step()
+                ra.flush()
+                track.append(g._features_rest.detach().cpu().clone())
+            stt = g.optimizer.state[g._features_rest]
+            res[fused] = (track, stt["exp_avg"].detach().cpu().clone(), stt["exp_avg_sq"].detach().cpu().clone())
+            BinningPolicy.reset("exact")
+        for fused in (False, True):
+            track = res[fused][0]
+            assert float(track[2].abs().max()) == 0                       # untouched while never updated
+            assert float(track[4].abs().max()) > 0                        # trained at degree 1
+            for a_, b_ in ((4, 5), (5, 6), (6, 7)):                       # gated off again: still moving on its momentum
+                assert float((track[a_] - track[b_]).abs().max()) > 0, (fused, a_)
+        tol = 5e-2 if cuda else 1e-5
+        for k in range(8):
+            a_, b_ = res[True][0][k], res[False][0][k]
+            if cuda and k >= 3:
+                continue   # sign-like first Adam steps on rounding-level different gradients, see the crossing test
+            assert float((a_ - b_).norm()) <= tol * float(b_.norm() + 1e-12) + 0.0, k
+        if not cuda:
+            for i in (1, 2):
+                rel = float((res[True][i] - res[False][i]).norm() / (res[False][i].norm() + 1e-20))
+                assert rel <= 1e-5, (i, rel)
+        # the moments freeze while the tensor is gated off (both paths)
+    finally:
+        BinningPolicy.reset("exact")
+
+
 def check_split_sh_equals_concatenated(dev, degree=2, P=300, W=64, H=48, seed=5):
     """GaussianRasterizer.forward(shs=f_dc, shs_rest=f_rest) must give what shs=cat(f_dc, f_rest) gives: same image, radii
     and gradients (reference scene/gaussian_model.py:129-132 concatenates; here the two tensors go in as they are)."""

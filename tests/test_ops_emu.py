@@ -49,6 +49,10 @@ def test_fused_train_step_equals_autograd_path(emu):
     ops_util.check_fused_train_step_equals_autograd_path(emu)
 
 
+def test_gated_off_tensor_keeps_moving(emu):
+    ops_util.check_gated_off_tensor_keeps_moving(emu)
+
+
 def test_run_ahead_crosses_sh_degree_step(emu):
     ops_util.check_run_ahead_crosses_sh_degree_step(emu)
 

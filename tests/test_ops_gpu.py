@@ -45,6 +45,10 @@ def test_fused_train_step_equals_autograd_path(gpu):
     ops_util.check_fused_train_step_equals_autograd_path(gpu, iters=12, Wm=48, W=96)
 
 
+def test_gated_off_tensor_keeps_moving(gpu):
+    ops_util.check_gated_off_tensor_keeps_moving(gpu)
+
+
 def test_run_ahead_crosses_sh_degree_step(gpu):
     ops_util.check_run_ahead_crosses_sh_degree_step(gpu)
 
