@@ -155,6 +155,7 @@ __device__ __forceinline__ float gs_wave_sum_row3(float v) {
 // Two floats in an aligned VGPR pair: element-wise arithmetic on it compiles to CDNA3/4's full-rate packed-FP32 ops
 // (v_pk_add/mul/fma_f32: two lanes' worth of work per issue slot).
 typedef float gs_v2f __attribute__((vector_size(8)));
+__device__ __forceinline__ gs_v2f gs_fma2(gs_v2f a, gs_v2f b, gs_v2f c) { return a * b + c; }  // contracted: v_pk_fma_f32
 
 // Hides a value's producer from the optimiser (no instruction is emitted): stops it from re-computing a product on
 // both sides of a DPP exchange, which costs more VALU ops than the exchange saves.

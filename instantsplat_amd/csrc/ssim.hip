@@ -5,8 +5,11 @@
 //
 // One workgroup = one 32x16 output tile of one (batch, channel) plane.  The 42x26 input halo of both
 // images is staged in LDS once; the 11x11 window is applied separably (row pass into LDS, column
-// pass in registers) for the five moments x, y, x^2, y^2, xy.  HBM-bound: forward reads 8 B and
-// writes 12 B per element (+ halo re-reads served by L2), backward reads 20 B and writes 4 B.
+// pass in registers) for the five moments x, y, x^2, y^2, xy.  A thread owns the output columns
+// (lx, lx + 16) and carries them as one packed-FP32 pair through both passes (v_pk_mul/fma_f32: one
+// VALU issue per two pixels; the per-component arithmetic is that of the scalar formulation).
+// HBM: forward reads 8 B and writes 12 B per element (+ halo re-reads served by L2), backward reads
+// 20 B and writes 4 B; measured they are VALU/LDS-bound (profiles/).
 #include "common.h"
 
 namespace {
@@ -17,6 +20,9 @@ constexpr int TSX = 32;         // output tile WIDTH: two columns (lx, lx + 16) 
 constexpr int HALO = 5;         // window radius
 constexpr int TH = TS + 2 * HALO;    // 26 input rows per tile
 constexpr int THX = TSX + 2 * HALO;  // 42 input columns per tile
+constexpr int SXP = 48;              // staged row stride in floats: the four rows a wave reads at once (16 lanes each) fall into
+                                     // disjoint 16-bank groups (48 = 16 mod 32 ... 0, 48, 96, 144 -> banks 0, 48, 32, 16)
+constexpr int ROW_ITEMS = TH * TS;   // row-pass work items: (staged row, column pair)
 constexpr float C1 = 0.01f * 0.01f;
 constexpr float C2 = 0.03f * 0.03f;
 
@@ -36,62 +42,70 @@ __device__ __forceinline__ float ssim_rcp(float x) {
 __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                    float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                                                    float* __restrict__ dm_dsigma12, float* __restrict__ partial /*[nblocks,2]*/) {
-  __shared__ float s_x[TH][THX + 1];
-  __shared__ float s_y[TH][THX + 1];
-  __shared__ float s_h[5][TH][TSX + 1];
+  __shared__ float s_x[TH][SXP];
+  __shared__ float s_y[TH][SXP];
+  __shared__ gs_v2f s_h[5][TH][TS];  // row-pass results, columns (c, c + 16) as one pair
   __shared__ float s_red[2][4];
   const int tid = threadIdx.y * TS + threadIdx.x;
   const int plane = blockIdx.z;
   const int ox = blockIdx.x * TSX, oy = blockIdx.y * TS;
   const float* p1 = img1 + (size_t)plane * H * W;
   const float* p2 = img2 + (size_t)plane * H * W;
-  for (int i = tid; i < TH * THX; i += 256) {
-    const int r = i / THX, c = i - r * THX;
+  for (int i = tid; i < TH * SXP; i += 256) {
+    const int r = i / SXP, c = i - r * SXP;
     const int gy = oy + r - HALO, gx = ox + c - HALO;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const bool in = c < THX && gy >= 0 && gy < H && gx >= 0 && gx < W;
     s_x[r][c] = in ? p1[(size_t)gy * W + gx] : 0.f;
     s_y[r][c] = in ? p2[(size_t)gy * W + gx] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < TH * TSX; i += 256) {
-    const int r = i / TSX, c = i - r * TSX;
-    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+  for (int i = tid; i < ROW_ITEMS; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    gs_v2f sx = {0.f, 0.f}, sy = sx, sxx = sx, syy = sx, sxy = sx;
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-      const float w = gw(k), x = s_x[r][c + k], y = s_y[r][c + k];
-      sx += w * x; sy += w * y; sxx += w * x * x; syy += w * y * y; sxy += w * x * y;
+      const gs_v2f w = {gw(k), gw(k)};
+      const gs_v2f x = {s_x[r][c + k], s_x[r][c + TS + k]}, y = {s_y[r][c + k], s_y[r][c + TS + k]};
+      const gs_v2f wx = w * x, wy = w * y;
+      sx = gs_fma2(w, x, sx); sy = gs_fma2(w, y, sy);
+      sxx = gs_fma2(wx, x, sxx); syy = gs_fma2(wy, y, syy); sxy = gs_fma2(wx, y, sxy);
     }
     s_h[0][r][c] = sx; s_h[1][r][c] = sy; s_h[2][r][c] = sxx; s_h[3][r][c] = syy; s_h[4][r][c] = sxy;
   }
   __syncthreads();
-  const int ly = threadIdx.y;
+  const int ly = threadIdx.y, lx = threadIdx.x;
   float val = 0.f, l1 = 0.f;
-#pragma unroll
-  for (int half = 0; half < TSX / TS; ++half) {
-    const int lx = threadIdx.x + half * TS;
-    float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+  {
+    gs_v2f mu1 = {0.f, 0.f}, mu2 = mu1, exx = mu1, eyy = mu1, exy = mu1;
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-      const float w = gw(k);
-      mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx]; exx += w * s_h[2][ly + k][lx];
-      eyy += w * s_h[3][ly + k][lx]; exy += w * s_h[4][ly + k][lx];
+      const gs_v2f w = {gw(k), gw(k)};
+      mu1 = gs_fma2(w, s_h[0][ly + k][lx], mu1); mu2 = gs_fma2(w, s_h[1][ly + k][lx], mu2);
+      exx = gs_fma2(w, s_h[2][ly + k][lx], exx); eyy = gs_fma2(w, s_h[3][ly + k][lx], eyy);
+      exy = gs_fma2(w, s_h[4][ly + k][lx], exy);
     }
-    const int gx = ox + lx, gy = oy + ly;
-    if (gx < W && gy < H) {
-      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-      const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
-      const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu12 + C1, Dd = 2.f * s12 + C2;
-      // two reciprocals (v_rcp_f32 + one Newton step: <= 1 ulp) instead of four IEEE divisions (~10 VALU ops each)
-      const float invA = ssim_rcp(A), invB = ssim_rcp(B);
-      const float invAB = invA * invB;
-      val += Cc * Dd * invAB;
-      const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
-      if (dm_dmu1) {
-        dm_dmu1[o] = (mu2 * 2.f * Dd) * invAB - (mu2 * 2.f * Cc) * invAB - (mu1 * 2.f * Cc * Dd) * invAB * invA + (mu1 * 2.f * Cc * Dd) * invAB * invB;
-        dm_dsigma1_sq[o] = -Cc * Dd * invAB * invB;
-        dm_dsigma12[o] = 2.f * Cc * invAB;
+    const gs_v2f two = {2.f, 2.f}, c1 = {C1, C1}, c2 = {C2, C2};
+    const gs_v2f mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const gs_v2f s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+    const gs_v2f A = mu1_sq + mu2_sq + c1, B = s1 + s2 + c2, Cc = two * mu12 + c1, Dd = two * s12 + c2;
+    // two reciprocals per pixel (v_rcp_f32 + one Newton step: <= 1 ulp) instead of four IEEE divisions (~10 VALU ops each)
+    const gs_v2f invA = {ssim_rcp(A[0]), ssim_rcp(A[1])}, invB = {ssim_rcp(B[0]), ssim_rcp(B[1])};
+    const gs_v2f invAB = invA * invB;
+    const gs_v2f m = Cc * Dd * invAB;
+    const gs_v2f t = mu1 * two * Cc * Dd * invAB;
+    const gs_v2f d1 = (mu2 * two * Dd) * invAB - (mu2 * two * Cc) * invAB - t * invA + t * invB;
+    const gs_v2f d2 = -m * invB;
+    const gs_v2f d3 = two * Cc * invAB;
+    const int gy = oy + ly;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int gx = ox + lx + half * TS;
+      if (gx < W && gy < H) {
+        val += m[half];
+        const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
+        if (dm_dmu1) { dm_dmu1[o] = d1[half]; dm_dsigma1_sq[o] = d2[half]; dm_dsigma12[o] = d3[half]; }
+        l1 += fabsf(s_x[ly + HALO][lx + half * TS + HALO] - s_y[ly + HALO][lx + half * TS + HALO]);
       }
-      l1 += fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
     }
   }
   val = gs_wave_sum(val);
@@ -151,10 +165,10 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
       *loss = (1.0f - lambda_dssim) * lm + lambda_dssim * (1.0f - sm);  // reference train.py:176
     }
   }
-  __shared__ float s_a[TH][THX + 1];
-  __shared__ float s_b[TH][THX + 1];
-  __shared__ float s_c[TH][THX + 1];
-  __shared__ float s_h[3][TH][TSX + 1];
+  __shared__ float s_a[TH][SXP];
+  __shared__ float s_b[TH][SXP];
+  __shared__ float s_c[TH][SXP];
+  __shared__ gs_v2f s_h[3][TH][TS];  // columns (c, c + 16) as one pair, see k_ssim_fwd
   const int tid = threadIdx.y * TS + threadIdx.x;
   const int plane = blockIdx.z;
   const int ox = blockIdx.x * TSX, oy = blockIdx.y * TS;
@@ -163,46 +177,49 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
   const float ks = (ssim_scale ? *ssim_scale : 1.f) * ssim_scale_host * inv_n;
   const float kl = (l1_scale ? *l1_scale : 1.f) * l1_scale_host * inv_n;
   if (ks != 0.f) {
-    for (int i = tid; i < TH * THX; i += 256) {
-      const int r = i / THX, c = i - r * THX;
+    for (int i = tid; i < TH * SXP; i += 256) {
+      const int r = i / SXP, c = i - r * SXP;
       const int gy = oy + r - HALO, gx = ox + c - HALO;
-      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const bool in = c < THX && gy >= 0 && gy < H && gx >= 0 && gx < W;
       const size_t o = po + (size_t)gy * W + gx;
       s_a[r][c] = in ? dm_dmu1[o] : 0.f;
       s_b[r][c] = in ? dm_dsigma1_sq[o] : 0.f;
       s_c[r][c] = in ? dm_dsigma12[o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < TH * TSX; i += 256) {
-      const int r = i / TSX, c = i - r * TSX;
-      float a = 0.f, b = 0.f, cc = 0.f;
+    for (int i = tid; i < ROW_ITEMS; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      gs_v2f a = {0.f, 0.f}, b = a, cc = a;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
-        const float w = gw(k);
-        a += w * s_a[r][c + k]; b += w * s_b[r][c + k]; cc += w * s_c[r][c + k];
+        const gs_v2f w = {gw(k), gw(k)};
+        a = gs_fma2(w, gs_v2f{s_a[r][c + k], s_a[r][c + TS + k]}, a);
+        b = gs_fma2(w, gs_v2f{s_b[r][c + k], s_b[r][c + TS + k]}, b);
+        cc = gs_fma2(w, gs_v2f{s_c[r][c + k], s_c[r][c + TS + k]}, cc);
       }
       s_h[0][r][c] = a; s_h[1][r][c] = b; s_h[2][r][c] = cc;
     }
     __syncthreads();
   }
-  const int ly = threadIdx.y;
+  const int ly = threadIdx.y, lx = threadIdx.x;
+  const int gy = oy + ly;
+  if (gy >= H) return;
+  gs_v2f a = {0.f, 0.f}, b = a, cc = a;
+  if (ks != 0.f) {
 #pragma unroll
-  for (int half = 0; half < TSX / TS; ++half) {
-    const int lx = threadIdx.x + half * TS;
-    const int gx = ox + lx, gy = oy + ly;
-    if (gx >= W || gy >= H) continue;
+    for (int k = 0; k < 11; ++k) {
+      const gs_v2f w = {gw(k), gw(k)};
+      a = gs_fma2(w, s_h[0][ly + k][lx], a); b = gs_fma2(w, s_h[1][ly + k][lx], b); cc = gs_fma2(w, s_h[2][ly + k][lx], cc);
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int gx = ox + lx + half * TS;
+    if (gx >= W) continue;
     const size_t o = po + (size_t)gy * W + gx;
     const float x = img1[o], y = img2[o];
     float g = 0.f;
-    if (ks != 0.f) {
-      float a = 0.f, b = 0.f, cc = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; ++k) {
-        const float w = gw(k);
-        a += w * s_h[0][ly + k][lx]; b += w * s_h[1][ly + k][lx]; cc += w * s_h[2][ly + k][lx];
-      }
-      g = ks * (a + 2.f * x * b + y * cc);
-    }
+    if (ks != 0.f) g = ks * (a[half] + 2.f * x * b[half] + y * cc[half]);
     if (kl != 0.f) {
       const float d = x - y;
       g += kl * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
