@@ -22,6 +22,7 @@ constexpr int TH = TS + 2 * HALO;    // 26 input rows per tile
 constexpr int THX = TSX + 2 * HALO;  // 42 input columns per tile
 constexpr int SXP = 48;              // staged row stride in floats: the four rows a wave reads at once (16 lanes each) fall into
                                      // disjoint 16-bank groups (48 = 16 mod 32 ... 0, 48, 96, 144 -> banks 0, 48, 32, 16)
+constexpr int STAGE_ITERS = (TH * SXP + 255) / 256;  // 5
 constexpr int ROW_ITEMS = TH * TS;   // row-pass work items: (staged row, column pair)
 constexpr float C1 = 0.01f * 0.01f;
 constexpr float C2 = 0.03f * 0.03f;
@@ -51,12 +52,24 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __r
   const int ox = blockIdx.x * TSX, oy = blockIdx.y * TS;
   const float* p1 = img1 + (size_t)plane * H * W;
   const float* p2 = img2 + (size_t)plane * H * W;
-  for (int i = tid; i < TH * SXP; i += 256) {
-    const int r = i / SXP, c = i - r * SXP;
-    const int gy = oy + r - HALO, gx = ox + c - HALO;
-    const bool in = c < THX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    s_x[r][c] = in ? p1[(size_t)gy * W + gx] : 0.f;
-    s_y[r][c] = in ? p2[(size_t)gy * W + gx] : 0.f;
+  // Staging: every load goes to a clamped (always valid) address and is issued before the first LDS write, so a thread
+  // waits for HBM/L2 once — as a loop of predicated loads this was ten dependent round trips per thread and most of the
+  // kernel's duration.
+  {
+    float vx[STAGE_ITERS], vy[STAGE_ITERS];
+#pragma unroll
+    for (int j = 0; j < STAGE_ITERS; ++j) {
+      const int i = tid + 256 * j, r = i / SXP, c = i - r * SXP;
+      const size_t o = (size_t)min(max(oy + r - HALO, 0), H - 1) * W + min(max(ox + c - HALO, 0), W - 1);
+      vx[j] = p1[o]; vy[j] = p2[o];
+    }
+#pragma unroll
+    for (int j = 0; j < STAGE_ITERS; ++j) {
+      const int i = tid + 256 * j, r = i / SXP, c = i - r * SXP;
+      const int gy = oy + r - HALO, gx = ox + c - HALO;
+      const bool in = c < THX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      if (i < TH * SXP) { s_x[r][c] = in ? vx[j] : 0.f; s_y[r][c] = in ? vy[j] : 0.f; }
+    }
   }
   __syncthreads();
   for (int i = tid; i < ROW_ITEMS; i += 256) {
@@ -176,15 +189,29 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
   // scale = (device scalar, if given) x (host scalar)
   const float ks = (ssim_scale ? *ssim_scale : 1.f) * ssim_scale_host * inv_n;
   const float kl = (l1_scale ? *l1_scale : 1.f) * l1_scale_host * inv_n;
+  // the two output pixels' own values: requested now, used after the passes
+  float px[2], py[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const size_t o = po + (size_t)min(oy + (int)threadIdx.y, H - 1) * W + min(ox + (int)threadIdx.x + half * TS, W - 1);
+    px[half] = img1[o]; py[half] = img2[o];
+  }
   if (ks != 0.f) {
-    for (int i = tid; i < TH * SXP; i += 256) {
-      const int r = i / SXP, c = i - r * SXP;
-      const int gy = oy + r - HALO, gx = ox + c - HALO;
-      const bool in = c < THX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const size_t o = po + (size_t)gy * W + gx;
-      s_a[r][c] = in ? dm_dmu1[o] : 0.f;
-      s_b[r][c] = in ? dm_dsigma1_sq[o] : 0.f;
-      s_c[r][c] = in ? dm_dsigma12[o] : 0.f;
+    {  // staged with clamped addresses, all loads in flight before the first LDS write (see k_ssim_fwd)
+      float va[STAGE_ITERS], vb[STAGE_ITERS], vc[STAGE_ITERS];
+#pragma unroll
+      for (int j = 0; j < STAGE_ITERS; ++j) {
+        const int i = tid + 256 * j, r = i / SXP, c = i - r * SXP;
+        const size_t o = po + (size_t)min(max(oy + r - HALO, 0), H - 1) * W + min(max(ox + c - HALO, 0), W - 1);
+        va[j] = dm_dmu1[o]; vb[j] = dm_dsigma1_sq[o]; vc[j] = dm_dsigma12[o];
+      }
+#pragma unroll
+      for (int j = 0; j < STAGE_ITERS; ++j) {
+        const int i = tid + 256 * j, r = i / SXP, c = i - r * SXP;
+        const int gy = oy + r - HALO, gx = ox + c - HALO;
+        const bool in = c < THX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (i < TH * SXP) { s_a[r][c] = in ? va[j] : 0.f; s_b[r][c] = in ? vb[j] : 0.f; s_c[r][c] = in ? vc[j] : 0.f; }
+      }
     }
     __syncthreads();
     for (int i = tid; i < ROW_ITEMS; i += 256) {
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
     const int gx = ox + lx + half * TS;
     if (gx >= W) continue;
     const size_t o = po + (size_t)gy * W + gx;
-    const float x = img1[o], y = img2[o];
+    const float x = px[half], y = py[half];
     float g = 0.f;
     if (ks != 0.f) g = ks * (a[half] + 2.f * x * b[half] + y * cc[half]);
     if (kl != 0.f) {
