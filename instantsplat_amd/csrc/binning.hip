@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(int n, const uint32_t* __res
 // tile's segment (one returning global atomic), then hands out slots with returning LDS atomics.
 // Order inside a tile is arbitrary here; K4's sort makes it deterministic.
 constexpr int BIN_CHUNK = 512;   // Gaussians per workgroup: 384 workgroups at 196k Gaussians (2048 left 160 of 256 CUs idle)
+static_assert(BIN_CHUNK == 512, "two Gaussians per thread (own_depth selection in k_scatter_lds)");
 constexpr int BIN_MAX_LDS_TILES = 16384;  // 64 KiB of LDS; larger grids use the direct-atomic kernels
 
 __device__ __forceinline__ bool unpack_rect(uint2 r, int& x0, int& y0, int& x1, int& y1) {
@@ -190,16 +191,24 @@ __device__ __forceinline__ bool unpack_rect(uint2 r, int& x0, int& y0, int& x1, 
 // the instance count grew by 13 %.  Rectangles above BIN_WIDE tiles are queued in LDS and walked by a 16-lane row each.
 constexpr int BIN_WIDE = 8;
 
+constexpr int BIN_PER_THREAD = BIN_CHUNK / 256;
+
+// f(i, j, x, y): instance (Gaussian i, tile (x, y)); j = the calling thread's own slot of Gaussian i (index into what it
+// preloaded), or -1 on the wide path where another thread's Gaussian is walked.  own[j] = rectangle of Gaussian
+// lo + tid + 256 j, preloaded by the caller ((0,0,0,0) past the end): the kernels that use this run in one resident round,
+// every workgroup in the same phase, and a load issued inside the loop is a round trip to L2/HBM nobody covers.
 template <class F>
-__device__ __forceinline__ void for_each_instance(int lo, int hi, const uint2* __restrict__ rects, uint32_t* s_wide, uint32_t* s_nwide,
-                                                  F&& f) {
+__device__ __forceinline__ void for_each_instance(int lo, int hi, const uint2 (&own)[BIN_PER_THREAD], const uint2* __restrict__ rects,
+                                                  uint32_t* s_wide, uint32_t* s_nwide, F&& f) {
   const int tid = threadIdx.x;
-  for (int i = lo + tid; i < hi; i += 256) {
+#pragma unroll
+  for (int j = 0; j < BIN_PER_THREAD; ++j) {
+    const int i = lo + tid + 256 * j;
     int x0, y0, x1, y1;
-    if (!unpack_rect(rects[i], x0, y0, x1, y1)) continue;
+    if (i >= hi || !unpack_rect(own[j], x0, y0, x1, y1)) continue;
     if ((x1 - x0) * (y1 - y0) > BIN_WIDE) { s_wide[atomicAdd(s_nwide, 1u)] = (uint32_t)i; continue; }
     for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) f(i, x, y);
+      for (int x = x0; x < x1; ++x) f(i, j, x, y);
   }
   __syncthreads();
   const int nwide = (int)*s_nwide;
@@ -208,7 +217,7 @@ __device__ __forceinline__ void for_each_instance(int lo, int hi, const uint2* _
     int x0, y0, x1, y1;
     unpack_rect(rects[i], x0, y0, x1, y1);
     const int w = x1 - x0, n = w * (y1 - y0);
-    for (int j = tid & 15; j < n; j += 16) f(i, x0 + j % w, y0 + j / w);
+    for (int j = tid & 15; j < n; j += 16) f(i, -1, x0 + j % w, y0 + j / w);
   }
 }
 
@@ -218,11 +227,14 @@ __global__ __launch_bounds__(256) void k_count_tiles_lds(int P, int T, int gx, c
   __shared__ uint32_t s_wide[BIN_CHUNK];
   __shared__ uint32_t s_nwide;
   const int tid = threadIdx.x;
+  const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
+  uint2 own[BIN_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < BIN_PER_THREAD; ++j) own[j] = rects[min(lo + tid + 256 * j, P - 1)];
   for (int t = tid; t < T; t += 256) s_bins[t] = 0;
   if (tid == 0) s_nwide = 0;
   __syncthreads();
-  const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
-  for_each_instance(lo, hi, rects, s_wide, &s_nwide, [&](int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
+  for_each_instance(lo, hi, own, rects, s_wide, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
   __syncthreads();
   for (int t = tid; t < T; t += 256) {
     const uint32_t c = s_bins[t];
@@ -237,20 +249,45 @@ __global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const
   __shared__ uint32_t s_wide[BIN_CHUNK];
   __shared__ uint32_t s_nwide;
   const int tid = threadIdx.x;
+  const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
+  // this thread's Gaussians: rectangle and depth (the high half of the sort key), requested before anything waits
+  uint2 own[BIN_PER_THREAD];
+  uint32_t own_depth[BIN_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < BIN_PER_THREAD; ++j) {
+    const int ic = min(lo + tid + 256 * j, P - 1);
+    own[j] = rects[ic];
+    own_depth[j] = __float_as_uint(recs[ic].q2.w);
+  }
   for (int t = tid; t < T; t += 256) s_bins[t] = 0;
   if (tid == 0) s_nwide = 0;
   __syncthreads();
-  const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
-  for_each_instance(lo, hi, rects, s_wide, &s_nwide, [&](int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
+  for_each_instance(lo, hi, own, rects, s_wide, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
   __syncthreads();
-  for (int t = tid; t < T; t += 256) {
-    const uint32_t c = s_bins[t];
-    if (c) s_bins[t] = start[t] + atomicAdd(&cursor[t], c);  // first slot of this workgroup's range in tile t
+  // Private counts -> first slot of this workgroup's range in each touched tile.  Four returning atomics per thread are in
+  // flight before the first result is consumed (one at a time they were four dependent trips to the L2).
+  for (int t0 = 0; t0 < T; t0 += 1024) {
+    uint32_t c[4], r[4], st[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + tid + 256 * j;
+      c[j] = t < T ? s_bins[t] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + tid + 256 * j;
+      r[j] = 0u; st[j] = 0u;
+      if (c[j]) { r[j] = atomicAdd(&cursor[t], c[j]); st[j] = start[t]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c[j]) s_bins[t0 + tid + 256 * j] = st[j] + r[j];
   }
   if (tid == 0) s_nwide = 0;
   __syncthreads();
-  for_each_instance(lo, hi, rects, s_wide, &s_nwide, [&](int i, int x, int y) {
-    const uint64_t key = ((uint64_t)__float_as_uint(recs[i].q2.w) << 32) | (uint32_t)i;
+  for_each_instance(lo, hi, own, rects, s_wide, &s_nwide, [&](int i, int j, int x, int y) {
+    const uint32_t depth = j == 0 ? own_depth[0] : (j == 1 ? own_depth[BIN_PER_THREAD - 1] : __float_as_uint(recs[i].q2.w));
+    const uint64_t key = ((uint64_t)depth << 32) | (uint32_t)i;
     const uint32_t pos = atomicAdd(&s_bins[y * gx + x], 1u);
     if (pos < capacity) keys[pos] = key;
   });
