@@ -20,7 +20,7 @@ def test_ssim_ragged_sizes(emu):
     ops_util.check_ssim_random(emu, 33, 17)   # not multiples of the 16x16 tile
 
 
-@pytest.mark.parametrize("n,dup", [(1, False), (3, False), (300, False), (700, True)])
+@pytest.mark.parametrize("n,dup", [(1, False), (3, False), (300, False), (700, True), (9000, False)])
 def test_knn_matches_kdtree(emu, n, dup):
     ops_util.check_knn(emu, n, duplicates=dup)
 
