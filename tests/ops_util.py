@@ -210,9 +210,14 @@ def check_run_ahead_equals_sync_loop(dev, iters=23, force_overflow=False, Wm=20,
         ema_b = ra.flush()
         if force_overflow:
             assert ra.replays >= 3, ra.replays
-        # CPU tier: the emulated kernels are deterministic, so the EMA must agree to rounding; GPU: float-atomic order
-        # differs between any two runs and Adam amplifies it, measured run-to-run spread of the EMA is ~1e-3 relative
-        ema_tol = 1e-6 if torch.device(dev).type != "cuda" else 1e-2
+        # CPU tier: the emulated kernels are deterministic and the one-call step evaluates the same expressions as the
+        # op-by-op path, so the EMA must agree to rounding (1e-6) — that is the equivalence check.  GPU: the two paths round
+        # differently (the one-call step transforms by the pose inside the projection kernels, different FMA contraction)
+        # and float-atomic order differs between any two runs; Adam turns rounding-level gradients of zero-gradient elements
+        # into +-lr steps (check_fused_step_gradients_equal_autograd bounds the gradients themselves).  Measured with
+        # tools/ema_probe.py on this scene: same loop run twice 0.5e-3..4.4e-3, op-by-op vs one-call 4.8e-3..1.1e-2 (parameters:
+        # same loop twice up to 2.3e-3, op-by-op vs one-call up to 6.1e-3, both largest on _scaling).
+        ema_tol = 1e-6 if torch.device(dev).type != "cuda" else 3e-2
         assert abs(ema - ema_b) <= ema_tol * max(1e-3, abs(ema)), (ema, ema_b)
         # Parameters: on the CPU tier the kernels run deterministically, so both loops must agree tightly.  On the GPU
         # the float atomics of the backward pass make even two runs of the SAME loop differ in the last bits, and Adam
@@ -274,7 +279,8 @@ def check_fused_train_step_equals_autograd_path(dev, iters=6, Wm=12, W=32):
                           {n: st.gaussians.optimizer.state[getattr(st.gaussians, n)]["exp_avg_sq"].detach().cpu().clone() for n in names})
             BinningPolicy.reset("exact")
         cuda = torch.device(dev).type == "cuda"
-        assert abs(res[True][0] - res[False][0]) <= (1e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
+        # GPU bound: see check_run_ahead_equals_sync_loop (one-call vs op-by-op EMA measured up to 1.1e-2 on a 23-iteration run)
+        assert abs(res[True][0] - res[False][0]) <= (3e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
         # Under the emulator (deterministic atomics) the two paths agree to rounding.  On the GPU the float atomics of the
         # composite backward land in a different order every run and Adam amplifies that over the iterations; the second
         # moments (sums of squared gradients) are the most sensitive quantity compared here.
@@ -365,7 +371,8 @@ def check_run_ahead_crosses_sh_degree_step(dev, Wm=10, W=24):
             assert float(st.gaussians._features_rest.detach()[:, 3:].abs().max()) == 0   # higher bands still untouched
             res[fused] = (ema, {n: getattr(st.gaussians, n).detach().cpu().clone() for n in names})
             BinningPolicy.reset("exact")
-        assert abs(res[True][0] - res[False][0]) <= (1e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
+        # GPU bound: see check_run_ahead_equals_sync_loop (one-call vs op-by-op EMA measured up to 1.1e-2 on a 23-iteration run)
+        assert abs(res[True][0] - res[False][0]) <= (3e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
         for n in names:
             a_, b_ = res[True][1][n], res[False][1][n]
             rel = float((a_ - b_).norm() / (b_.norm() + 1e-12))
