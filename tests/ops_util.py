@@ -70,8 +70,9 @@ def check_adam_golden(dev):
         assert torch.allclose(p2.detach().cpu(), T(f"adam_p2_{t + 1}"), rtol=2e-6, atol=1e-7), t
 
 
-def check_train_matches_cpu_oracle(dev, iters, Wm=16, W=32):
-    """Full train iterations on the device path vs the all-CPU oracle trainer from identical state.
+def check_train_matches_cpu_oracle(dev, iters, Wm=16, W=32, fused_step=False):
+    """Full train iterations on the device path vs the all-CPU oracle trainer from identical state
+    (fused_step: the iterations of part (2) run on the one-call library step instead of the op-by-op path).
 
     (1) gradients of one iteration agree per tensor (rel-L2 <= 1e-4).  `rotation` is compared with an
         absolute bound instead: at initialisation every Gaussian is isotropic (3 equal scales, reference
@@ -113,8 +114,12 @@ def check_train_matches_cpu_oracle(dev, iters, Wm=16, W=32):
         t.grad = None
         cpu.p[name].grad = None
 
+    if fused_step:
+        from instantsplat_amd.train import FusedTrainer
+        assert FusedTrainer.supported(st)
     for it in range(iters):
-        l_dev = train_iteration(st)
+        l_dev = train_iteration(st, fused_step=fused_step)
+        assert (getattr(st, "_trainer", None) is not None) == fused_step
         for grp, dgrp in zip(cpu.opt.param_groups, g.optimizer.param_groups):
             grp["lr"] = dgrp["lr"]
         l_cpu = cpu.iteration()

@@ -106,3 +106,7 @@ def test_split_sh_equals_concatenated(emu, degree):
 @pytest.mark.parametrize("degree", [0, 1, 3])
 def test_fused_step_gradients_equal_autograd(emu, degree):
     ops_util.check_fused_step_gradients_equal_autograd(emu, degree)
+
+
+def test_two_one_call_train_iterations_match_cpu_oracle(emu):
+    ops_util.check_train_matches_cpu_oracle(emu, iters=2, fused_step=True)

@@ -82,3 +82,7 @@ def test_split_sh_equals_concatenated(gpu, degree):
 @pytest.mark.parametrize("degree", [0, 1, 3])
 def test_fused_step_gradients_equal_autograd(gpu, degree):
     ops_util.check_fused_step_gradients_equal_autograd(gpu, degree)
+
+
+def test_one_call_train_iterations_match_cpu_oracle(gpu):
+    ops_util.check_train_matches_cpu_oracle(gpu, iters=5, Wm=48, W=96, fused_step=True)
