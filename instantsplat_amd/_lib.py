@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 
 import torch
 

@@ -8,7 +8,6 @@ seven pose gradients on the device, so one tracking iteration is ~15 kernel laun
 """
 from __future__ import annotations
 
-import math
 import time
 from typing import List
 

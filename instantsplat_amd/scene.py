@@ -3,7 +3,6 @@ and optimiser groups of the reference's GaussianModel (reference scene/gaussian_
 minus everything that is never executed by InstantSplat (densify/prune, :328-477)."""
 from __future__ import annotations
 
-import math
 
 import torch
 import torch.nn as nn

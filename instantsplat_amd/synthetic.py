@@ -14,11 +14,11 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import List
 
 import torch
 
-from .camera import Camera, fov2focal
+from .camera import Camera
 
 SH_C0 = 0.28209479177387814
 

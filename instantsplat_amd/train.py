@@ -22,7 +22,7 @@ from .optim import PerPointAdam
 from .fused_ssim import fused_l1_ssim_loss, fused_ssim
 from .diff_gaussian_rasterization import BinningPolicy, binning_hint
 from .gaussian_renderer import render
-from .pose_utils import get_tensor_from_camera, quadmultiply
+from .pose_utils import quadmultiply
 from .scene import GaussianModel, confidence_to_lr_modifiers
 from .synthetic import PointmapScene
 

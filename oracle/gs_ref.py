@@ -11,7 +11,6 @@ import ctypes
 import os
 import subprocess
 
-import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -23,8 +23,7 @@ checked against each other in tests/test_oracle.py.
 """
 from __future__ import annotations
 
-import math
-from typing import NamedTuple, Optional
+from typing import NamedTuple
 
 import torch
 

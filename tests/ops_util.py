@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from oracle import adam_ref, knn_ref, ssim_ref
+from oracle import knn_ref, ssim_ref
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
 T = lambda k: torch.from_numpy(G[k])

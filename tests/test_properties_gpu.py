@@ -4,7 +4,6 @@ oracle would be too slow to be the checker.
   * backward is linear in dL/dpixel;
   * with a black background the image is linear in precomputed colours (transmittance does not depend on colour);
   * every per-tile list the binning produces is sorted by (depth, index) and its length matches the tile counts."""
-import math
 
 import pytest
 import torch
