@@ -177,3 +177,52 @@ def check_tile_lists_sorted(dev, n):
         assert bool((key[1:] > key[:-1]).all()), (tile, len(seg))
     return longest
 
+
+
+def check_operator_error_behaviour(dev, tmp_path):
+    """Error contract of the rasterizer module (operator __init__ as called at reference
+    gaussian_renderer/__init__.py:126-135): exactly one colour source and one covariance source or an `Exception`, the
+    means3D shape message, and with `debug=True` a failing call leaves `snapshot_fw.dump` (a torch.save of the CPU copies
+    of its arguments) in the working directory before the exception propagates."""
+    import os
+    import pytest
+    from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from instantsplat_amd.synthetic import syn_blob
+    from tests.util import settings_for
+    sc = syn_blob(64, 48, 32, seed=2)
+    dev = torch.device(dev)
+    t = lambda x: x.to(dev)
+    means, shs, op = t(sc.means3D), t(sc.shs), torch.sigmoid(t(sc.opacity_logit))
+    scales, rots = torch.exp(t(sc.scaling_logit)), t(sc.rotation)
+    m2d = torch.zeros_like(means)
+    cols, cov = torch.rand(64, 3, device=dev), torch.rand(64, 6, device=dev)
+    bg = torch.zeros(3)
+    r = GaussianRasterizer(settings_for(sc.camera, 0, GaussianRasterizationSettings, bg, device=dev))
+    with pytest.raises(Exception, match="one of either SHs or precomputed colors"):
+        r(means3D=means, means2D=m2d, opacities=op, shs=shs, colors_precomp=cols, scales=scales, rotations=rots)
+    with pytest.raises(Exception, match="one of either SHs or precomputed colors"):
+        r(means3D=means, means2D=m2d, opacities=op, scales=scales, rotations=rots)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=means, means2D=m2d, opacities=op, shs=shs, scales=scales, rotations=rots, cov3D_precomp=cov)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=means, means2D=m2d, opacities=op, shs=shs, scales=scales)
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        r(means3D=means[:, :2].contiguous(), means2D=m2d, opacities=op, shs=shs, scales=scales, rotations=rots)
+    # a call the library rejects (SH degree 4), debug on: snapshot + exception; debug off: exception only
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        bad = GaussianRasterizer(settings_for(sc.camera, 4, GaussianRasterizationSettings, bg, device=dev))
+        with pytest.raises(RuntimeError):
+            bad(means3D=means, means2D=m2d, opacities=op, shs=shs, scales=scales, rotations=rots)
+        assert not os.path.exists("snapshot_fw.dump")
+        bad = GaussianRasterizer(settings_for(sc.camera, 4, GaussianRasterizationSettings, bg, device=dev, debug=True))
+        with pytest.raises(RuntimeError):
+            bad(means3D=means, means2D=m2d, opacities=op, shs=shs, scales=scales, rotations=rots)
+        dump = torch.load("snapshot_fw.dump", weights_only=False)
+        assert torch.equal(dump[0], means.cpu()) and dump[-1][8] == 4   # (means3D, ..., settings tuple with sh_degree)
+    finally:
+        os.chdir(cwd)
+    # and the valid call still works afterwards
+    color, radii = r(means3D=means, means2D=m2d, opacities=op, shs=shs, scales=scales, rotations=rots)
+    assert color.shape == (3, 32, 48) and radii.shape == (64,) and bool(torch.isfinite(color).all())

@@ -36,3 +36,7 @@ def test_long_tile_lists(emu, n):
 @pytest.mark.parametrize("n,longer_than", [(600, 0), (3000, 2048), (12000, 8192)])
 def test_tile_lists_sorted(emu, n, longer_than):
     assert edge_cases.check_tile_lists_sorted(emu, n) > longer_than
+
+
+def test_operator_error_behaviour(emu, tmp_path):
+    edge_cases.check_operator_error_behaviour(emu, tmp_path)

@@ -37,3 +37,7 @@ def test_long_tile_lists(gpu, n):
 @pytest.mark.parametrize("n,longer_than", [(600, 0), (3000, 2048), (12000, 8192), (40000, 8192)])
 def test_tile_lists_sorted(gpu, n, longer_than):
     assert edge_cases.check_tile_lists_sorted(gpu, n) > longer_than
+
+
+def test_operator_error_behaviour(gpu, tmp_path):
+    edge_cases.check_operator_error_behaviour(gpu, tmp_path)
