@@ -400,6 +400,10 @@ class RunAhead:
                 losses.append(float(l.item()))
                 _optimizer_step(self.st)
             BinningPolicy.mode = "bounded"
+            if self.trainer is not None:
+                # the replay rewrote parameters and moments behind the handle's back (it is their only writer otherwise,
+                # include/mi355gs.h): start from a fresh handle, sized for the counts the replay has just verified
+                self._make_trainer()
         for l in losses:
             self.ema = 0.4 * l + 0.6 * self.ema   # reference train.py:188
         self.st.last_loss = losses[-1]
