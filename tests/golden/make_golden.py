@@ -11,6 +11,7 @@ exists in the reference tree as Python:
   get_camera_from_tensor, quadmultiply, get_tensor_from_camera   reference utils/pose_utils.py:10-215
   PerPointAdam.step            reference scene/per_point_adam.py:34-100
   psnr                         reference utils/image_utils.py:17-19
+  load_and_prepare_confidence  reference train.py:63-85 (function definition executed on its own)
 
 Run:  python tests/golden/make_golden.py
 """
@@ -133,3 +134,22 @@ out2["colmap_img_camid"] = np.array([imgs[i].camera_id for i in iid])
 out2["colmap_img_R"] = np.stack([cl.qvec2rotmat(imgs[i].qvec) for i in iid])
 np.savez_compressed(OUT, **out2)
 print("added COLMAP vectors:", len(out2), "arrays")
+
+# ---- MASt3R confidence -> per-point LR multipliers (reference train.py:63-85; train.py itself cannot be imported here —
+# torchvision / the CUDA operators are missing — so only that function's definition is taken from the file and executed)
+import ast  # noqa: E402
+import tempfile  # noqa: E402
+
+src = open(os.path.join(REF, "train.py")).read()
+fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "load_and_prepare_confidence")
+ns = {"np": np, "torch": torch}
+exec(compile(ast.Module(body=[fn], type_ignores=[]), os.path.join(REF, "train.py"), "exec"), ns)
+g3 = torch.Generator().manual_seed(7)
+conf = (3.0 + 2.0 * torch.randn(64, 1, generator=g3)).numpy().astype(np.float32)
+with tempfile.TemporaryDirectory() as td:
+    np.save(os.path.join(td, "confidence_dsp.npy"), conf)
+    lr_mod = ns["load_and_prepare_confidence"](os.path.join(td, "confidence_dsp.npy"), device="cpu", scale=(1, 100))
+out3 = dict(np.load(OUT))
+out3["confidence_raw"], out3["confidence_lr_modifiers"] = conf, lr_mod.numpy()
+np.savez_compressed(OUT, **out3)
+print("added confidence vectors:", len(out3), "arrays")

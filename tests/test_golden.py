@@ -79,3 +79,11 @@ def test_adam_oracle_matches_reference_trajectory():
 
 def test_psnr_matches_reference():
     assert torch.allclose(psnr(T("psnr_a"), T("psnr_b")), T("psnr_val"))
+
+
+def test_confidence_lr_modifiers_match_reference():
+    """reference train.py:63-85 called with scale=(1, 100) at :96 — the per-point LR multipliers PerPointAdam applies to xyz."""
+    ours = scene.confidence_to_lr_modifiers(T("confidence_raw"), scale=(1.0, 100.0))
+    ref = T("confidence_lr_modifiers")
+    assert ours.shape == ref.shape and torch.allclose(ours, ref, rtol=1e-6, atol=0)
+    assert float(ref.min()) >= 1.0 and float(ref.max()) <= 100.0
