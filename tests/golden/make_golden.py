@@ -12,6 +12,8 @@ exists in the reference tree as Python:
   PerPointAdam.step            reference scene/per_point_adam.py:34-100
   psnr                         reference utils/image_utils.py:17-19
   load_and_prepare_confidence  reference train.py:63-85 (function definition executed on its own)
+  GaussianModel                reference scene/gaussian_model.py:29-243 (create_from_pcd, init_RT_seq, activations,
+                               training_setup_pp, update_learning_rate, oneupSHdegree; module executed from its file)
 
 Run:  python tests/golden/make_golden.py
 """
@@ -153,3 +155,80 @@ out3 = dict(np.load(OUT))
 out3["confidence_raw"], out3["confidence_lr_modifiers"] = conf, lr_mod.numpy()
 np.savez_compressed(OUT, **out3)
 print("added confidence vectors:", len(out3), "arrays")
+
+# ---- GaussianModel (reference scene/gaussian_model.py:29-243): initialisation from a point cloud, parameter layouts,
+# activations, optimiser groups and LR schedule, produced by the reference's OWN class.  The module is executed from its
+# file with (a) `.cuda()` / device="cuda" rewritten to the CPU in memory, (b) stand-ins for the two imports that do not
+# exist here: `plyfile` (unused by the methods called) and `simple_knn._C.distCUDA2` (the exact 3-NN mean squared distance,
+# computed by oracle/knn_ref.py's float64 k-d tree), (c) `scene` registered as a bare namespace package so that
+# `scene.per_point_adam` loads without scene/__init__.py (which needs plyfile / PIL readers).
+import types  # noqa: E402
+from argparse import ArgumentParser  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import knn_ref  # noqa: E402
+
+knn_mod = types.ModuleType("simple_knn._C")
+knn_mod.distCUDA2 = lambda pts: knn_ref.dist2(pts)
+sys.modules["simple_knn"] = types.ModuleType("simple_knn")
+sys.modules["simple_knn._C"] = knn_mod
+ply_mod = types.ModuleType("plyfile")
+ply_mod.PlyData = ply_mod.PlyElement = object
+sys.modules["plyfile"] = ply_mod
+scene_pkg = types.ModuleType("scene")
+scene_pkg.__path__ = [os.path.join(REF, "scene")]
+sys.modules["scene"] = scene_pkg
+gm_path = os.path.join(REF, "scene", "gaussian_model.py")
+gm_src = open(gm_path).read().replace(".cuda()", "").replace('device="cuda"', 'device="cpu"')
+gm = types.ModuleType("ref_gaussian_model")
+exec(compile(gm_src, gm_path, "exec"), gm.__dict__)
+from arguments import OptimizationParams as RefOptimizationParams  # noqa: E402
+from utils.graphics_utils import BasicPointCloud, getWorld2View2  # noqa: E402
+
+g4 = torch.Generator().manual_seed(11)
+n_pts = 96
+pts = (torch.rand(n_pts, 3, generator=g4) * 2 - 1).numpy().astype(np.float32)
+cols = torch.rand(n_pts, 3, generator=g4).numpy().astype(np.float32)
+conf_lr = (1.0 + 99.0 * torch.rand(n_pts, 1, generator=g4)).float()
+
+
+class _Cam:  # the one attribute init_RT_seq reads (reference scene/cameras.py:52)
+    def __init__(self, R, t):
+        self.world_view_transform = torch.tensor(getWorld2View2(R, t, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+
+
+cam_R, cam_t = [], []
+for k in range(3):
+    a = 0.2 * (k - 1)
+    cam_R.append(np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float64))
+    cam_t.append(np.array([0.1 * k, -0.05 * k, 4.0 + 0.3 * k], dtype=np.float64))
+ref_model = gm.GaussianModel(3)
+ref_model.create_from_pcd(BasicPointCloud(points=pts, colors=cols, normals=np.zeros_like(pts)), 2.5)
+ref_model.init_RT_seq({1.0: [_Cam(R, t) for R, t in zip(cam_R, cam_t)]})
+ropt = RefOptimizationParams(ArgumentParser())
+ropt.iterations = 1000
+ref_model.training_setup_pp(ropt, conf_lr)
+out4 = dict(np.load(OUT))
+out4["gm_points"], out4["gm_colors"], out4["gm_conf_lr"] = pts, cols, conf_lr.numpy()
+out4["gm_cam_R"], out4["gm_cam_t"] = np.stack(cam_R), np.stack(cam_t)
+for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "P"):
+    out4["gm" + name if name.startswith("_") else "gm_" + name] = getattr(ref_model, name).detach().numpy().copy()
+out4["gm_get_scaling"], out4["gm_get_opacity"] = ref_model.get_scaling.detach().numpy(), ref_model.get_opacity.detach().numpy()
+out4["gm_get_features"] = ref_model.get_features.detach().numpy()
+out4["gm_get_rotation"] = ref_model.get_rotation.detach().numpy()
+torch.zeros = lambda *a, **k: _zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})  # general_utils: device="cuda"
+try:
+    out4["gm_get_covariance"] = ref_model.get_covariance(1.3).detach().numpy()
+finally:
+    torch.zeros = _zeros
+out4["gm_group_names"] = np.array([grp["name"] for grp in ref_model.optimizer.param_groups])
+lr_rows = []
+for it in (1, 2, 10, 500, 1000):
+    ref_model.update_learning_rate(it)
+    lr_rows.append([grp["lr"] for grp in ref_model.optimizer.param_groups])
+out4["gm_lr_iterations"], out4["gm_group_lrs"] = np.array([1, 2, 10, 500, 1000]), np.array(lr_rows, dtype=np.float64)
+ref_model.oneupSHdegree()
+out4["gm_sh_degree_after_oneup"] = np.array(ref_model.active_sh_degree)
+np.savez_compressed(OUT, **out4)
+print("added GaussianModel vectors:", len(out4), "arrays")

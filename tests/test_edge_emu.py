@@ -40,3 +40,44 @@ def test_tile_lists_sorted(emu, n, longer_than):
 
 def test_operator_error_behaviour(emu, tmp_path):
     edge_cases.check_operator_error_behaviour(emu, tmp_path)
+
+
+def test_gaussian_model_matches_reference_class(emu):
+    """scene.GaussianModel vs vectors produced by the reference's OWN GaussianModel (tests/golden/make_golden.py executes
+    reference scene/gaussian_model.py with its CUDA device strings rewritten): create_from_pcd layouts and values, pose
+    parameters, activations, packed covariance, optimiser group order / learning rates / schedule, SH degree step."""
+    import os
+    import numpy as np
+    import torch
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.camera import Camera
+    from instantsplat_amd.scene import GaussianModel
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k])
+    g = GaussianModel(3)
+    g.create_from_pcd(T("gm_points"), T("gm_colors"), 2.5, emu)
+    for name in ("_xyz", "_features_dc", "_features_rest", "_rotation", "_opacity"):
+        assert torch.equal(getattr(g, name).detach(), T("gm" + name)), name
+    # scales come from the 3-NN kernel (fp32) on one side and the float64 k-d tree on the other
+    assert torch.allclose(g._scaling.detach(), T("gm_scaling"), rtol=0, atol=2e-6)
+    cams = []
+    for k in range(3):
+        w2c = torch.eye(4, dtype=torch.float64)
+        w2c[:3, :3] = T("gm_cam_R")[k].t()          # getWorld2View2: rotation stored transposed (reference utils/graphics_utils.py:38-49)
+        w2c[:3, 3] = T("gm_cam_t")[k]
+        cams.append(Camera(k, w2c, 1.0, 0.8, 64, 48))
+    g.init_RT_seq(cams, emu)
+    assert torch.allclose(g.P.detach(), T("gm_P"), rtol=0, atol=1e-6)
+    g._scaling.data.copy_(T("gm_scaling"))          # compare the activations on identical raw values
+    assert torch.equal(g.get_scaling.detach(), T("gm_get_scaling")) and torch.equal(g.get_opacity.detach(), T("gm_get_opacity"))
+    assert torch.equal(g.get_features.detach(), T("gm_get_features")) and torch.equal(g.get_rotation.detach(), T("gm_get_rotation"))
+    assert torch.allclose(g.get_covariance(1.3).detach(), T("gm_get_covariance"), rtol=1e-5, atol=1e-9)
+    g.training_setup_pp(OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True), T("gm_conf_lr"))
+    assert [grp["name"] for grp in g.optimizer.param_groups] == list(G["gm_group_names"])
+    assert g.optimizer.param_groups[0]["per_point_lr"] is g.per_point_lr
+    for it, row in zip(G["gm_lr_iterations"], G["gm_group_lrs"]):
+        g.update_learning_rate(int(it))
+        ours = np.array([grp["lr"] for grp in g.optimizer.param_groups], dtype=np.float64)
+        assert np.allclose(ours, row, rtol=1e-12, atol=0), (it, ours, row)
+    g.oneupSHdegree()
+    assert g.active_sh_degree == int(G["gm_sh_degree_after_oneup"]) == 1
