@@ -14,6 +14,8 @@ exists in the reference tree as Python:
   load_and_prepare_confidence  reference train.py:63-85 (function definition executed on its own)
   GaussianModel                reference scene/gaussian_model.py:29-243 (create_from_pcd, init_RT_seq, activations,
                                training_setup_pp, update_learning_rate, oneupSHdegree; module executed from its file)
+  render()                     reference gaussian_renderer/__init__.py:23-144 — the arguments it passes to the rasterizer
+                               operator (recorded with a stand-in operator), default pipeline and both python-flag variants
 
 Run:  python tests/golden/make_golden.py
 """
@@ -232,3 +234,79 @@ ref_model.oneupSHdegree()
 out4["gm_sh_degree_after_oneup"] = np.array(ref_model.active_sh_degree)
 np.savez_compressed(OUT, **out4)
 print("added GaussianModel vectors:", len(out4), "arrays")
+
+# ---- render() glue (reference gaussian_renderer/__init__.py:23-144): what the reference hands to the rasterizer operator.
+# The operator itself does not exist here, so a recording stand-in is registered under its module name and the reference's
+# own render() is executed (device strings rewritten as above) for the default pipeline and both python-flag variants; the
+# recorded keyword arguments and settings are the golden values for instantsplat_amd.gaussian_renderer.render().
+import collections  # noqa: E402
+
+_FIELDS = ["image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix", "sh_degree",
+           "campos", "prefiltered", "debug"]
+_rec = {}
+
+
+class _RecordingRasterizer:
+    def __init__(self, raster_settings):
+        self.s = raster_settings
+
+    def __call__(self, **kw):
+        _rec.clear()
+        _rec.update(kw)
+        _rec["settings"] = self.s
+        return torch.zeros(3, self.s.image_height, self.s.image_width), torch.ones(kw["means3D"].shape[0], dtype=torch.int32)
+
+
+dgr_mod = types.ModuleType("diff_gaussian_rasterization")
+dgr_mod.GaussianRasterizationSettings = collections.namedtuple("GaussianRasterizationSettings", _FIELDS)
+dgr_mod.GaussianRasterizer = _RecordingRasterizer
+sys.modules["diff_gaussian_rasterization"] = dgr_mod
+gr_path = os.path.join(REF, "gaussian_renderer", "__init__.py")
+gr_src = open(gr_path).read().replace(".cuda()", "").replace('device="cuda"', 'device="cpu"')
+gr = types.ModuleType("ref_gaussian_renderer")
+exec(compile(gr_src, gr_path, "exec"), gr.__dict__)
+
+g5 = torch.Generator().manual_seed(13)
+with torch.no_grad():
+    ref_model._rotation.copy_(torch.randn(n_pts, 4, generator=g5) * (0.8 + 0.4 * torch.rand(n_pts, 1, generator=g5)))
+    ref_model._scaling.copy_(torch.log(torch.tensor(0.05)) + 0.5 * torch.randn(n_pts, 3, generator=g5))
+    ref_model._opacity.copy_(1.5 * torch.randn(n_pts, 1, generator=g5))
+    ref_model._features_dc.copy_(0.5 * torch.randn(n_pts, 1, 3, generator=g5))
+    ref_model._features_rest.copy_(0.1 * torch.randn(n_pts, 15, 3, generator=g5))
+    ref_model._xyz.add_(torch.tensor([0.0, 0.0, 4.0]))
+ref_model.active_sh_degree = 2
+pose7 = torch.tensor([0.9, 0.05, -0.1, 0.02, 0.1, -0.2, 0.3])   # un-normalised quaternion (w, x, y, z) + translation
+
+
+class _ViewCam:
+    FoVx, FoVy, image_height, image_width = 1.0, 0.8, 48, 64
+    projection_matrix = graphics_utils.getProjectionMatrix(0.01, 100.0, 1.0, 0.8).transpose(0, 1)
+    camera_center = torch.tensor([0.3, -0.2, 0.1])
+
+
+class _Pipe:
+    def __init__(self, cov, sh):
+        self.compute_cov3D_python, self.convert_SHs_python, self.debug = cov, sh, False
+
+
+out5 = dict(np.load(OUT))
+for k in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest"):
+    out5["render_in" + k] = getattr(ref_model, k).detach().numpy().copy()
+out5["render_in_pose"], out5["render_in_bg"] = pose7.numpy(), np.array([0.1, 0.2, 0.3], dtype=np.float32)
+out5["render_in_camera_center"] = _ViewCam.camera_center.numpy()
+torch.zeros = lambda *a, **k: _zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})  # general_utils: device="cuda"
+try:
+    for tag, (cov, shp) in {"default": (False, False), "cov_python": (True, False), "sh_python": (False, True)}.items():
+        gr.render(_ViewCam, ref_model, _Pipe(cov, shp), torch.tensor([0.1, 0.2, 0.3]), scaling_modifier=1.2, camera_pose=pose7)
+        for k in ("means3D", "means2D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp"):
+            v = _rec[k]
+            out5[f"render_{tag}_{k}"] = np.zeros(0, dtype=np.float32) if v is None else v.detach().numpy().copy()
+        s_ = _rec["settings"]
+        out5[f"render_{tag}_settings_scalars"] = np.array([s_.image_height, s_.image_width, s_.tanfovx, s_.tanfovy, s_.scale_modifier,
+                                                           s_.sh_degree, float(s_.prefiltered), float(s_.debug)], dtype=np.float64)
+        out5[f"render_{tag}_viewmatrix"], out5[f"render_{tag}_projmatrix"] = s_.viewmatrix.numpy(), s_.projmatrix.numpy()
+        out5[f"render_{tag}_campos"], out5[f"render_{tag}_bg"] = s_.campos.numpy(), s_.bg.numpy()
+finally:
+    torch.zeros = _zeros
+np.savez_compressed(OUT, **out5)
+print("added render() glue vectors:", len(out5), "arrays")

@@ -81,3 +81,71 @@ def test_gaussian_model_matches_reference_class(emu):
         assert np.allclose(ours, row, rtol=1e-12, atol=0), (it, ours, row)
     g.oneupSHdegree()
     assert g.active_sh_degree == int(G["gm_sh_degree_after_oneup"]) == 1
+
+
+def test_render_glue_hands_the_operator_what_the_reference_does(emu, monkeypatch):
+    """gaussian_renderer.render() vs the arguments the reference's OWN render() passes to the rasterizer operator
+    (recorded by tests/golden/make_golden.py with a stand-in operator; reference gaussian_renderer/__init__.py:50-135):
+    identity view / zero camera position, camera-frame means, raw Hamilton product of the rotations, activations, SH
+    features, and the cov3D / colour tensors of the two python-flag variants.  The default variant runs through the fused
+    pose kernel (emulated) and through the op-by-op glue."""
+    import os
+    import numpy as np
+    import torch
+    import instantsplat_amd.gaussian_renderer as gr
+    from instantsplat_amd.arguments import PipelineParams
+    from instantsplat_amd.scene import GaussianModel
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k])
+    rec = {}
+
+    class Recording:
+        def __init__(self, raster_settings):
+            self.s = raster_settings
+
+        def __call__(self, **kw):
+            rec.clear()
+            rec.update(kw)
+            rec["settings"] = self.s
+            return torch.zeros(3, self.s.image_height, self.s.image_width), torch.ones(kw["means3D"].shape[0], dtype=torch.int32)
+
+    monkeypatch.setattr(gr, "GaussianRasterizer", Recording)
+    g = GaussianModel(3)
+    for k in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest"):
+        setattr(g, k, torch.nn.Parameter(T("render_in" + k).clone()))
+    g.active_sh_degree = 2
+
+    class Cam:
+        FoVx, FoVy, image_height, image_width = 1.0, 0.8, 48, 64
+        projection_matrix = T("render_default_projmatrix")   # identity view: the settings' projmatrix IS the camera's
+        camera_center = T("render_in_camera_center")
+
+    pose, bg = T("render_in_pose"), T("render_in_bg")
+    close = lambda a, b: torch.allclose(a.detach().float().cpu(), b, rtol=2e-5, atol=2e-6)
+    for tag, cov, shp, fused in (("default", False, False, True), ("default", False, False, False),
+                                 ("cov_python", True, False, False), ("sh_python", False, True, False)):
+        monkeypatch.setattr(gr, "FUSED_GLUE", fused)
+        out = gr.render(Cam, g, PipelineParams(convert_SHs_python=shp, compute_cov3D_python=cov), bg, scaling_modifier=1.2,
+                        camera_pose=pose)
+        assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii"}
+        s = rec["settings"]
+        ours = np.array([s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree,
+                         float(s.prefiltered), float(s.debug)], dtype=np.float64)
+        assert np.allclose(ours, G[f"render_{tag}_settings_scalars"], rtol=1e-12), (tag, ours)
+        assert torch.equal(s.viewmatrix.cpu(), T(f"render_{tag}_viewmatrix")) and torch.equal(s.campos.cpu(), T(f"render_{tag}_campos"))
+        assert torch.equal(s.projmatrix.cpu(), T(f"render_{tag}_projmatrix")) and torch.equal(s.bg.cpu(), T(f"render_{tag}_bg"))
+        assert close(rec["means3D"], T(f"render_{tag}_means3D")), tag
+        assert close(rec["opacities"], T(f"render_{tag}_opacities")), tag
+        assert tuple(rec["means2D"].shape) == tuple(G[f"render_{tag}_means2D"].shape) and float(rec["means2D"].detach().abs().max()) == 0
+        for k in ("scales", "rotations", "cov3D_precomp", "colors_precomp"):
+            ref = T(f"render_{tag}_{k}")
+            if ref.numel() == 0:
+                assert rec.get(k) is None, (tag, k)
+            else:
+                assert close(rec[k], ref), (tag, k)
+        ref_shs = T(f"render_{tag}_shs")
+        if ref_shs.numel() == 0:
+            assert rec.get("shs") is None
+        else:
+            shs = rec["shs"] if rec.get("shs_rest") is None else torch.cat((rec["shs"], rec["shs_rest"]), dim=1)
+            assert torch.equal(shs.detach().cpu(), ref_shs), tag
