@@ -14,6 +14,7 @@ exists in the reference tree as Python:
   load_and_prepare_confidence  reference train.py:63-85 (function definition executed on its own)
   GaussianModel                reference scene/gaussian_model.py:29-243 (create_from_pcd, init_RT_seq, activations,
                                training_setup_pp, update_learning_rate, oneupSHdegree; module executed from its file)
+  Camera                       reference scene/cameras.py:17-57 (per-view constants from the reference's own class)
   render()                     reference gaussian_renderer/__init__.py:23-144 — the arguments it passes to the rasterizer
                                operator (recorded with a stand-in operator), default pipeline and both python-flag variants
 
@@ -310,3 +311,23 @@ finally:
     torch.zeros = _zeros
 np.savez_compressed(OUT, **out5)
 print("added render() glue vectors:", len(out5), "arrays")
+
+# ---- Camera (reference scene/cameras.py:17-57): per-view constants, from the reference's own class (device rewritten)
+cam_path = os.path.join(REF, "scene", "cameras.py")
+cm = types.ModuleType("ref_cameras")
+exec(compile(open(cam_path).read().replace(".cuda()", ""), cam_path, "exec"), cm.__dict__)
+g6 = torch.Generator().manual_seed(17)
+img = torch.rand(3, 20, 28, generator=g6) * 1.4 - 0.2          # exercises the clamp to [0, 1]
+a6 = 0.35
+R6 = np.array([[np.cos(a6), 0.0, np.sin(a6)], [0.0, 1.0, 0.0], [-np.sin(a6), 0.0, np.cos(a6)]]) @ \
+    np.array([[1.0, 0.0, 0.0], [0.0, np.cos(0.2), -np.sin(0.2)], [0.0, np.sin(0.2), np.cos(0.2)]])
+T6 = np.array([0.3, -0.4, 3.5])
+rc = cm.Camera(colmap_id=5, R=R6, T=T6, FoVx=1.05, FoVy=0.8, image=img, gt_alpha_mask=None, image_name="v", uid=2, data_device="cpu")
+out6 = dict(np.load(OUT))
+out6["camera_R"], out6["camera_T"], out6["camera_fov"], out6["camera_image_in"] = R6, T6, np.array([1.05, 0.8]), img.numpy()
+out6["camera_world_view_transform"], out6["camera_projection_matrix"] = rc.world_view_transform.numpy(), rc.projection_matrix.numpy()
+out6["camera_full_proj_transform"], out6["camera_center"] = rc.full_proj_transform.numpy(), rc.camera_center.numpy()
+out6["camera_original_image"] = rc.original_image.numpy()
+out6["camera_scalars"] = np.array([rc.image_width, rc.image_height, rc.znear, rc.zfar, rc.uid, rc.colmap_id], dtype=np.float64)
+np.savez_compressed(OUT, **out6)
+print("added Camera vectors:", len(out6), "arrays")

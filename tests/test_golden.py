@@ -87,3 +87,18 @@ def test_confidence_lr_modifiers_match_reference():
     ref = T("confidence_lr_modifiers")
     assert ours.shape == ref.shape and torch.allclose(ours, ref, rtol=1e-6, atol=0)
     assert float(ref.min()) >= 1.0 and float(ref.max()) <= 100.0
+
+
+def test_camera_constants_match_reference_class():
+    """instantsplat_amd.camera.Camera vs the reference's own Camera (scene/cameras.py:17-57, executed by make_golden.py)."""
+    R, Tv, fov = G["camera_R"], G["camera_T"], G["camera_fov"]
+    w2c = torch.eye(4, dtype=torch.float64)
+    w2c[:3, :3] = torch.from_numpy(R).t()     # getWorld2View2 stores R transposed (reference utils/graphics_utils.py:38-49)
+    w2c[:3, 3] = torch.from_numpy(Tv)
+    c = camera.Camera(2, w2c, float(fov[0]), float(fov[1]), 28, 20, image=T("camera_image_in"), colmap_id=5)
+    assert torch.allclose(c.world_view_transform, T("camera_world_view_transform"), rtol=0, atol=1e-7)
+    assert torch.allclose(c.projection_matrix, T("camera_projection_matrix"), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(c.full_proj_transform, T("camera_full_proj_transform"), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(c.camera_center, T("camera_center"), rtol=1e-5, atol=1e-6)
+    assert torch.equal(c.original_image, T("camera_original_image"))
+    assert [c.image_width, c.image_height, c.znear, c.zfar, c.uid, c.colmap_id] == list(G["camera_scalars"])
