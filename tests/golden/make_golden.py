@@ -16,7 +16,8 @@ exists in the reference tree as Python:
                                training_setup_pp, update_learning_rate, oneupSHdegree; module executed from its file)
   Camera                       reference scene/cameras.py:17-57 (per-view constants from the reference's own class)
   render()                     reference gaussian_renderer/__init__.py:23-144 — the arguments it passes to the rasterizer
-                               operator (recorded with a stand-in operator), default pipeline and both python-flag variants
+                               operator (recorded with a stand-in operator), default pipeline and both python-flag variants;
+                               and the gradients autograd carries back through that glue from a linear stand-in operator
 
 Run:  python tests/golden/make_golden.py
 """
@@ -331,3 +332,33 @@ out6["camera_original_image"] = rc.original_image.numpy()
 out6["camera_scalars"] = np.array([rc.image_width, rc.image_height, rc.znear, rc.zfar, rc.uid, rc.colmap_id], dtype=np.float64)
 np.savez_compressed(OUT, **out6)
 print("added Camera vectors:", len(out6), "arrays")
+
+# ---- gradients through the render() glue: the stand-in operator now returns an image that is LINEAR in the tensors it is
+# handed, with fixed random coefficients, so d(image.sum())/d(operator input) is known and autograd carries it through the
+# reference's own pose transform / activations back to the raw parameters and the 7-vector camera pose.
+g7 = torch.Generator().manual_seed(19)
+_coef = {k: torch.randn(*shape, generator=g7) for k, shape in
+         {"means3D": (n_pts, 3), "rotations": (n_pts, 4), "scales": (n_pts, 3), "opacities": (n_pts, 1)}.items()}
+
+
+class _LinearRasterizer(_RecordingRasterizer):
+    def __call__(self, **kw):
+        tot = sum((kw[k] * c).sum() for k, c in _coef.items())
+        return tot.expand(3, self.s.image_height, self.s.image_width) / (3 * self.s.image_height * self.s.image_width), \
+            torch.ones(kw["means3D"].shape[0], dtype=torch.int32)
+
+
+gr.GaussianRasterizer = _LinearRasterizer
+pose_leaf = pose7.clone().requires_grad_(True)
+for p_ in (ref_model._xyz, ref_model._rotation, ref_model._scaling, ref_model._opacity):
+    p_.grad = None
+res = gr.render(_ViewCam, ref_model, _Pipe(False, False), torch.tensor([0.1, 0.2, 0.3]), scaling_modifier=1.0, camera_pose=pose_leaf)
+res["render"].sum().backward()
+out7 = dict(np.load(OUT))
+for k, c in _coef.items():
+    out7["glue_coef_" + k] = c.numpy()
+for name in ("_xyz", "_rotation", "_scaling", "_opacity"):
+    out7["glue_grad" + name] = getattr(ref_model, name).grad.numpy().copy()
+out7["glue_grad_pose"] = pose_leaf.grad.numpy().copy()
+np.savez_compressed(OUT, **out7)
+print("added glue-gradient vectors:", len(out7), "arrays")
