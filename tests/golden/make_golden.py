@@ -15,6 +15,8 @@ exists in the reference tree as Python:
   GaussianModel                reference scene/gaussian_model.py:29-243 (create_from_pcd, init_RT_seq, activations,
                                training_setup_pp, update_learning_rate, oneupSHdegree; module executed from its file)
   Camera                       reference scene/cameras.py:17-57 (per-view constants from the reference's own class)
+  training()                   reference train.py:87-230 — the loop itself, executed around the fp32 C oracle as the operator:
+                               per-iteration losses, view order, LR schedule, optimizer steps, final parameters
   render()                     reference gaussian_renderer/__init__.py:23-144 — the arguments it passes to the rasterizer
                                operator (recorded with a stand-in operator), default pipeline and both python-flag variants;
                                and the gradients autograd carries back through that glue from a linear stand-in operator
@@ -362,3 +364,160 @@ for name in ("_xyz", "_rotation", "_scaling", "_opacity"):
 out7["glue_grad_pose"] = pose_leaf.grad.numpy().copy()
 np.savez_compressed(OUT, **out7)
 print("added glue-gradient vectors:", len(out7), "arrays")
+
+# ---- the training loop itself (reference train.py:87-230, `training()`): LR schedule, view sampling, render, loss,
+# backward, PerPointAdam step, the skipped optimizer step of the last iteration — driven by the reference's OWN function.
+# Only the function definition is taken from train.py (the file imports torchvision / tensorboard / the CUDA operators) and
+# executed with: the reference GaussianModel / render() / Camera / l1_loss / ssim / PerPointAdam / load_and_prepare_confidence
+# loaded above, a Scene stand-in that does what reference scene/__init__.py:85-101 does with an in-memory point cloud
+# (create_from_pcd + init_RT_seq), no-op logging, and — as the rasterizer operator, which does not exist — the fp32 C oracle
+# (oracle/gs_ref.py, operator calling convention).  The trajectory therefore pins the LOOP (everything around the operator).
+import random  # noqa: E402
+from instantsplat_amd.synthetic import syn_pointmap  # noqa: E402  (input data only: cameras, points, colours, confidence, pose noise)
+from oracle import gs_ref, raster_torch  # noqa: E402
+
+
+class _OracleRasterizer:
+    def __init__(self, raster_settings):
+        self.s = raster_settings
+
+    def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        return gs_ref.rasterize(means3D, means2D, opacities, self.s, shs=shs, colors_precomp=colors_precomp, scales=scales,
+                                rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+
+gr.GaussianRasterizationSettings = raster_torch.RasterSettings
+gr.GaussianRasterizer = _OracleRasterizer
+TL_V, TL_WM, TL_W, TL_H, TL_ITERS = 3, 6, 32, 24, 12
+sc8 = syn_pointmap(TL_V, TL_WM, TL_WM, TL_W, TL_H, seed=21)
+g8 = torch.Generator().manual_seed(23)
+pts_noisy = (sc8.points + 0.01 * torch.randn(sc8.points.shape, generator=g8)).numpy()
+col_noisy = (sc8.colors + 0.05 * torch.randn(sc8.colors.shape, generator=g8)).clamp(0, 1).numpy()
+bg8 = torch.zeros(3)
+init_scaling_delta = 0.35 * torch.randn(sc8.points.shape[0], 3, generator=g8)
+init_rotation = torch.randn(sc8.points.shape[0], 4, generator=g8)
+init_rotation = init_rotation / init_rotation.norm(dim=1, keepdim=True) * (0.9 + 0.2 * torch.rand(sc8.points.shape[0], 1, generator=g8))
+
+
+def _ref_cam(c, image):
+    w2c = c.world_view_transform.t().double().numpy()
+    return cm.Camera(colmap_id=c.colmap_id, R=w2c[:3, :3].T.copy(), T=w2c[:3, 3].copy(), FoVx=c.FoVx, FoVy=c.FoVy, image=image,
+                     gt_alpha_mask=None, image_name=f"v{c.uid}", uid=c.uid, data_device="cpu")
+
+
+teacher = gm.GaussianModel(3)
+teacher.create_from_pcd(BasicPointCloud(points=sc8.points.numpy(), colors=sc8.colors.numpy(), normals=np.zeros((sc8.points.shape[0], 3))),
+                        sc8.extent)
+blank = torch.zeros(3, TL_H, TL_W)
+teacher.init_RT_seq({1.0: [_ref_cam(c, blank) for c in sc8.cameras]})
+with torch.no_grad():
+    gts8 = [gr.render(_ref_cam(c, blank), teacher, _Pipe(False, False), bg8, camera_pose=teacher.get_RT(c.uid))["render"].clamp(0, 1)
+            for c in sc8.cameras]
+tl = {"models": [], "uids": [], "l1": [], "loss": []}
+
+
+class _TrackedModel(gm.GaussianModel):
+    def __init__(self, sh_degree):
+        super().__init__(sh_degree)
+        tl["models"].append(self)
+
+
+class _Scene:
+    def __init__(self, args, gaussians, *a, **k):
+        self.model_path, self.cameras_extent = args.model_path, sc8.extent
+        self.train_cameras = {1.0: [_ref_cam(c, gts8[c.uid]) for c in sc8.cameras]}
+        gaussians.create_from_pcd(BasicPointCloud(points=pts_noisy, colors=col_noisy, normals=np.zeros_like(pts_noisy)), self.cameras_extent, None)
+        gaussians.init_RT_seq(self.train_cameras)
+        with torch.no_grad():   # the estimated (noisy) camera poses an InstantSplat initialisation would hand over
+            P = gaussians.P.detach().clone()
+            P[:, :4] = pose_utils.quadmultiply(sc8.pose_noise_q, P[:, :4])
+            P[:, 4:] += sc8.pose_noise_t
+        gaussians.P = P.requires_grad_(True)
+        with torch.no_grad():
+            # create_from_pcd leaves every Gaussian isotropic with identity rotation, where d(loss)/d(rotation) is exactly
+            # zero and any two correct implementations hold different rounding noise there — which Adam's first steps turn
+            # into +-lr moves, so trajectories would separate for reasons that have nothing to do with the loop.  Start the
+            # student from anisotropic scales and generic rotations instead (a state any later iteration is in anyway).
+            gaussians._scaling.add_(init_scaling_delta)
+            gaussians._rotation.copy_(init_rotation)
+
+    def getTrainCameras(self, scale=1.0):
+        return self.train_cameras[scale]
+
+    def save(self, iteration):
+        pass
+
+
+class _Bar:
+    def __init__(self, *a, **k):
+        pass
+
+    def set_postfix(self, *a, **k):
+        pass
+
+    def update(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+class _Ev:
+    def record(self):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.0
+
+
+def _render_tracked(cam, *a, **k):
+    tl["uids"].append(cam.uid)
+    return gr.render(cam, *a, **k)
+
+
+def _l1_tracked(a, b):
+    v = loss_utils.l1_loss(a, b)
+    tl["l1"].append(v.detach())
+    return v
+
+
+def _ssim_tracked(a, b):
+    v = loss_utils.ssim(a, b)
+    tl["loss"].append(float((1.0 - 0.2) * tl["l1"][-1] + 0.2 * (1.0 - v.detach())))
+    return v
+
+
+tsrc = open(os.path.join(REF, "train.py")).read()
+tfn = next(n for n in ast.parse(tsrc).body if isinstance(n, ast.FunctionDef) and n.name == "training")
+tcode = ast.get_source_segment(tsrc, tfn).replace('device="cuda"', 'device="cpu"').replace("device='cuda'", "device='cpu'") \
+    .replace(".cuda()", "").replace("torch.cuda.Event(enable_timing = True)", "_Ev()")
+tns = {"os": os, "np": np, "torch": torch, "prepare_output_and_logger": lambda d: None, "GaussianModel": _TrackedModel,
+       "load_and_prepare_confidence": ns["load_and_prepare_confidence"], "Scene": _Scene, "save_pose": lambda *a, **k: None,
+       "tqdm": _Bar, "time": __import__("time").time, "randint": random.randint, "render": _render_tracked,
+       "l1_loss": _l1_tracked, "ssim": _ssim_tracked, "FUSED_SSIM_AVAILABLE": False, "save_time": lambda *a, **k: None,
+       "training_report": lambda *a, **k: None, "_Ev": _Ev}
+exec(compile(tcode, os.path.join(REF, "train.py"), "exec"), tns)
+topt = RefOptimizationParams(ArgumentParser())
+topt.iterations, topt.pp_optimizer, topt.optim_pose = TL_ITERS, True, True
+with tempfile.TemporaryDirectory() as td:
+    os.makedirs(os.path.join(td, f"sparse_{TL_V}", "0"))
+    np.save(os.path.join(td, f"sparse_{TL_V}", "0", "confidence_dsp.npy"), sc8.confidence.numpy())
+    dataset = types.SimpleNamespace(sh_degree=3, source_path=td, model_path=td, n_views=TL_V, white_background=False)
+    random.seed(0)
+    tns["training"](dataset, topt, _Pipe(False, False), [], [], [], None, -1)
+student = tl["models"][-1]
+out8 = dict(np.load(OUT))
+out8["loop_config"] = np.array([TL_V, TL_WM, TL_W, TL_H, TL_ITERS], dtype=np.int64)
+out8["loop_cam_w2c"] = np.stack([c.world_view_transform.t().numpy() for c in sc8.cameras])
+out8["loop_cam_fov"] = np.array([[c.FoVx, c.FoVy] for c in sc8.cameras])
+out8["loop_gt_images"] = np.stack([g_.numpy() for g_ in gts8])
+out8["loop_points_noisy"], out8["loop_colors_noisy"], out8["loop_extent"] = pts_noisy, col_noisy, np.float64(sc8.extent)
+out8["loop_confidence"], out8["loop_pose_noise_q"], out8["loop_pose_noise_t"] = sc8.confidence.numpy(), sc8.pose_noise_q.numpy(), sc8.pose_noise_t.numpy()
+out8["loop_init_scaling_delta"], out8["loop_init_rotation"] = init_scaling_delta.numpy(), init_rotation.numpy()
+out8["loop_view_uids"], out8["loop_losses"] = np.array(tl["uids"]), np.array(tl["loss"], dtype=np.float64)
+for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
+    out8["loop_final" + (name if name.startswith("_") else "_" + name)] = getattr(student, name).detach().numpy().copy()
+out8["loop_final_lrs"] = np.array([grp["lr"] for grp in student.optimizer.param_groups], dtype=np.float64)
+out8["loop_final_steps"] = np.array([student.optimizer.state[grp["params"][0]]["step"] for grp in student.optimizer.param_groups])
+np.savez_compressed(OUT, **out8)
+print("added training-loop vectors:", len(out8), "arrays; losses", np.round(out8["loop_losses"], 5), "views", out8["loop_view_uids"])

@@ -511,3 +511,87 @@ def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=Fa
     finally:
         BinningPolicy.slack, BinningPolicy.pad = 1.5, 16384
         BinningPolicy.reset("exact")
+
+
+def _reference_loop_start(dev):
+    """Initial state of the reference-driven training run recorded by tests/golden/make_golden.py (`loop_*` vectors)."""
+    import os
+    from instantsplat_amd.arguments import OptimizationParams, PipelineParams
+    from instantsplat_amd.camera import Camera
+    from instantsplat_amd.pose_utils import quadmultiply
+    from instantsplat_amd.scene import GaussianModel, confidence_to_lr_modifiers
+    from instantsplat_amd.train import TrainState
+    import random
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k])
+    V, _, W, H, iters = [int(x) for x in G["loop_config"]]
+    cams = [Camera(v, T("loop_cam_w2c")[v], float(G["loop_cam_fov"][v, 0]), float(G["loop_cam_fov"][v, 1]), W, H) for v in range(V)]
+    g = GaussianModel(3)
+    g.create_from_pcd(T("loop_points_noisy"), T("loop_colors_noisy"), float(G["loop_extent"]), dev)
+    with torch.no_grad():
+        # the recorded run took its initial scales from the float64 k-d tree (the reference's distCUDA2 does not exist here)
+        d2 = torch.clamp_min(knn_ref.dist2(T("loop_points_noisy")), 0.0000001)
+        assert torch.allclose(g._scaling.detach().cpu(), torch.log(torch.sqrt(d2))[:, None].repeat(1, 3), rtol=0, atol=2e-6)
+        g._scaling.copy_((torch.log(torch.sqrt(d2))[:, None].repeat(1, 3) + T("loop_init_scaling_delta")).to(dev))
+        g._rotation.copy_(T("loop_init_rotation").to(dev))
+    g.init_RT_seq(cams, dev)
+    with torch.no_grad():
+        P = g.P.detach().clone()
+        P[:, :4] = quadmultiply(T("loop_pose_noise_q").to(dev), P[:, :4])
+        P[:, 4:] += T("loop_pose_noise_t").to(dev)
+    g.P = P.requires_grad_(True)
+    opt = OptimizationParams(iterations=iters, pp_optimizer=True, optim_pose=True)
+    conf = confidence_to_lr_modifiers(T("loop_confidence").to(dev), scale=(1.0, 100.0))
+    g.training_setup_pp(opt, conf)
+    cams = [c.to(dev) for c in cams]
+    st = TrainState(g, cams, [T("loop_gt_images")[v].to(dev) for v in range(V)], torch.zeros(3, device=dev), opt, PipelineParams())
+    st.rng = random.Random(0)
+    return G, st, conf
+
+
+def check_training_loop_matches_reference_function(dev, fused_step):
+    """The device training loop vs a trajectory produced by the reference's OWN `training()` (train.py:87-230, executed by
+    make_golden.py around the fp32 C oracle as the rasterizer operator): per-iteration losses, the view order, the LR
+    schedule, the skipped optimizer step of the last iteration, and the final parameters.  The start is non-degenerate
+    (anisotropic scales, generic rotations), so no parameter has a structurally zero gradient for Adam to amplify."""
+    import random
+    from instantsplat_amd.train import FusedTrainer, train_iteration
+    G, st, _ = _reference_loop_start(dev)
+    iters = int(G["loop_config"][4])
+    rng, stack, order = random.Random(0), [], []
+    for _ in range(iters):          # reference train.py:152-157
+        if not stack:
+            stack = list(range(int(G["loop_config"][0])))
+        order.append(stack.pop(rng.randint(0, len(stack) - 1)))
+    assert order == list(G["loop_view_uids"])
+    if fused_step:
+        assert FusedTrainer.supported(st)
+    cuda = torch.device(dev).type == "cuda"
+    for it in range(iters):
+        l = float(train_iteration(st, fused_step=fused_step))
+        assert abs(l - G["loop_losses"][it]) <= (5e-3 if cuda else 1e-3) * G["loop_losses"][it], (it, l, G["loop_losses"][it])
+    g = st.gaussians
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
+        a, b = getattr(g, n).detach().cpu(), torch.from_numpy(G["loop_final" + (n if n.startswith("_") else "_" + n)])
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        assert rel <= (2e-3 if cuda else 1e-5), (n, rel)
+    assert np.allclose([grp["lr"] for grp in g.optimizer.param_groups], G["loop_final_lrs"], rtol=1e-12, atol=0)
+    assert [g.optimizer.state[grp["params"][0]]["step"] for grp in g.optimizer.param_groups] == list(G["loop_final_steps"])
+
+
+def check_oracle_trainer_matches_reference_function(dev):
+    """oracle/train_ref.CpuTrainer (the restated loop behind bench.py's cpu_baseline and the device-vs-oracle tests) vs the
+    same reference-driven trajectory: same operator (the C oracle) on both sides, so the losses agree to rounding."""
+    from oracle.train_ref import CpuTrainer
+    G, st, conf = _reference_loop_start(dev)   # (the initial scales go through the 3-NN kernel once, then CPU only)
+    g = st.gaussians
+    params = dict(xyz=g._xyz, f_dc=g._features_dc, f_rest=g._features_rest, opacity=g._opacity, scaling=g._scaling,
+                  rotation=g._rotation, pose=g.P)
+    g.update_learning_rate(1)
+    cpu = CpuTrainer(params, st.cameras, st.gt_images, conf, {grp["name"]: grp["lr"] for grp in g.optimizer.param_groups})
+    for it in range(1, int(G["loop_config"][4]) + 1):
+        g.update_learning_rate(it)
+        for grp, dgrp in zip(cpu.opt.param_groups, g.optimizer.param_groups):
+            grp["lr"] = dgrp["lr"]
+        l = cpu.iteration()
+        assert abs(l - G["loop_losses"][it - 1]) <= 5e-5 * G["loop_losses"][it - 1], (it, l, G["loop_losses"][it - 1])

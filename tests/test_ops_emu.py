@@ -110,3 +110,12 @@ def test_fused_step_gradients_equal_autograd(emu, degree):
 
 def test_two_one_call_train_iterations_match_cpu_oracle(emu):
     ops_util.check_train_matches_cpu_oracle(emu, iters=2, fused_step=True)
+
+
+@pytest.mark.parametrize("fused_step", [False, True])
+def test_training_loop_matches_reference_function(emu, fused_step):
+    ops_util.check_training_loop_matches_reference_function(emu, fused_step)
+
+
+def test_oracle_trainer_matches_reference_function(emu):
+    ops_util.check_oracle_trainer_matches_reference_function(emu)
