@@ -17,6 +17,8 @@ exists in the reference tree as Python:
   Camera                       reference scene/cameras.py:17-57 (per-view constants from the reference's own class)
   training()                   reference train.py:87-230 — the loop itself, executed around the fp32 C oracle as the operator:
                                per-iteration losses, view order, LR schedule, optimizer steps, final parameters
+  render_set_optimize()        reference render.py:99-186 — test-view pose tracking, executed the same way: pose sequence,
+                               masked-L1 losses, best pose, final rendering
   render()                     reference gaussian_renderer/__init__.py:23-144 — the arguments it passes to the rasterizer
                                operator (recorded with a stand-in operator), default pipeline and both python-flag variants;
                                and the gradients autograd carries back through that glue from a linear stand-in operator
@@ -521,3 +523,68 @@ out8["loop_final_lrs"] = np.array([grp["lr"] for grp in student.optimizer.param_
 out8["loop_final_steps"] = np.array([student.optimizer.state[grp["params"][0]]["step"] for grp in student.optimizer.param_groups])
 np.savez_compressed(OUT, **out8)
 print("added training-loop vectors:", len(out8), "arrays; losses", np.round(out8["loop_losses"], 5), "views", out8["loop_view_uids"])
+
+# ---- test-view pose tracking (reference render.py:99-186, `render_set_optimize`): Gaussians frozen, Adam on (t, q) with
+# weight decay and cosine annealing, masked L1, best-loss pose kept — again the reference's own function, taken from its
+# file and run around the C oracle operator, on the student the training run above produced.
+rsrc = open(os.path.join(REF, "render.py")).read()
+rfn = next(n for n in ast.parse(rsrc).body if isinstance(n, ast.FunctionDef) and n.name == "render_set_optimize")
+rcode = ast.get_source_segment(rsrc, rfn).replace('device="cuda"', 'device="cpu"').replace(".cuda()", "")
+trk = {"poses": [], "losses": [], "saved": []}
+
+
+class _Tqdm:
+    def __init__(self, iterable=None, **k):
+        self.it = iterable
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def update(self, *a, **k):
+        pass
+
+    def set_postfix(self, *a, **k):
+        pass
+
+
+def _render_pose_tracked(cam, pc, pipe, bg, camera_pose=None, **k):
+    trk["poses"].append(camera_pose.detach().clone())
+    return gr.render(cam, pc, pipe, bg, camera_pose=camera_pose, **k)
+
+
+def _l1_mask_tracked(a, b, m):
+    v = loss_utils.l1_loss_mask(a, b, m)
+    trk["losses"].append(float(v))
+    return v
+
+
+tv_stub = types.SimpleNamespace(utils=types.SimpleNamespace(save_image=lambda img, path: trk["saved"].append(img.detach().clone())))
+TRACK_ITERS = 15
+rns = {"os": os, "makedirs": os.makedirs, "tqdm": _Tqdm, "get_tensor_from_camera": pose_utils.get_tensor_from_camera, "torch": torch,
+       "render": _render_pose_tracked, "l1_loss_mask": _l1_mask_tracked, "torchvision": tv_stub,
+       "args": types.SimpleNamespace(optim_test_pose_iter=TRACK_ITERS, test_fps=False), "perf_counter": __import__("time").perf_counter,
+       "json": __import__("json")}
+exec(compile(rcode, os.path.join(REF, "render.py"), "exec"), rns)
+true_cam = sc8.cameras[1]
+w2c_true = true_cam.world_view_transform.t().double()
+ang = np.radians(1.5)
+dR = torch.tensor([[np.cos(ang), 0.0, np.sin(ang), 0.0], [0.0, 1.0, 0.0, 0.0], [-np.sin(ang), 0.0, np.cos(ang), 0.0], [0.0, 0.0, 0.0, 1.0]])
+w2c_guess = dR @ w2c_true
+w2c_guess[:3, 3] += torch.tensor([0.03, -0.02, 0.04], dtype=torch.float64)
+guess_cam = cm.Camera(colmap_id=9, R=w2c_guess[:3, :3].numpy().T.copy(), T=w2c_guess[:3, 3].numpy().copy(), FoVx=true_cam.FoVx,
+                      FoVy=true_cam.FoVy, image=gts8[1], gt_alpha_mask=None, image_name="track", uid=0, data_device="cpu")
+with tempfile.TemporaryDirectory() as td:
+    rns["render_set_optimize"](td, "test", 12, [guess_cam], student, _Pipe(False, False), bg8)
+out9 = dict(np.load(OUT))
+out9["track_w2c_guess"], out9["track_gt"], out9["track_iters"] = w2c_guess.float().numpy(), gts8[1].numpy(), np.array(TRACK_ITERS)
+out9["track_pose_sequence"] = torch.stack(trk["poses"]).numpy()          # pose used by each of the num_iter renders + the final one
+out9["track_losses"] = np.array(trk["losses"], dtype=np.float64)
+out9["track_optimal_pose"], out9["track_final_render"] = trk["poses"][-1].numpy(), trk["saved"][0].numpy()
+np.savez_compressed(OUT, **out9)
+print("added pose-tracking vectors:", len(out9), "arrays; losses", np.round(out9["track_losses"], 5))

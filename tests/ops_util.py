@@ -595,3 +595,44 @@ def check_oracle_trainer_matches_reference_function(dev):
             grp["lr"] = dgrp["lr"]
         l = cpu.iteration()
         assert abs(l - G["loop_losses"][it - 1]) <= 5e-5 * G["loop_losses"][it - 1], (it, l, G["loop_losses"][it - 1])
+
+
+def check_pose_tracking_matches_reference_function(dev):
+    """pose_tracking.optimize_view_pose vs the reference's own `render_set_optimize` (render.py:99-186, executed by
+    make_golden.py around the C oracle operator on the student of the recorded training run): the pose handed to every
+    render of the 15 tracking iterations, the masked-L1 losses, the best pose and its final rendering."""
+    import os
+    from instantsplat_amd.arguments import PipelineParams
+    from instantsplat_amd.camera import Camera
+    from instantsplat_amd.scene import GaussianModel
+    from instantsplat_amd import pose_tracking
+    import instantsplat_amd.gaussian_renderer as gr
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k])
+    _, _, W, H, _ = [int(x) for x in G["loop_config"]]
+    g = GaussianModel(3)
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        setattr(g, n, torch.nn.Parameter(T("loop_final" + n).clone().to(dev)))
+    view = Camera(0, T("track_w2c_guess"), float(G["loop_cam_fov"][1, 0]), float(G["loop_cam_fov"][1, 1]), W, H, image=T("track_gt")).to(dev)
+    poses = []
+    real_render = gr.render
+
+    def recording_render(cam, pc, pipe, bg, camera_pose=None, **k):
+        poses.append(camera_pose.detach().cpu().clone())
+        return real_render(cam, pc, pipe, bg, camera_pose=camera_pose, **k)
+
+    pose_tracking.render = recording_render
+    try:
+        res = pose_tracking.render_set_optimize([view], g, PipelineParams(), torch.zeros(3, device=dev), num_iter=int(G["track_iters"]))[0]
+    finally:
+        pose_tracking.render = real_render
+    cuda = torch.device(dev).type == "cuda"
+    ref_seq = T("track_pose_sequence")
+    assert len(poses) == ref_seq.shape[0]
+    assert float((torch.stack(poses) - ref_seq).abs().max()) <= (5e-4 if cuda else 2e-5)
+    assert abs(res["initial_loss"] - G["track_losses"][0]) <= 1e-4 * G["track_losses"][0]
+    assert abs(res["best_loss"] - G["track_losses"].min()) <= (2e-3 if cuda else 2e-4) * G["track_losses"].min()
+    assert float((res["pose"].cpu() - T("track_optimal_pose")).abs().max()) <= (5e-4 if cuda else 2e-5)
+    assert float((res["render"].cpu() - T("track_final_render")).abs().max()) <= (5e-3 if cuda else 2e-4)
+    for t in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation):
+        assert not t.requires_grad

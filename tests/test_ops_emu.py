@@ -119,3 +119,7 @@ def test_training_loop_matches_reference_function(emu, fused_step):
 
 def test_oracle_trainer_matches_reference_function(emu):
     ops_util.check_oracle_trainer_matches_reference_function(emu)
+
+
+def test_pose_tracking_matches_reference_function(emu):
+    ops_util.check_pose_tracking_matches_reference_function(emu)
