@@ -17,6 +17,7 @@ exists in the reference tree as Python:
   Camera                       reference scene/cameras.py:17-57 (per-view constants from the reference's own class)
   training()                   reference train.py:87-230 — the loop itself, executed around the fp32 C oracle as the operator:
                                per-iteration losses, view order, LR schedule, optimizer steps, final parameters
+  save_pose()                  reference train.py:46-60
   render_set_optimize()        reference render.py:99-186 — test-view pose tracking, executed the same way: pose sequence,
                                masked-L1 losses, best pose, final rendering
   render()                     reference gaussian_renderer/__init__.py:23-144 — the arguments it passes to the rasterizer
@@ -588,3 +589,16 @@ out9["track_losses"] = np.array(trk["losses"], dtype=np.float64)
 out9["track_optimal_pose"], out9["track_final_render"] = trk["poses"][-1].numpy(), trk["saved"][0].numpy()
 np.savez_compressed(OUT, **out9)
 print("added pose-tracking vectors:", len(out9), "arrays; losses", np.round(out9["track_losses"], 5))
+
+# ---- pose export (reference train.py:46-60, `save_pose`): [V,7] poses -> [V,4,4] ordered by COLMAP id
+sfn = next(n for n in ast.parse(tsrc).body if isinstance(n, ast.FunctionDef) and n.name == "save_pose")
+sns = {"np": np, "torch": torch, "get_camera_from_tensor": pose_utils.get_camera_from_tensor}
+exec(compile(ast.Module(body=[sfn], type_ignores=[]), os.path.join(REF, "train.py"), "exec"), sns)
+ids10 = [3, 1, 2]
+with tempfile.TemporaryDirectory() as td:
+    sns["save_pose"](os.path.join(td, "pose_optimized.npy"), student.P, [types.SimpleNamespace(colmap_id=i) for i in ids10])
+    saved10 = np.load(os.path.join(td, "pose_optimized.npy"))
+out10 = dict(np.load(OUT))
+out10["save_pose_in"], out10["save_pose_colmap_ids"], out10["save_pose_out"] = student.P.detach().numpy().copy(), np.array(ids10), saved10
+np.savez_compressed(OUT, **out10)
+print("added save_pose vectors:", len(out10), "arrays")

@@ -67,3 +67,12 @@ def test_save_pose_orders_by_colmap_id(tmp_path):
     io.save_pose(tmp_path / "pose_optimized.npy", poses, colmap_ids=[2, 1])
     a = np.load(tmp_path / "pose_optimized.npy")
     assert a.shape == (2, 4, 4) and np.allclose(a[0, :3, 3], [4, 5, 6]) and np.allclose(a[1, :3, 3], [1, 2, 3])
+
+
+def test_save_pose_matches_reference_function(tmp_path):
+    """io.save_pose vs the output of the reference's own save_pose (train.py:46-60, executed by make_golden.py)."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    io.save_pose(tmp_path / "pose_optimized.npy", torch.from_numpy(G["save_pose_in"]), colmap_ids=[int(i) for i in G["save_pose_colmap_ids"]])
+    ours = np.load(tmp_path / "pose_optimized.npy")
+    assert ours.shape == G["save_pose_out"].shape and ours.dtype == G["save_pose_out"].dtype
+    assert np.allclose(ours, G["save_pose_out"], rtol=0, atol=1e-7)
