@@ -500,15 +500,31 @@ tns = {"os": os, "np": np, "torch": torch, "prepare_output_and_logger": lambda d
        "l1_loss": _l1_tracked, "ssim": _ssim_tracked, "FUSED_SSIM_AVAILABLE": False, "save_time": lambda *a, **k: None,
        "training_report": lambda *a, **k: None, "_Ev": _Ev}
 exec(compile(tcode, os.path.join(REF, "train.py"), "exec"), tns)
-topt = RefOptimizationParams(ArgumentParser())
-topt.iterations, topt.pp_optimizer, topt.optim_pose = TL_ITERS, True, True
-with tempfile.TemporaryDirectory() as td:
-    os.makedirs(os.path.join(td, f"sparse_{TL_V}", "0"))
-    np.save(os.path.join(td, f"sparse_{TL_V}", "0", "confidence_dsp.npy"), sc8.confidence.numpy())
-    dataset = types.SimpleNamespace(sh_degree=3, source_path=td, model_path=td, n_views=TL_V, white_background=False)
-    random.seed(0)
-    tns["training"](dataset, topt, _Pipe(False, False), [], [], [], None, -1)
-student = tl["models"][-1]
+def _run_reference_training(prefix, pp_optimizer, optim_pose, iters):
+    for k in ("models", "uids", "l1", "loss"):
+        tl[k].clear()
+    topt = RefOptimizationParams(ArgumentParser())
+    topt.iterations, topt.pp_optimizer, topt.optim_pose = iters, pp_optimizer, optim_pose
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, f"sparse_{TL_V}", "0"))
+        np.save(os.path.join(td, f"sparse_{TL_V}", "0", "confidence_dsp.npy"), sc8.confidence.numpy())
+        dataset = types.SimpleNamespace(sh_degree=3, source_path=td, model_path=td, n_views=TL_V, white_background=False)
+        random.seed(0)
+        tns["training"](dataset, topt, _Pipe(False, False), [], [], [], None, -1)
+    model = tl["models"][-1]
+    o = dict(np.load(OUT))
+    o[prefix + "_view_uids"], o[prefix + "_losses"] = np.array(tl["uids"]), np.array(tl["loss"], dtype=np.float64)
+    for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
+        o[prefix + "_final" + (name if name.startswith("_") else "_" + name)] = getattr(model, name).detach().numpy().copy()
+    o[prefix + "_final_lrs"] = np.array([grp["lr"] for grp in model.optimizer.param_groups], dtype=np.float64)
+    o[prefix + "_final_steps"] = np.array([model.optimizer.state[grp["params"][0]].get("step", 0) if grp["params"][0] in model.optimizer.state
+                                            else 0 for grp in model.optimizer.param_groups])
+    o[prefix + "_flags"] = np.array([int(pp_optimizer), int(optim_pose), iters])
+    np.savez_compressed(OUT, **o)
+    print("added training-loop vectors", prefix, len(o), "arrays; losses", np.round(o[prefix + "_losses"], 5), "views", o[prefix + "_view_uids"])
+    return model
+
+
 out8 = dict(np.load(OUT))
 out8["loop_config"] = np.array([TL_V, TL_WM, TL_W, TL_H, TL_ITERS], dtype=np.int64)
 out8["loop_cam_w2c"] = np.stack([c.world_view_transform.t().numpy() for c in sc8.cameras])
@@ -517,13 +533,10 @@ out8["loop_gt_images"] = np.stack([g_.numpy() for g_ in gts8])
 out8["loop_points_noisy"], out8["loop_colors_noisy"], out8["loop_extent"] = pts_noisy, col_noisy, np.float64(sc8.extent)
 out8["loop_confidence"], out8["loop_pose_noise_q"], out8["loop_pose_noise_t"] = sc8.confidence.numpy(), sc8.pose_noise_q.numpy(), sc8.pose_noise_t.numpy()
 out8["loop_init_scaling_delta"], out8["loop_init_rotation"] = init_scaling_delta.numpy(), init_rotation.numpy()
-out8["loop_view_uids"], out8["loop_losses"] = np.array(tl["uids"]), np.array(tl["loss"], dtype=np.float64)
-for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
-    out8["loop_final" + (name if name.startswith("_") else "_" + name)] = getattr(student, name).detach().numpy().copy()
-out8["loop_final_lrs"] = np.array([grp["lr"] for grp in student.optimizer.param_groups], dtype=np.float64)
-out8["loop_final_steps"] = np.array([student.optimizer.state[grp["params"][0]]["step"] for grp in student.optimizer.param_groups])
 np.savez_compressed(OUT, **out8)
-print("added training-loop vectors:", len(out8), "arrays; losses", np.round(out8["loop_losses"], 5), "views", out8["loop_view_uids"])
+# second configuration first (plain Adam, poses fixed: reference train.py:98-101,146-147), then the one the scripts run
+_run_reference_training("loopb", False, False, 8)
+student = _run_reference_training("loop", True, True, TL_ITERS)
 
 # ---- test-view pose tracking (reference render.py:99-186, `render_set_optimize`): Gaussians frozen, Adam on (t, q) with
 # weight decay and cosine annealing, masked L1, best-loss pose kept — again the reference's own function, taken from its

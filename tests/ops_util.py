@@ -513,8 +513,9 @@ def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=Fa
         BinningPolicy.reset("exact")
 
 
-def _reference_loop_start(dev):
-    """Initial state of the reference-driven training run recorded by tests/golden/make_golden.py (`loop_*` vectors)."""
+def _reference_loop_start(dev, run="loop"):
+    """Initial state of a reference-driven training run recorded by tests/golden/make_golden.py (`loop_*` inputs; run "loop" =
+    --pp_optimizer --optim_pose, 12 iterations; run "loopb" = plain Adam with fixed poses, 8 iterations)."""
     import os
     from instantsplat_amd.arguments import OptimizationParams, PipelineParams
     from instantsplat_amd.camera import Camera
@@ -524,7 +525,8 @@ def _reference_loop_start(dev):
     import random
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
     T = lambda k: torch.from_numpy(G[k])
-    V, _, W, H, iters = [int(x) for x in G["loop_config"]]
+    V, _, W, H, _ = [int(x) for x in G["loop_config"]]
+    pp, optim_pose, iters = [int(x) for x in G[run + "_flags"]]
     cams = [Camera(v, T("loop_cam_w2c")[v], float(G["loop_cam_fov"][v, 0]), float(G["loop_cam_fov"][v, 1]), W, H) for v in range(V)]
     g = GaussianModel(3)
     g.create_from_pcd(T("loop_points_noisy"), T("loop_colors_noisy"), float(G["loop_extent"]), dev)
@@ -540,43 +542,47 @@ def _reference_loop_start(dev):
         P[:, :4] = quadmultiply(T("loop_pose_noise_q").to(dev), P[:, :4])
         P[:, 4:] += T("loop_pose_noise_t").to(dev)
     g.P = P.requires_grad_(True)
-    opt = OptimizationParams(iterations=iters, pp_optimizer=True, optim_pose=True)
+    opt = OptimizationParams(iterations=iters, pp_optimizer=bool(pp), optim_pose=bool(optim_pose))
     conf = confidence_to_lr_modifiers(T("loop_confidence").to(dev), scale=(1.0, 100.0))
-    g.training_setup_pp(opt, conf)
+    if pp:
+        g.training_setup_pp(opt, conf)
+    else:
+        g.training_setup(opt)            # reference train.py:98-101
     cams = [c.to(dev) for c in cams]
     st = TrainState(g, cams, [T("loop_gt_images")[v].to(dev) for v in range(V)], torch.zeros(3, device=dev), opt, PipelineParams())
     st.rng = random.Random(0)
     return G, st, conf
 
 
-def check_training_loop_matches_reference_function(dev, fused_step):
+def check_training_loop_matches_reference_function(dev, fused_step, run="loop"):
     """The device training loop vs a trajectory produced by the reference's OWN `training()` (train.py:87-230, executed by
     make_golden.py around the fp32 C oracle as the rasterizer operator): per-iteration losses, the view order, the LR
     schedule, the skipped optimizer step of the last iteration, and the final parameters.  The start is non-degenerate
     (anisotropic scales, generic rotations), so no parameter has a structurally zero gradient for Adam to amplify."""
     import random
     from instantsplat_amd.train import FusedTrainer, train_iteration
-    G, st, _ = _reference_loop_start(dev)
-    iters = int(G["loop_config"][4])
+    G, st, _ = _reference_loop_start(dev, run)
+    iters = int(G[run + "_flags"][2])
     rng, stack, order = random.Random(0), [], []
     for _ in range(iters):          # reference train.py:152-157
         if not stack:
             stack = list(range(int(G["loop_config"][0])))
         order.append(stack.pop(rng.randint(0, len(stack) - 1)))
-    assert order == list(G["loop_view_uids"])
+    assert order == list(G[run + "_view_uids"])
     if fused_step:
         assert FusedTrainer.supported(st)
     cuda = torch.device(dev).type == "cuda"
     for it in range(iters):
         l = float(train_iteration(st, fused_step=fused_step))
-        assert abs(l - G["loop_losses"][it]) <= (5e-3 if cuda else 1e-3) * G["loop_losses"][it], (it, l, G["loop_losses"][it])
+        assert abs(l - G[run + "_losses"][it]) <= (5e-3 if cuda else 1e-3) * G[run + "_losses"][it], (it, l, G[run + "_losses"][it])
     g = st.gaussians
     for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
-        a, b = getattr(g, n).detach().cpu(), torch.from_numpy(G["loop_final" + (n if n.startswith("_") else "_" + n)])
+        a, b = getattr(g, n).detach().cpu(), torch.from_numpy(G[run + "_final" + (n if n.startswith("_") else "_" + n)])
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         assert rel <= (2e-3 if cuda else 1e-5), (n, rel)
-    assert np.allclose([grp["lr"] for grp in g.optimizer.param_groups], G["loop_final_lrs"], rtol=1e-12, atol=0)
-    assert [g.optimizer.state[grp["params"][0]]["step"] for grp in g.optimizer.param_groups] == list(G["loop_final_steps"])
+    assert np.allclose([grp["lr"] for grp in g.optimizer.param_groups], G[run + "_final_lrs"], rtol=1e-12, atol=0)
+    steps = [int(g.optimizer.state.get(grp["params"][0], {}).get("step", 0)) for grp in g.optimizer.param_groups]
+    assert steps == [int(x) for x in G[run + "_final_steps"]], steps   # a fixed pose tensor never gets optimizer state
 
 
 def check_oracle_trainer_matches_reference_function(dev):

@@ -112,9 +112,9 @@ def test_two_one_call_train_iterations_match_cpu_oracle(emu):
     ops_util.check_train_matches_cpu_oracle(emu, iters=2, fused_step=True)
 
 
-@pytest.mark.parametrize("fused_step", [False, True])
-def test_training_loop_matches_reference_function(emu, fused_step):
-    ops_util.check_training_loop_matches_reference_function(emu, fused_step)
+@pytest.mark.parametrize("fused_step,run", [(False, "loop"), (True, "loop"), (False, "loopb")])
+def test_training_loop_matches_reference_function(emu, fused_step, run):
+    ops_util.check_training_loop_matches_reference_function(emu, fused_step, run)
 
 
 def test_oracle_trainer_matches_reference_function(emu):
