@@ -1,0 +1,152 @@
+"""CPU tier, build container only (skipped where /root/reference is absent): the drop-in of INTEGRATION.md section 1.
+
+The reference's OWN `training()` (train.py:87-230), `render()` (gaussian_renderer/__init__.py), `GaussianModel`,
+`Camera`, `PerPointAdam` and confidence loader are executed from their files, with `diff_gaussian_rasterization`,
+`simple_knn._C` and `fused_ssim` resolved to instantsplat_amd's packages through `sys.modules` exactly as the integration
+note prescribes.  Two things differ from a GPU run, both forced by the CPU tier: the packages are routed to the SIMT-emulated
+build of the unmodified kernels (tests/emu), and the reference's hard-coded "cuda" device strings are rewritten to "cpu" in
+memory.  The resulting trajectory must equal the golden one (tests/golden/make_golden.py: the same reference code around the
+C oracle operator): the reference cannot tell our operators from the ones it was written for."""
+import ast
+import os
+import random
+import sys
+import tempfile
+import types
+from argparse import ArgumentParser
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "scene")), reason="reference tree not present")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_CPU = lambda src: src.replace('device="cuda"', 'device="cpu"').replace("device='cuda'", "device='cpu'").replace(".cuda()", "")
+
+
+def _exec_file(path, name, rewrite=True):
+    mod = types.ModuleType(name)
+    src = open(path).read()
+    exec(compile(_CPU(src) if rewrite else src, path, "exec"), mod.__dict__)
+    return mod
+
+
+@pytest.fixture()
+def reference_modules_cleanup():
+    yield
+    for k in [k for k, m in sys.modules.items() if getattr(m, "__file__", None) and str(m.__file__).startswith(REF)]:
+        del sys.modules[k]
+
+
+def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup):
+    import instantsplat_amd.diff_gaussian_rasterization as dgr
+    import instantsplat_amd.fused_ssim as fs
+    import instantsplat_amd.simple_knn as sk
+    import instantsplat_amd.simple_knn._C as skc
+    G = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k])
+    V, _, W, H, iters = [int(x) for x in G["loop_config"]]
+
+    # ---- alias the operator packages
+    monkeypatch.syspath_prepend(REF)
+    for name, mod in (("diff_gaussian_rasterization", dgr), ("simple_knn", sk), ("simple_knn._C", skc), ("fused_ssim", fs)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    # things of the reference tree that cannot be imported here and are not on the path under test
+    ply = types.ModuleType("plyfile")
+    ply.PlyData = ply.PlyElement = object
+    monkeypatch.setitem(sys.modules, "plyfile", ply)
+    scene_pkg = types.ModuleType("scene")          # bare namespace: scene/__init__.py pulls in the dataset readers (PIL, plyfile)
+    scene_pkg.__path__ = [os.path.join(REF, "scene")]
+    monkeypatch.setitem(sys.modules, "scene", scene_pkg)
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k == "arguments"]:
+        monkeypatch.delitem(sys.modules, m)        # the reference's `utils` / `arguments` packages, not anything cached
+    _zeros = torch.zeros
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: _zeros(*a, **{kk: ("cpu" if (kk == "device" and vv == "cuda") else vv)
+                                                                    for kk, vv in k.items()}))
+    from utils import loss_utils, pose_utils          # reference
+    from utils.graphics_utils import BasicPointCloud  # reference
+    from arguments import OptimizationParams          # reference
+    gm = _exec_file(os.path.join(REF, "scene", "gaussian_model.py"), "ref_gaussian_model")
+    monkeypatch.setitem(sys.modules, "scene.gaussian_model", gm)
+    gr = _exec_file(os.path.join(REF, "gaussian_renderer", "__init__.py"), "ref_gaussian_renderer")
+    cm = _exec_file(os.path.join(REF, "scene", "cameras.py"), "ref_cameras")
+    assert gr.GaussianRasterizer is dgr.GaussianRasterizer and gm.distCUDA2 is skc.distCUDA2   # ours, through the aliases
+
+    tsrc = open(os.path.join(REF, "train.py")).read()
+    fns = {n.name: n for n in ast.parse(tsrc).body if isinstance(n, ast.FunctionDef)}
+    track = {"models": [], "loss": [], "uids": []}
+
+    class TrackedModel(gm.GaussianModel):
+        def __init__(self, sh_degree):
+            super().__init__(sh_degree)
+            track["models"].append(self)
+
+    def ref_cam(v, image):
+        w2c = T("loop_cam_w2c")[v].double().numpy()
+        return cm.Camera(colmap_id=v + 1, R=w2c[:3, :3].T.copy(), T=w2c[:3, 3].copy(), FoVx=float(G["loop_cam_fov"][v, 0]),
+                         FoVy=float(G["loop_cam_fov"][v, 1]), image=image, gt_alpha_mask=None, image_name=f"v{v}", uid=v, data_device="cpu")
+
+    class Scene:   # what reference scene/__init__.py:85-101 does, from the in-memory point cloud of the golden run
+        def __init__(self, args, gaussians, *a, **k):
+            self.model_path, self.cameras_extent = args.model_path, float(G["loop_extent"])
+            self.train_cameras = {1.0: [ref_cam(v, T("loop_gt_images")[v]) for v in range(V)]}
+            pts = G["loop_points_noisy"]
+            gaussians.create_from_pcd(BasicPointCloud(points=pts, colors=G["loop_colors_noisy"], normals=np.zeros_like(pts)),
+                                      self.cameras_extent, None)
+            gaussians.init_RT_seq(self.train_cameras)
+            with torch.no_grad():
+                P = gaussians.P.detach().clone()
+                P[:, :4] = pose_utils.quadmultiply(T("loop_pose_noise_q"), P[:, :4])
+                P[:, 4:] += T("loop_pose_noise_t")
+                gaussians._scaling.add_(T("loop_init_scaling_delta"))
+                gaussians._rotation.copy_(T("loop_init_rotation"))
+            gaussians.P = P.requires_grad_(True)
+
+        def getTrainCameras(self, scale=1.0):
+            return self.train_cameras[scale]
+
+    class Quiet:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            return lambda *a, **k: 0.0
+
+    def fused_ssim_tracked(a, b):          # train.py:173 — OUR fused_ssim through the alias; the loss value is recorded
+        v = fs.fused_ssim(a, b)
+        l1 = loss_utils.l1_loss(a[0], b[0])
+        track["loss"].append(float(((1.0 - 0.2) * l1 + 0.2 * (1.0 - v)).detach()))
+        return v
+
+    def render_tracked(cam, *a, **k):
+        track["uids"].append(cam.uid)
+        return gr.render(cam, *a, **k)
+
+    code = _CPU(ast.get_source_segment(tsrc, fns["training"])).replace("torch.cuda.Event(enable_timing = True)", "Quiet()")
+    conf_ns = {"np": np, "torch": torch}
+    exec(compile(_CPU(ast.get_source_segment(tsrc, fns["load_and_prepare_confidence"])), "train.py", "exec"), conf_ns)
+    ns = {"os": os, "np": np, "torch": torch, "prepare_output_and_logger": lambda d: None, "GaussianModel": TrackedModel,
+          "load_and_prepare_confidence": conf_ns["load_and_prepare_confidence"], "Scene": Scene, "save_pose": lambda *a, **k: None,
+          "tqdm": Quiet, "time": __import__("time").time, "randint": random.randint, "render": render_tracked,
+          "l1_loss": loss_utils.l1_loss, "ssim": loss_utils.ssim, "FUSED_SSIM_AVAILABLE": True, "fused_ssim": fused_ssim_tracked,
+          "save_time": lambda *a, **k: None, "training_report": lambda *a, **k: None, "Quiet": Quiet}
+    exec(compile(code, os.path.join(REF, "train.py"), "exec"), ns)
+    opt = OptimizationParams(ArgumentParser())
+    opt.iterations, opt.pp_optimizer, opt.optim_pose = iters, True, True
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, f"sparse_{V}", "0"))
+        np.save(os.path.join(td, f"sparse_{V}", "0", "confidence_dsp.npy"), G["loop_confidence"])
+        dataset = types.SimpleNamespace(sh_degree=3, source_path=td, model_path=td, n_views=V, white_background=False)
+        random.seed(0)
+        ns["training"](dataset, opt, pipe, [], [], [], None, -1)
+
+    model = track["models"][-1]
+    assert track["uids"] == list(G["loop_view_uids"])
+    assert np.allclose(track["loss"], G["loop_losses"], rtol=1e-3, atol=0), (track["loss"], G["loop_losses"])
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
+        a, b = getattr(model, n).detach(), T("loop_final" + (n if n.startswith("_") else "_" + n))
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        assert rel <= 1e-5, (n, rel)
+    assert [model.optimizer.state[grp["params"][0]]["step"] for grp in model.optimizer.param_groups] == list(G["loop_final_steps"])
