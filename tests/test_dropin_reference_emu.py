@@ -39,7 +39,10 @@ def reference_modules_cleanup():
         del sys.modules[k]
 
 
-def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup):
+@pytest.mark.parametrize("fused_glue", [False, True])
+def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup, fused_glue):
+    """fused_glue: also take the second block of INTEGRATION.md section 1 — `gaussian_renderer.render` and `PerPointAdam`
+    replaced by ours (fused pose kernel, multi-tensor Adam kernel), identical signatures."""
     import instantsplat_amd.diff_gaussian_rasterization as dgr
     import instantsplat_amd.fused_ssim as fs
     import instantsplat_amd.simple_knn as sk
@@ -72,6 +75,11 @@ def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_mo
     gr = _exec_file(os.path.join(REF, "gaussian_renderer", "__init__.py"), "ref_gaussian_renderer")
     cm = _exec_file(os.path.join(REF, "scene", "cameras.py"), "ref_cameras")
     assert gr.GaussianRasterizer is dgr.GaussianRasterizer and gm.distCUDA2 is skc.distCUDA2   # ours, through the aliases
+    if fused_glue:
+        import instantsplat_amd.gaussian_renderer as our_gr
+        import instantsplat_amd.optim as our_optim
+        gm.PerPointAdam = our_optim.PerPointAdam     # `import scene.per_point_adam as ppa; ppa.PerPointAdam = opt.PerPointAdam`
+        gr.render = our_gr.render                    # `sys.modules["gaussian_renderer"] = instantsplat_amd.gaussian_renderer`
 
     tsrc = open(os.path.join(REF, "train.py")).read()
     fns = {n.name: n for n in ast.parse(tsrc).body if isinstance(n, ast.FunctionDef)}
