@@ -32,25 +32,12 @@ def _exec_file(path, name, rewrite=True):
     return mod
 
 
-@pytest.fixture()
-def reference_modules_cleanup():
-    yield
-    for k in [k for k, m in sys.modules.items() if getattr(m, "__file__", None) and str(m.__file__).startswith(REF)]:
-        del sys.modules[k]
-
-
-@pytest.mark.parametrize("fused_glue", [False, True])
-def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup, fused_glue):
-    """fused_glue: also take the second block of INTEGRATION.md section 1 — `gaussian_renderer.render` and `PerPointAdam`
-    replaced by ours (fused pose kernel, multi-tensor Adam kernel), identical signatures."""
+def _load_reference(monkeypatch):
+    """INTEGRATION.md section 1 on the CPU tier; returns the reference modules loaded from their files."""
     import instantsplat_amd.diff_gaussian_rasterization as dgr
     import instantsplat_amd.fused_ssim as fs
     import instantsplat_amd.simple_knn as sk
     import instantsplat_amd.simple_knn._C as skc
-    G = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
-    T = lambda k: torch.from_numpy(G[k])
-    V, _, W, H, iters = [int(x) for x in G["loop_config"]]
-
     # ---- INTEGRATION.md section 1: alias the operator packages
     monkeypatch.syspath_prepend(REF)
     for name, mod in (("diff_gaussian_rasterization", dgr), ("simple_knn", sk), ("simple_knn._C", skc), ("fused_ssim", fs)):
@@ -75,6 +62,27 @@ def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_mo
     gr = _exec_file(os.path.join(REF, "gaussian_renderer", "__init__.py"), "ref_gaussian_renderer")
     cm = _exec_file(os.path.join(REF, "scene", "cameras.py"), "ref_cameras")
     assert gr.GaussianRasterizer is dgr.GaussianRasterizer and gm.distCUDA2 is skc.distCUDA2   # ours, through the aliases
+    return types.SimpleNamespace(gm=gm, gr=gr, cm=cm, loss_utils=loss_utils, pose_utils=pose_utils, BasicPointCloud=BasicPointCloud,
+                                 OptimizationParams=OptimizationParams, fs=fs)
+
+
+@pytest.fixture()
+def reference_modules_cleanup():
+    yield
+    for k in [k for k, m in sys.modules.items() if getattr(m, "__file__", None) and str(m.__file__).startswith(REF)]:
+        del sys.modules[k]
+
+
+@pytest.mark.parametrize("fused_glue", [False, True])
+def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup, fused_glue):
+    """fused_glue: also take the second block of INTEGRATION.md section 1 — `gaussian_renderer.render` and `PerPointAdam`
+    replaced by ours (fused pose kernel, multi-tensor Adam kernel), identical signatures."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k])
+    V, _, W, H, iters = [int(x) for x in G["loop_config"]]
+    R = _load_reference(monkeypatch)
+    gm, gr, cm, loss_utils, pose_utils, BasicPointCloud, OptimizationParams, fs = (R.gm, R.gr, R.cm, R.loss_utils, R.pose_utils,
+                                                                                    R.BasicPointCloud, R.OptimizationParams, R.fs)
     if fused_glue:
         import instantsplat_amd.gaussian_renderer as our_gr
         import instantsplat_amd.optim as our_optim
@@ -158,3 +166,62 @@ def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_mo
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         assert rel <= 1e-5, (n, rel)
     assert [model.optimizer.state[grp["params"][0]]["step"] for grp in model.optimizer.param_groups] == list(G["loop_final_steps"])
+
+
+def test_reference_pose_tracking_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup):
+    """The second caller of the operator: the reference's own `render_set_optimize` (render.py:99-186) on our packages."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k])
+    _, _, W, H, _ = [int(x) for x in G["loop_config"]]
+    R = _load_reference(monkeypatch)
+    model = R.gm.GaussianModel(3)
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        setattr(model, n, torch.nn.Parameter(T("loop_final" + n).clone()))
+    w2c = T("track_w2c_guess").double().numpy()
+    view = R.cm.Camera(colmap_id=9, R=w2c[:3, :3].T.copy(), T=w2c[:3, 3].copy(), FoVx=float(G["loop_cam_fov"][1, 0]),
+                       FoVy=float(G["loop_cam_fov"][1, 1]), image=T("track_gt"), gt_alpha_mask=None, image_name="track", uid=0,
+                       data_device="cpu")
+    rsrc = open(os.path.join(REF, "render.py")).read()
+    fn = next(n for n in ast.parse(rsrc).body if isinstance(n, ast.FunctionDef) and n.name == "render_set_optimize")
+    track = {"poses": [], "losses": [], "saved": []}
+
+    class Tqdm:
+        def __init__(self, iterable=None, **k):
+            self.it = iterable
+
+        def __iter__(self):
+            return iter(self.it)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def update(self, *a, **k):
+            pass
+
+        def set_postfix(self, *a, **k):
+            pass
+
+    def render_tracked(cam, pc, pipe, bg, camera_pose=None, **k):
+        track["poses"].append(camera_pose.detach().clone())
+        return R.gr.render(cam, pc, pipe, bg, camera_pose=camera_pose, **k)
+
+    def l1_mask_tracked(a, b, m):
+        v = R.loss_utils.l1_loss_mask(a, b, m)
+        track["losses"].append(float(v.detach()))
+        return v
+
+    tv = types.SimpleNamespace(utils=types.SimpleNamespace(save_image=lambda img, path: track["saved"].append(img.detach().clone())))
+    ns = {"os": os, "makedirs": os.makedirs, "tqdm": Tqdm, "get_tensor_from_camera": R.pose_utils.get_tensor_from_camera, "torch": torch,
+          "render": render_tracked, "l1_loss_mask": l1_mask_tracked, "torchvision": tv,
+          "args": types.SimpleNamespace(optim_test_pose_iter=int(G["track_iters"]), test_fps=False),
+          "perf_counter": __import__("time").perf_counter, "json": __import__("json")}
+    exec(compile(_CPU(ast.get_source_segment(rsrc, fn)), os.path.join(REF, "render.py"), "exec"), ns)
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+    with tempfile.TemporaryDirectory() as td:
+        ns["render_set_optimize"](td, "test", 12, [view], model, pipe, torch.zeros(3))
+    assert float((torch.stack(track["poses"]) - T("track_pose_sequence")).abs().max()) <= 2e-5
+    assert np.allclose(track["losses"], G["track_losses"], rtol=2e-4, atol=0)
+    assert float((track["saved"][0] - T("track_final_render")).abs().max()) <= 2e-4
