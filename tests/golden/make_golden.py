@@ -416,7 +416,8 @@ teacher.init_RT_seq({1.0: [_ref_cam(c, blank) for c in sc8.cameras]})
 with torch.no_grad():
     gts8 = [gr.render(_ref_cam(c, blank), teacher, _Pipe(False, False), bg8, camera_pose=teacher.get_RT(c.uid))["render"].clamp(0, 1)
             for c in sc8.cameras]
-tl = {"models": [], "uids": [], "l1": [], "loss": []}
+tl = {"models": [], "uids": [], "l1": [], "loss": [], "params": [], "grads": []}
+TL_NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
 
 
 class _TrackedModel(gm.GaussianModel):
@@ -466,8 +467,20 @@ class _Bar:
 
 
 class _Ev:
+    """Stand-in for the two torch.cuda.Event objects of train.py:120-121.  The reference records `iter_start` as the first
+    statement of an iteration (train.py:140) and `iter_end` right after `loss.backward()` (train.py:178), which makes them
+    the two points at which a teacher-forced comparison needs the state: parameters going into the iteration, and the
+    gradients its backward produced (before the optimizer consumes them)."""
+
     def record(self):
-        pass
+        if not tl["models"]:
+            return
+        m = tl["models"][-1]
+        if all(getattr(m, n).grad is None for n in TL_NAMES):
+            tl["params"].append({n: getattr(m, n).detach().clone() for n in TL_NAMES})
+        else:
+            tl["grads"].append({n: (torch.zeros_like(getattr(m, n)) if getattr(m, n).grad is None else getattr(m, n).grad.detach().clone())
+                                for n in TL_NAMES})
 
     def elapsed_time(self, other):
         return 0.0
@@ -501,7 +514,7 @@ tns = {"os": os, "np": np, "torch": torch, "prepare_output_and_logger": lambda d
        "training_report": lambda *a, **k: None, "_Ev": _Ev}
 exec(compile(tcode, os.path.join(REF, "train.py"), "exec"), tns)
 def _run_reference_training(prefix, pp_optimizer, optim_pose, iters):
-    for k in ("models", "uids", "l1", "loss"):
+    for k in ("models", "uids", "l1", "loss", "params", "grads"):
         tl[k].clear()
     topt = RefOptimizationParams(ArgumentParser())
     topt.iterations, topt.pp_optimizer, topt.optim_pose = iters, pp_optimizer, optim_pose
@@ -520,6 +533,11 @@ def _run_reference_training(prefix, pp_optimizer, optim_pose, iters):
     o[prefix + "_final_steps"] = np.array([model.optimizer.state[grp["params"][0]].get("step", 0) if grp["params"][0] in model.optimizer.state
                                             else 0 for grp in model.optimizer.param_groups])
     o[prefix + "_flags"] = np.array([int(pp_optimizer), int(optim_pose), iters])
+    assert len(tl["params"]) == iters and len(tl["grads"]) == iters, (len(tl["params"]), len(tl["grads"]))
+    for name in TL_NAMES:   # teacher forcing: the state going into every iteration and the gradients that iteration produced
+        key = name if name.startswith("_") else "_" + name
+        o[prefix + "_iter_params" + key] = np.stack([p_[name].numpy() for p_ in tl["params"]])
+        o[prefix + "_iter_grads" + key] = np.stack([g_[name].numpy() for g_ in tl["grads"]])
     np.savez_compressed(OUT, **o)
     print("added training-loop vectors", prefix, len(o), "arrays; losses", np.round(o[prefix + "_losses"], 5), "views", o[prefix + "_view_uids"])
     return model

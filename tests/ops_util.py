@@ -9,6 +9,45 @@ from oracle import knn_ref, ssim_ref
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
 T = lambda k: torch.from_numpy(G[k])
 
+# ---- measured bounds.  Every device-vs-device / device-vs-oracle tolerance below goes through `bound`, which records the
+# measured value; `GS_CALIBRATE=1 pytest ... -s` prints them all at the end of the session instead of failing (conftest.py),
+# which is how the GPU-tier limits were set (round 2: measured on MI355X, limit = roughly 10-30x the measurement, never a guess).
+MEASURED = []
+
+
+def bound(label, value, limit):
+    value = float(value)
+    MEASURED.append((label, value, float(limit)))
+    if os.environ.get("GS_CALIBRATE") != "1":
+        assert value <= limit, (label, value, limit)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def generic_start(st, seed=101):
+    """Moves a freshly set-up student off the two measure-zero sets the reference's `create_from_pcd` state sits on, which
+    make trajectory comparisons meaningless for reasons that have nothing to do with the code under test:
+      * isotropic scales + identity rotations: d(loss)/d(rotation) is exactly zero, only rounding noise is computed, and
+        Adam (eps 1e-15) turns noise into +-lr steps;
+      * colour channels clamped to exactly 0 or 1: f_dc = RGB2SH(0) puts C0 * f_dc + 0.5 on the edge of the SH colour
+        clamp, where the gradient mask depends on the last bit (round 2, tools/diag_step0.py).
+    Same treatment as the recorded reference run gets in tests/golden/make_golden.py (_Scene)."""
+    g = st.gaussians
+    gen = torch.Generator().manual_seed(seed)
+    n = g._xyz.shape[0]
+    dev = g._xyz.device
+    with torch.no_grad():
+        g._scaling.add_((0.35 * torch.randn(n, 3, generator=gen)).to(dev))
+        q = torch.randn(n, 4, generator=gen)
+        q = q / q.norm(dim=1, keepdim=True) * (0.9 + 0.2 * torch.rand(n, 1, generator=gen))
+        g._rotation.copy_(q.to(dev))
+        g._features_dc.add_((0.02 + 0.02 * torch.rand(g._features_dc.shape, generator=gen)).to(dev)
+                            * torch.where(g._features_dc < 0, 1.0, -1.0))
+    return st
+
 
 def check_ssim_golden(dev):
     from instantsplat_amd.fused_ssim import fused_l1_ssim_loss, fused_ssim
@@ -123,9 +162,10 @@ def check_train_matches_cpu_oracle(dev, iters, Wm=16, W=32, fused_step=False):
         for grp, dgrp in zip(cpu.opt.param_groups, g.optimizer.param_groups):
             grp["lr"] = dgrp["lr"]
         l_cpu = cpu.iteration()
-        # trajectories separate slowly: Adam turns rounding-level gradient differences (float-atomic order on the GPU,
-        # the zero-gradient rotation direction) into +-lr steps, so the bound on the loss is loose by design
-        assert abs(l_dev - l_cpu) <= 5e-3 * max(1e-2, abs(l_cpu)), (it, l_dev, l_cpu)
+        # this test starts from the reference's isotropic create_from_pcd state ON PURPOSE (part (1) checks the structurally
+        # zero rotation gradient), so Adam turns the rotations' rounding noise into +-lr steps on both sides and the losses
+        # separate slowly; the tight trajectory checks are the generic-start and reference-function tests
+        bound("cpu_oracle_loop/loss[%s]" % ("one-call" if fused_step else "op-by-op"), abs(l_dev - l_cpu) / max(1e-2, abs(l_cpu)), 5e-3)
 
 
 def check_pose_activations(dev, P=777, seed=0):
@@ -199,7 +239,7 @@ def check_run_ahead_equals_sync_loop(dev, iters=23, force_overflow=False, Wm=20,
     from instantsplat_amd.synthetic import syn_pointmap
     from instantsplat_amd.train import RunAhead, setup_training, train_iteration
     sc = syn_pointmap(3, Wm, Wm, W, W, seed=7)
-    mk = lambda: setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True))
+    mk = lambda: generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
     names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
     try:
         st_a = mk()
@@ -216,25 +256,14 @@ def check_run_ahead_equals_sync_loop(dev, iters=23, force_overflow=False, Wm=20,
         if force_overflow:
             assert ra.replays >= 3, ra.replays
         # CPU tier: the emulated kernels are deterministic and the one-call step evaluates the same expressions as the
-        # op-by-op path, so the EMA must agree to rounding (1e-6) — that is the equivalence check.  GPU: the two paths round
-        # differently (the one-call step transforms by the pose inside the projection kernels, different FMA contraction)
-        # and float-atomic order differs between any two runs; Adam turns rounding-level gradients of zero-gradient elements
-        # into +-lr steps (check_fused_step_gradients_equal_autograd bounds the gradients themselves).  Measured with
-        # tools/ema_probe.py on this scene: same loop run twice 0.5e-3..4.4e-3, op-by-op vs one-call 4.8e-3..1.1e-2 (parameters:
-        # same loop twice up to 2.3e-3, op-by-op vs one-call up to 6.1e-3, both largest on _scaling).  A change of nothing but
-        # FMA contraction moves this EMA by 4e-3 on the CPU as well (tools/ema_emu_probe.py).
-        ema_tol = 1e-6 if torch.device(dev).type != "cuda" else 3e-2
-        assert abs(ema - ema_b) <= ema_tol * max(1e-3, abs(ema)), (ema, ema_b)
-        # Parameters: on the CPU tier the kernels run deterministically, so both loops must agree tightly.  On the GPU
-        # the float atomics of the backward pass make even two runs of the SAME loop differ in the last bits, and Adam
-        # turns that into +-lr steps for elements whose gradient is pure rounding noise — so the bound there is loose
-        # and the tight check is the EMA of the loss above (any real divergence, e.g. a wrong replay, moves it).
-        tol = 1e-4 if torch.device(dev).type != "cuda" else 2e-2
+        # op-by-op path, so everything must agree to rounding.  GPU: the two paths round differently (the one-call step
+        # transforms by the pose inside the projection kernels) and float-atomic order differs between any two runs; from the
+        # generic start (no structurally zero gradients, no colours on the clamp edge) that stays at rounding level — the
+        # 1e-2-level separations round 1 bounded here came from the degenerate start, not from the loops.
+        cuda = torch.device(dev).type == "cuda"
+        bound("run_ahead_vs_sync/ema", abs(ema - ema_b) / max(1e-3, abs(ema)), 2e-3 if cuda else 1e-6)   # MI355X: 1.1e-4 (23 iterations)
         for n in names:
-            if n == "_rotation":
-                continue  # zero-gradient direction at the isotropic initialisation: noise-driven on every path
-            a, b = getattr(st_a.gaussians, n).detach().cpu(), getattr(st_b.gaussians, n).detach().cpu()
-            assert float((a - b).norm() / (a.norm() + 1e-12)) <= tol, (n, float((a - b).norm() / (a.norm() + 1e-12)))
+            bound("run_ahead_vs_sync/param" + n, rel_l2(getattr(st_b.gaussians, n), getattr(st_a.gaussians, n)), 2e-3 if cuda else 1e-5)   # MI355X: <= 1.3e-4
     finally:
         BinningPolicy.slack, BinningPolicy.pad = 1.5, 16384
         BinningPolicy.reset("exact")
@@ -271,8 +300,8 @@ def check_fused_train_step_equals_autograd_path(dev, iters=6, Wm=12, W=32):
     from instantsplat_amd.synthetic import syn_pointmap
     from instantsplat_amd.train import RunAhead, setup_training
     sc = syn_pointmap(3, Wm, Wm, W, W, seed=9)
-    mk = lambda: setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True))
-    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "P")
+    mk = lambda: generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
     try:
         res = {}
         for fused in (False, True):
@@ -285,16 +314,14 @@ def check_fused_train_step_equals_autograd_path(dev, iters=6, Wm=12, W=32):
                           {n: st.gaussians.optimizer.state[getattr(st.gaussians, n)]["exp_avg_sq"].detach().cpu().clone() for n in names})
             BinningPolicy.reset("exact")
         cuda = torch.device(dev).type == "cuda"
-        # GPU bound: see check_run_ahead_equals_sync_loop (one-call vs op-by-op EMA measured up to 1.1e-2 on a 23-iteration run)
-        assert abs(res[True][0] - res[False][0]) <= (3e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
-        # Under the emulator (deterministic atomics) the two paths agree to rounding.  On the GPU the float atomics of the
-        # composite backward land in a different order every run and Adam amplifies that over the iterations; the second
-        # moments (sums of squared gradients) are the most sensitive quantity compared here.
+        bound("one_call_vs_autograd/ema", abs(res[True][0] - res[False][0]) / max(1e-3, abs(res[False][0])), 2e-4 if cuda else 1e-6)
+        # Under the emulator (deterministic atomics) the two paths agree to rounding; on the GPU to float-atomic order.  The
+        # second moments (sums of squared gradients) are the most sensitive quantity compared here.
         for n in names:
-            for k in (1, 2):
-                tol = (2e-2 if k == 1 else 5e-2) if cuda else 1e-5
-                a, b = res[True][k][n], res[False][k][n]
-                assert float((a - b).norm() / (b.norm() + 1e-12)) <= tol, (n, k, float((a - b).norm() / (b.norm() + 1e-12)))
+            for k, what in ((1, "param"), (2, "exp_avg_sq")):
+                # MI355X: parameters <= 1.0e-5, second moments <= 1.4e-4
+                bound("one_call_vs_autograd/%s%s" % (what, n), rel_l2(res[True][k][n], res[False][k][n]),
+                      ((2e-4 if k == 1 else 2e-3) if cuda else 1e-5))
     finally:
         BinningPolicy.reset("exact")
 
@@ -360,7 +387,7 @@ def check_run_ahead_crosses_sh_degree_step(dev, Wm=10, W=24):
     try:
         res = {}
         for fused in (False, True):
-            st = setup_training(sc, dev, opt=OptimizationParams(iterations=1003, pp_optimizer=True, optim_pose=True))
+            st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1003, pp_optimizer=True, optim_pose=True)))
             st.iteration = 996
             ra = RunAhead(st, window=2, fused_step=fused)
             assert (ra.trainer is not None) == fused
@@ -377,16 +404,11 @@ def check_run_ahead_crosses_sh_degree_step(dev, Wm=10, W=24):
             assert float(st.gaussians._features_rest.detach()[:, 3:].abs().max()) == 0   # higher bands still untouched
             res[fused] = (ema, {n: getattr(st.gaussians, n).detach().cpu().clone() for n in names})
             BinningPolicy.reset("exact")
-        # GPU bound: see check_run_ahead_equals_sync_loop (one-call vs op-by-op EMA measured up to 1.1e-2 on a 23-iteration run)
-        assert abs(res[True][0] - res[False][0]) <= (3e-2 if cuda else 1e-6) * max(1e-3, abs(res[False][0]))
+        bound("sh_degree_step/ema", abs(res[True][0] - res[False][0]) / max(1e-3, abs(res[False][0])), 2e-4 if cuda else 1e-6)
         for n in names:
-            a_, b_ = res[True][1][n], res[False][1][n]
-            rel = float((a_ - b_).norm() / (b_.norm() + 1e-12))
-            # GPU: f_rest has had three sign-like Adam steps from zero by now, on gradients whose rounding differs between
-            # the two paths (see check_fused_step_gradients_equal_autograd) — only the emulator can compare it
-            if cuda and n == "_features_rest":
-                continue
-            assert rel <= (5e-2 if cuda else 1e-5), (n, rel)
+            # f_rest included: its first Adam steps from zero are sign-like, but the gradients behind them are ordinary
+            # (dL/dcolour times the SH basis), not rounding noise, so the two paths take the same steps
+            bound("sh_degree_step/param" + n, rel_l2(res[True][1][n], res[False][1][n]), 2e-4 if cuda else 1e-5)
     finally:
         BinningPolicy.reset("exact")
 
@@ -406,7 +428,7 @@ def check_gated_off_tensor_keeps_moving(dev, Wm=10, W=24):
     try:
         res = {}
         for fused in (False, True):
-            st = setup_training(sc, dev, opt=OptimizationParams(iterations=500, pp_optimizer=True, optim_pose=True))
+            st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=500, pp_optimizer=True, optim_pose=True)))
             ra = RunAhead(st, window=2, fused_step=fused)
             g = st.gaussians
             track = []
@@ -424,16 +446,12 @@ def check_gated_off_tensor_keeps_moving(dev, Wm=10, W=24):
             assert float(track[4].abs().max()) > 0                        # trained at degree 1
             for a_, b_ in ((4, 5), (5, 6), (6, 7)):                       # gated off again: still moving on its momentum
                 assert float((track[a_] - track[b_]).abs().max()) > 0, (fused, a_)
-        tol = 5e-2 if cuda else 1e-5
         for k in range(8):
             a_, b_ = res[True][0][k], res[False][0][k]
-            if cuda and k >= 3:
-                continue   # sign-like first Adam steps on rounding-level different gradients, see the crossing test
-            assert float((a_ - b_).norm()) <= tol * float(b_.norm() + 1e-12) + 0.0, k
-        if not cuda:
-            for i in (1, 2):
-                rel = float((res[True][i] - res[False][i]).norm() / (res[False][i].norm() + 1e-20))
-                assert rel <= 1e-5, (i, rel)
+            bound("gated_off/f_rest_track", float((a_ - b_).norm()) / float(b_.norm() + 1e-12) if float(b_.norm()) > 0 else float(a_.norm()),
+                  2e-4 if cuda else 1e-5)
+        for i, what in ((1, "exp_avg"), (2, "exp_avg_sq")):
+            bound("gated_off/f_rest_" + what, rel_l2(res[True][i], res[False][i]), 2e-4 if cuda else 1e-5)
         # the moments freeze while the tensor is gated off (both paths)
     finally:
         BinningPolicy.reset("exact")
@@ -490,8 +508,8 @@ def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=Fa
     from instantsplat_amd.synthetic import syn_pointmap
     from instantsplat_amd.train import setup_training, train_iteration
     sc = syn_pointmap(3, Wm, Wm, W, W, seed=17)
-    mk = lambda: setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True))
-    names = ("_xyz", "_features_dc", "_opacity", "_scaling", "P")
+    mk = lambda: generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
     cuda = torch.device(dev).type == "cuda"
     try:
         BinningPolicy.reset("exact")
@@ -504,13 +522,15 @@ def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=Fa
         if not force_overflow:
             assert b._trainer is not None
         for x, y in zip(la, lb):
-            assert abs(x - y) <= (5e-3 if cuda else 1e-6) * max(1e-2, abs(x)), (la, lb)
+            bound("synced_one_call_vs_autograd/loss", abs(x - y) / max(1e-2, abs(x)), 1e-3 if cuda else 1e-6)   # MI355X: 6.5e-5
         for n in names:
-            p, q = getattr(a.gaussians, n).detach().cpu(), getattr(b.gaussians, n).detach().cpu()
-            assert float((p - q).norm() / (p.norm() + 1e-12)) <= (2e-2 if cuda else 1e-5), n
+            bound("synced_one_call_vs_autograd/param" + n, rel_l2(getattr(b.gaussians, n), getattr(a.gaussians, n)), 1e-3 if cuda else 1e-5)   # MI355X: <= 5.3e-5
     finally:
         BinningPolicy.slack, BinningPolicy.pad = 1.5, 16384
         BinningPolicy.reset("exact")
+
+
+TRAIN_TENSORS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
 
 
 def _reference_loop_start(dev, run="loop"):
@@ -542,6 +562,17 @@ def _reference_loop_start(dev, run="loop"):
         P[:, :4] = quadmultiply(T("loop_pose_noise_q").to(dev), P[:, :4])
         P[:, 4:] += T("loop_pose_noise_t").to(dev)
     g.P = P.requires_grad_(True)
+    with torch.no_grad():
+        # Same initial BITS as the recorded run.  create_from_pcd on the device reproduces them to 1 ulp (RGB2SH divides by a
+        # constant, which the GPU evaluates as a multiplication by its reciprocal), and 1 ulp is not harmless here: the
+        # synthetic colours are clamped to [0, 1], so some channels are exactly 0, f_dc = RGB2SH(0) = -0.5/C0, and
+        # C0 * f_dc + 0.5 lands on either side of the SH colour clamp (colour < 0 -> gradient masked) depending on that
+        # last bit.  Found on MI355X in round 2: 17 of 324 f_dc elements got a zero gradient, stayed put in Adam's first
+        # step (everyone else moves by lr) and the trajectory ended 2 % away in f_dc (tools/diag_step0.py).
+        for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
+            ref0 = T(run + "_iter_params" + (n if n.startswith("_") else "_" + n))[0].to(dev)
+            assert float((getattr(g, n).detach() - ref0).abs().max()) <= 1e-6, n
+            getattr(g, n).copy_(ref0)
     opt = OptimizationParams(iterations=iters, pp_optimizer=bool(pp), optim_pose=bool(optim_pose))
     conf = confidence_to_lr_modifiers(T("loop_confidence").to(dev), scale=(1.0, 100.0))
     if pp:
@@ -557,8 +588,9 @@ def _reference_loop_start(dev, run="loop"):
 def check_training_loop_matches_reference_function(dev, fused_step, run="loop"):
     """The device training loop vs a trajectory produced by the reference's OWN `training()` (train.py:87-230, executed by
     make_golden.py around the fp32 C oracle as the rasterizer operator): per-iteration losses, the view order, the LR
-    schedule, the skipped optimizer step of the last iteration, and the final parameters.  The start is non-degenerate
-    (anisotropic scales, generic rotations), so no parameter has a structurally zero gradient for Adam to amplify."""
+    schedule, the skipped optimizer step of the last iteration, the parameters after every iteration and at the end.  The
+    start is non-degenerate (anisotropic scales, generic rotations: no structurally zero gradient for Adam to amplify) and
+    bit-identical to the recorded run's (see _reference_loop_start for why the last bit of f_dc matters)."""
     import random
     from instantsplat_amd.train import FusedTrainer, train_iteration
     G, st, _ = _reference_loop_start(dev, run)
@@ -571,18 +603,72 @@ def check_training_loop_matches_reference_function(dev, fused_step, run="loop"):
     assert order == list(G[run + "_view_uids"])
     if fused_step:
         assert FusedTrainer.supported(st)
-    cuda = torch.device(dev).type == "cuda"
+    # Tolerances measured, not guessed: on MI355X (round 2, tools/diag_loop.py) the free-running loop ends within 6e-7
+    # (relative L2, every tensor) of the reference's trajectory, op-by-op and one-call alike, the same as under the
+    # emulator; the last iteration's loss is 2e-4 off on both (one pixel/Gaussian pair on the other side of alpha = 1/255).
+    g = st.gaussians
+    key = lambda kind, n: run + kind + (n if n.startswith("_") else "_" + n)
     for it in range(iters):
         l = float(train_iteration(st, fused_step=fused_step))
-        assert abs(l - G[run + "_losses"][it]) <= (5e-3 if cuda else 1e-3) * G[run + "_losses"][it], (it, l, G[run + "_losses"][it])
-    g = st.gaussians
-    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
-        a, b = getattr(g, n).detach().cpu(), torch.from_numpy(G[run + "_final" + (n if n.startswith("_") else "_" + n)])
+        assert abs(l - G[run + "_losses"][it]) <= 1e-3 * G[run + "_losses"][it], (it, l, G[run + "_losses"][it])
+        if it + 1 < iters:   # the state the reference's run went into its next iteration with
+            for n in TRAIN_TENSORS:
+                a, b = getattr(g, n).detach().cpu(), torch.from_numpy(G[key("_iter_params", n)][it + 1])
+                rel = float((a - b).norm() / (b.norm() + 1e-30))
+                assert rel <= 2e-5, (it, n, rel)
+    for n in TRAIN_TENSORS:
+        a, b = getattr(g, n).detach().cpu(), torch.from_numpy(G[key("_final", n)])
         rel = float((a - b).norm() / (b.norm() + 1e-30))
-        assert rel <= (2e-3 if cuda else 1e-5), (n, rel)
+        assert rel <= 2e-5, (n, rel)
     assert np.allclose([grp["lr"] for grp in g.optimizer.param_groups], G[run + "_final_lrs"], rtol=1e-12, atol=0)
     steps = [int(g.optimizer.state.get(grp["params"][0], {}).get("step", 0)) for grp in g.optimizer.param_groups]
     assert steps == [int(x) for x in G[run + "_final_steps"]], steps   # a fixed pose tensor never gets optimizer state
+
+
+def check_teacher_forced_gradients_match_reference_function(dev, run="loop", fused_loss=True):
+    """Teacher forcing: at every iteration of the reference's own `training()` run the recorded parameters
+    are loaded, ONE forward + backward runs on the device path, and each tensor's gradient is compared with the gradient
+    the reference run held right after its `loss.backward()` (train.py:177; recorded by tests/golden/make_golden.py through
+    the `iter_end.record()` stand-in).  Unlike a trajectory this cannot hide or amplify anything: a kernel bug shows as a
+    gradient mismatch in the iteration and tensor where it occurs.  Measured on MI355X: <= 8e-6 in every tensor/iteration."""
+    from instantsplat_amd.fused_ssim import fused_l1_ssim_loss, fused_ssim
+    from instantsplat_amd.gaussian_renderer import render
+    G, st, _ = _reference_loop_start(dev, run)
+    g = st.gaussians
+    key = lambda kind, n: run + kind + (n if n.startswith("_") else "_" + n)
+    pp, optim_pose, iters = [int(x) for x in G[run + "_flags"]]
+    if not optim_pose:
+        g.P.requires_grad_(False)
+    for it in range(iters):
+        with torch.no_grad():
+            for n in TRAIN_TENSORS:
+                getattr(g, n).copy_(torch.from_numpy(G[key("_iter_params", n)][it]).to(dev))
+                getattr(g, n).grad = None
+        uid = int(G[run + "_view_uids"][it])
+        pkg = render(st.cameras[uid], g, st.pipe, st.background, camera_pose=g.get_RT(uid))
+        image, gt = pkg["render"], st.gt_images[uid]
+        if fused_loss:
+            loss, _ = fused_l1_ssim_loss(image.unsqueeze(0), gt.unsqueeze(0), st.opt.lambda_dssim)
+        else:
+            loss = (1.0 - st.opt.lambda_dssim) * (image - gt).abs().mean() \
+                + st.opt.lambda_dssim * (1.0 - fused_ssim(image.unsqueeze(0), gt.unsqueeze(0)))
+        loss.backward()
+        ref_l = float(G[run + "_losses"][it])
+        assert abs(float(loss.detach()) - ref_l) <= 1e-4 * ref_l, (it, float(loss.detach()), ref_l)
+        for n in TRAIN_TENSORS:
+            ref = torch.from_numpy(G[key("_iter_grads", n)][it]).double()
+            got = getattr(g, n).grad
+            if n == "P" and not optim_pose:
+                assert got is None
+                continue
+            got = got.detach().cpu().double()
+            if float(ref.abs().max()) == 0.0:      # f_rest below its SH degree: exactly zero in the reference, and here
+                assert float(got.abs().max()) == 0.0, (it, n)
+                continue
+            rel = float((got - ref).norm() / ref.norm())
+            assert rel <= 1e-4, (it, n, rel)
+            # and element-wise where the reference gradient is exactly zero (masked SH clamp, culled Gaussians)
+            assert float(got[ref == 0].abs().max() if bool((ref == 0).any()) else 0.0) <= 1e-7 * float(ref.abs().max()), (it, n)
 
 
 def check_oracle_trainer_matches_reference_function(dev):
@@ -632,13 +718,12 @@ def check_pose_tracking_matches_reference_function(dev):
         res = pose_tracking.render_set_optimize([view], g, PipelineParams(), torch.zeros(3, device=dev), num_iter=int(G["track_iters"]))[0]
     finally:
         pose_tracking.render = real_render
-    cuda = torch.device(dev).type == "cuda"
     ref_seq = T("track_pose_sequence")
     assert len(poses) == ref_seq.shape[0]
-    assert float((torch.stack(poses) - ref_seq).abs().max()) <= (5e-4 if cuda else 2e-5)
-    assert abs(res["initial_loss"] - G["track_losses"][0]) <= 1e-4 * G["track_losses"][0]
-    assert abs(res["best_loss"] - G["track_losses"].min()) <= (2e-3 if cuda else 2e-4) * G["track_losses"].min()
-    assert float((res["pose"].cpu() - T("track_optimal_pose")).abs().max()) <= (5e-4 if cuda else 2e-5)
-    assert float((res["render"].cpu() - T("track_final_render")).abs().max()) <= (5e-3 if cuda else 2e-4)
+    bound("pose_tracking_ref/pose_sequence", (torch.stack(poses) - ref_seq).abs().max(), 2e-5)
+    bound("pose_tracking_ref/initial_loss", abs(res["initial_loss"] - G["track_losses"][0]) / G["track_losses"][0], 1e-4)
+    bound("pose_tracking_ref/best_loss", abs(res["best_loss"] - G["track_losses"].min()) / G["track_losses"].min(), 2e-4)
+    bound("pose_tracking_ref/optimal_pose", (res["pose"].cpu() - T("track_optimal_pose")).abs().max(), 2e-5)
+    bound("pose_tracking_ref/final_render", (res["render"].cpu() - T("track_final_render")).abs().max(), 2e-4)
     for t in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation):
         assert not t.requires_grad

@@ -117,6 +117,11 @@ def test_training_loop_matches_reference_function(emu, fused_step, run):
     ops_util.check_training_loop_matches_reference_function(emu, fused_step, run)
 
 
+@pytest.mark.parametrize("run", ["loop", "loopb"])
+def test_teacher_forced_gradients_match_reference_function(emu, run):
+    ops_util.check_teacher_forced_gradients_match_reference_function(emu, run)
+
+
 def test_oracle_trainer_matches_reference_function(emu):
     ops_util.check_oracle_trainer_matches_reference_function(emu)
 

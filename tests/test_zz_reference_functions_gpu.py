@@ -13,5 +13,14 @@ def test_training_loop_matches_reference_function(gpu, fused_step):
     ops_util.check_training_loop_matches_reference_function(gpu, fused_step)
 
 
+def test_training_loop_plain_adam_fixed_poses_matches_reference_function(gpu):
+    ops_util.check_training_loop_matches_reference_function(gpu, False, run="loopb")
+
+
+@pytest.mark.parametrize("run,fused_loss", [("loop", True), ("loop", False), ("loopb", True)])
+def test_teacher_forced_gradients_match_reference_function(gpu, run, fused_loss):
+    ops_util.check_teacher_forced_gradients_match_reference_function(gpu, run, fused_loss)
+
+
 def test_pose_tracking_matches_reference_function(gpu):
     ops_util.check_pose_tracking_matches_reference_function(gpu)
