@@ -1,0 +1,250 @@
+"""The oracle checked against itself — CPU only, no device code involved.
+
+`oracle/gs_ref.c` carries a hand-derived closed-form backward.  Nothing of the reference's CUDA
+operator exists to pin it (un-vendored submodule), so it is pinned from two independent directions instead:
+
+  1. `oracle/raster_torch.rasterize` — a dense PyTorch restatement of the same forward whose backward is *autograd's*, with
+     the operator's three deliberate deviations from the true derivative written as explicit straight-through/detach
+     constructs (App. A.4: `min(0.99, alpha)` passed through, the EWA clamp of t.x/t.z, t.y/t.z treated as a constant,
+     `1/(det^2 + 1e-7)` in the conic inverse).  float64: forward, radii and all gradients must agree to 1e-10.
+  2. central finite differences of the float64 C forward — the true derivative — which every gradient must match wherever
+     none of the three deviations is active, and must NOT match in exactly the elements where one is (that pins the quirks:
+     an oracle "fixed" to the true derivative would no longer restate the reference operator).
+
+Plus float32 vs float64 of the C oracle (the fp32 build is what device kernels are compared with).
+"""
+import math
+
+import pytest
+import torch
+
+from instantsplat_amd.camera import Camera
+from instantsplat_amd.synthetic import syn_blob
+from oracle import gs_ref
+from oracle import raster_torch as rt
+from tests.util import settings_for
+
+F64 = torch.float64
+
+
+def _settings64(cam, deg, bg, mod=1.0):
+    st = settings_for(cam, deg, rt.RasterSettings, bg, mod=mod)
+    return rt.RasterSettings(*[(x.double() if isinstance(x, torch.Tensor) else x) for x in st])
+
+
+def _blob_inputs(P, W, H, seed, scale_mean, dtype):
+    sc = syn_blob(P, W, H, seed=seed, scale_mean=scale_mean)
+    d = dict(means3D=sc.means3D, opac=torch.sigmoid(sc.opacity_logit), shs=sc.shs, scales=torch.exp(sc.scaling_logit),
+             rots=sc.rotation)
+    return sc.camera, {k: v.to(dtype) for k, v in d.items()}
+
+
+def _run(which, cam, inp, deg, dtype, wgt, precomp_color=False, precomp_cov=False, mod=1.0, bg=(0.2, 0.5, 0.9)):
+    """One forward + backward through the C oracle ("c") or the dense autograd restatement ("torch")."""
+    bg_t = torch.tensor(bg, dtype=torch.float32)
+    st = _settings64(cam, deg, bg_t, mod) if dtype == F64 else settings_for(cam, deg, rt.RasterSettings, bg_t, mod=mod)
+    lv = {k: v.clone().to(dtype).requires_grad_(True) for k, v in inp.items()}
+    m2d = torch.zeros(lv["means3D"].shape[0], 3, dtype=dtype, requires_grad=True)
+    kw = {}
+    if precomp_color:
+        lv["colors"] = torch.sigmoid(inp["shs"][:, 0, :]).clone().to(dtype).requires_grad_(True)
+        kw["colors_precomp"] = lv["colors"]
+    else:
+        kw["shs"] = lv["shs"]
+    if precomp_cov:
+        lv["cov3D"] = rt.cov3d_from_scale_rot(inp["scales"].to(dtype), mod, inp["rots"].to(dtype)).clone().requires_grad_(True)
+        kw["cov3D_precomp"] = lv["cov3D"]
+    else:
+        kw["scales"], kw["rotations"] = lv["scales"], lv["rots"]
+    if which == "c":
+        color, radii = gs_ref.rasterize(lv["means3D"], m2d, lv["opac"], st, **kw)
+    else:
+        color, radii = rt.rasterize(lv["means3D"], lv["opac"], st, means2D=m2d, **kw)
+    (color * wgt.to(dtype)).sum().backward()
+    grads = {k: (v.grad.detach().clone() if v.grad is not None else None) for k, v in lv.items()}
+    grads["means2D"] = m2d.grad.detach().clone()
+    used = {"means3D", "opac", "means2D"} | ({"colors"} if precomp_color else {"shs"}) | ({"cov3D"} if precomp_cov else {"scales", "rots"})
+    return color.detach(), radii, {k: v for k, v in grads.items() if k in used}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+CASES = [  # (P, W, H, deg, scale_mean, seed, precomp_color, precomp_cov, modifier)
+    (150, 48, 40, 0, 0.06, 1, False, False, 1.0),
+    (150, 48, 40, 3, 0.06, 2, False, False, 1.0),
+    (120, 40, 56, 2, 0.10, 3, False, False, 0.7),     # taller than wide, scale modifier
+    (100, 33, 31, 1, 0.08, 4, True, False, 1.0),      # colors_precomp; ragged tile grid (33x31)
+    (100, 48, 32, 3, 0.08, 5, False, True, 1.0),      # cov3D_precomp
+    (400, 32, 32, 0, 0.15, 6, False, False, 1.0),     # fat Gaussians: long per-pixel lists, T < 1e-4 terminations
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"P{c[0]}_{c[1]}x{c[2]}_sh{c[3]}" + ("_col" if c[6] else "") + ("_cov" if c[7] else "") for c in CASES])
+def test_c_oracle_equals_autograd_restatement_f64(case):
+    """gs_ref.c (tile lists, closed-form backward) vs raster_torch (dense, autograd) in float64: identical algorithm, two
+    independent derivations of the gradient.  Agreement is at rounding level (measured <= 1e-13)."""
+    P, W, H, deg, sm, seed, pc, pcov, mod = case
+    cam, inp = _blob_inputs(P, W, H, seed, sm, F64)
+    torch.manual_seed(seed + 50)
+    wgt = torch.randn(3, H, W, dtype=F64)
+    c_img, c_rad, c_g = _run("c", cam, inp, deg, F64, wgt, pc, pcov, mod)
+    t_img, t_rad, t_g = _run("torch", cam, inp, deg, F64, wgt, pc, pcov, mod)
+    assert torch.equal(c_rad, t_rad)
+    assert int((c_rad > 0).sum()) > P // 4
+    assert float((c_img - t_img).abs().max()) <= 1e-12
+    assert set(c_g) == set(t_g)
+    for k in c_g:
+        assert float(t_g[k].abs().max()) > 0, k
+        assert _rel(c_g[k], t_g[k]) <= 1e-10, (k, _rel(c_g[k], t_g[k]))
+
+
+@pytest.mark.parametrize("case", CASES[:3], ids=["sh0", "sh3", "sh2_mod"])
+def test_c_oracle_f32_vs_f64(case):
+    """The fp32 build (what the device kernels are compared with) against the fp64 build of the same C source."""
+    P, W, H, deg, sm, seed, pc, pcov, mod = case
+    cam, inp = _blob_inputs(P, W, H, seed, sm, F64)
+    torch.manual_seed(seed + 50)
+    wgt = torch.randn(3, H, W, dtype=F64)
+    img64, rad64, g64 = _run("c", cam, inp, deg, F64, wgt, pc, pcov, mod)
+    img32, rad32, g32 = _run("c", cam, {k: v.float() for k, v in inp.items()}, deg, torch.float32, wgt, pc, pcov, mod)
+    assert int((rad64 != rad32).sum()) <= 1
+    d = (img32.double() - img64).abs()
+    assert float((d > 1e-5).double().mean()) <= 1e-3 and float(d.max()) <= 5e-3   # isolated alpha-threshold flips only
+    for k in g64:
+        assert _rel(g32[k], g64[k]) <= 2e-4, (k, _rel(g32[k], g64[k]))
+
+
+# ---- finite differences ---------------------------------------------------------------------------------------------
+def _tiny_scene(kind):
+    """A handful of hand-placed Gaussians (camera frame, identity view) on a 24x20 image, a few pixels wide each so that
+    det(cov2D) >> 1e-7^(1/2) and the 1/(det^2 + 1e-7) deviation is below the finite-difference noise."""
+    W, H = 24, 20
+    fovx = math.radians(60.0)
+    tanx = math.tan(fovx / 2)
+    cam = Camera(0, torch.eye(4), fovx, 2 * math.atan(tanx * H / W), W, H)
+    g = torch.Generator().manual_seed({"generic": 11, "sh_clamp": 12, "ewa_clamp": 13, "alpha_clamp": 14}[kind])
+    P = 6
+    z = 3.0 + 2.0 * torch.rand(P, generator=g, dtype=F64)
+    x = (torch.rand(P, generator=g, dtype=F64) - 0.5) * 1.2 * tanx * z
+    y = (torch.rand(P, generator=g, dtype=F64) - 0.5) * 1.2 * tanx * (H / W) * z
+    means = torch.stack([x, y, z], 1)
+    scales = 0.25 + 0.2 * torch.rand(P, 3, generator=g, dtype=F64)
+    rots = torch.randn(P, 4, generator=g, dtype=F64)
+    rots = rots / rots.norm(dim=1, keepdim=True) * (0.9 + 0.2 * torch.rand(P, 1, generator=g, dtype=F64))
+    opac = 0.2 + 0.5 * torch.rand(P, 1, generator=g, dtype=F64)
+    shs = torch.zeros(P, 16, 3, dtype=F64)
+    shs[:, 0] = (torch.rand(P, 3, generator=g, dtype=F64) - 0.5) / rt.SH_C0 * 0.8
+    shs[:, 1:] = 0.15 * torch.randn(P, 15, 3, generator=g, dtype=F64)
+    special = None
+    if kind == "sh_clamp":
+        shs[1, 0, :] = -0.9 / rt.SH_C0            # all three channels of Gaussian 1 far below zero: clamped, gradient masked
+        shs[1, 1:] = 0.0
+        shs[4, 0, 1] = -0.8 / rt.SH_C0            # one channel of Gaussian 4
+        shs[4, 1:, 1] = 0.0
+        special = 1
+    if kind == "ewa_clamp":
+        # Gaussian 2 sits outside 1.3 * tan(fov/2) in x but is so wide that it still covers pixels: the Jacobian is evaluated
+        # at the clamped t.x and the operator treats that clamp as a constant
+        means[2] = torch.tensor([1.45 * tanx * 4.0, 0.02, 4.0], dtype=F64)
+        scales[2] = torch.tensor([1.6, 0.9, 0.7], dtype=F64)
+        opac[2] = 0.6
+        special = 2
+    if kind == "alpha_clamp":
+        opac[3] = 0.9999                          # opacity * G > 0.99 around the centre of Gaussian 3
+        means[3] = torch.tensor([0.1, -0.05, 3.5], dtype=F64)
+        scales[3] = torch.tensor([0.5, 0.45, 0.4], dtype=F64)
+        special = 3
+    return cam, dict(means3D=means, opac=opac, shs=shs, scales=scales, rots=rots), W, H, special
+
+
+def _fd_gradients(cam, inp, deg, wgt, eps=1e-6):
+    """Central differences of sum(wgt * image) through the float64 C forward, one parameter element at a time."""
+    st = _settings64(cam, deg, torch.tensor([0.2, 0.5, 0.9]))
+
+    def f(v):
+        color, _, _ = gs_ref.forward(v["means3D"], v["opac"].reshape(-1), st, shs=v["shs"], scales=v["scales"], rotations=v["rots"])
+        return float((color * wgt).sum())
+
+    out = {}
+    for k, t in inp.items():
+        g = torch.zeros_like(t)
+        flat, gf = t.reshape(-1), g.reshape(-1)
+        for i in range(flat.numel()):
+            if k == "shs" and (i // 3) % 16 >= (deg + 1) ** 2:
+                continue
+            v0 = float(flat[i])
+            flat[i] = v0 + eps
+            fp = f(inp)
+            flat[i] = v0 - eps
+            fm = f(inp)
+            flat[i] = v0
+            gf[i] = (fp - fm) / (2 * eps)
+        out[k] = g
+    return out
+
+
+@pytest.mark.parametrize("kind,deg", [("generic", 3), ("generic", 0), ("sh_clamp", 1), ("ewa_clamp", 0), ("alpha_clamp", 0)])
+def test_c_oracle_backward_vs_finite_differences(kind, deg):
+    cam, inp, W, H, special = _tiny_scene(kind)
+    torch.manual_seed(7)
+    wgt = torch.randn(3, H, W, dtype=F64)
+    img, radii, ana = _run("c", cam, inp, deg, F64, wgt)
+    assert int((radii > 0).sum()) == radii.numel()
+    fd = _fd_gradients(cam, {k: v.clone() for k, v in inp.items()}, deg, wgt)
+    scale = {k: float(fd[k].abs().max()) for k in fd}
+    assert all(s > 0 for s in scale.values())
+
+    def err(k, rows=None):
+        a, b = ana[k].reshape(ana[k].shape[0], -1), fd[k].reshape(fd[k].shape[0], -1)
+        if rows is not None:
+            a, b = a[rows], b[rows]
+        return float((a - b).abs().max()) / scale[k]
+
+    P = radii.numel()
+    others = [i for i in range(P) if i != special]
+    if kind in ("generic", "sh_clamp"):
+        # true derivative everywhere (a clamped colour has derivative zero, and the operator masks it to zero)
+        for k in ana:
+            if k != "means2D":
+                assert err(k) <= 1e-6, (k, err(k))
+        if kind == "sh_clamp":
+            assert float(ana["shs"][1].abs().max()) == 0.0                 # fully clamped Gaussian: no colour gradient at all
+            assert float(ana["shs"][4, :, 1].abs().max()) == 0.0 and float(ana["shs"][4, :, 0].abs().max()) > 0
+            assert float(fd["shs"][1].abs().max()) == 0.0
+    elif kind == "ewa_clamp":
+        tanx = math.tan(math.radians(60.0) / 2)
+        assert abs(float(inp["means3D"][2, 0] / inp["means3D"][2, 2])) > 1.3 * tanx
+        for k in ("opac", "shs", "scales", "rots"):                       # none of these sees the clamp
+            assert err(k) <= 1e-6, (k, err(k))
+        assert err("means3D", others) <= 1e-6
+        # the clamped Gaussian: d/dx and d/dy are exact (the clamped t.x = lim * t.z does not depend on x), d/dz is not —
+        # the operator ignores d(lim * t.z)/dz (App. A.4 #2).  Pin both halves of that statement.
+        a, b = ana["means3D"][2], fd["means3D"][2]
+        assert float((a[:2] - b[:2]).abs().max()) / scale["means3D"] <= 1e-6
+        assert abs(float(a[2] - b[2])) / scale["means3D"] > 1e-4
+    else:  # alpha_clamp
+        st = _settings64(cam, deg, torch.tensor([0.2, 0.5, 0.9]))
+        geom = rt.preprocess(inp["means3D"], inp["opac"], st, shs=inp["shs"], scales=inp["scales"], rotations=inp["rots"])
+        assert float(inp["opac"][3]) > 0.99
+        # Gaussians other than the saturated one get the true derivative; the saturated one gets min(0.99, .)'s gradient
+        # passed straight through (App. A.4 #1), which is NOT the derivative of the clamped forward: pin the deviation.
+        for k in ("opac", "scales", "rots", "means3D", "shs"):
+            assert err(k, others) <= 1e-6, (k, err(k, others))
+        assert err("opac", [3]) > 1e-3
+        assert geom["visible"][3]
+
+
+def test_fd_harness_detects_a_wrong_gradient():
+    """The finite-difference comparison above is only worth something if it fails for a wrong backward."""
+    cam, inp, W, H, _ = _tiny_scene("generic")
+    torch.manual_seed(7)
+    wgt = torch.randn(3, H, W, dtype=F64)
+    _, _, ana = _run("c", cam, inp, 0, F64, wgt)
+    fd = _fd_gradients(cam, {k: v.clone() for k, v in inp.items()}, 0, wgt)
+    wrong = ana["scales"].clone()
+    wrong[2, 1] *= 1.001
+    s = float(fd["scales"].abs().max())
+    assert float((ana["scales"] - fd["scales"]).abs().max()) / s <= 1e-6
+    assert float((wrong - fd["scales"]).abs().max()) / s > 1e-6 or float(ana["scales"][2, 1].abs()) < 1e-3 * s
