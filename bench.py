@@ -39,17 +39,47 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--sh-degree", type=int, default=0,
                     help="active SH degree during the run (exploratory; the reference's 1000-iteration schedule trains at 0)")
+    ap.add_argument("--emulated-kernels", default=None, metavar="LIBMI355GS_EMU_SO",
+                    help="TEST MODE for the CPU tier only (tests/test_dist.py): run the spawn / rendezvous / reduction plumbing with "
+                         "the g++-built SIMT emulation of the kernels on CPU tensors over gloo.  Never a measurement; the line says so.")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: become the launcher (what replaces reference scripts/run_infer.sh:22-27,104-124 — one
+    # process per GPU, all started together, then waited for).  The driver starts the ranks itself with exactly this command.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}: the line would report the wrong n_gpus"
+    emulated = args.emulated_kernels is not None
+    if emulated:
+        from instantsplat_amd import _lib as _l
+        _l._use_library_for_testing(args.emulated_kernels)
+        dev, backend, shared_gpu = torch.device("cpu"), "gloo", False
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        ndev = torch.cuda.device_count()
+        # one rank per GPU.  With fewer GPUs than ranks (a 1-GPU box exercising the N-rank path) ranks share devices; RCCL
+        # refuses two ranks of one communicator on the same device, so the 40-byte reductions go over gloo in that case only.
+        shared_gpu = ndev < world
+        torch.cuda.set_device(local_rank % ndev)
+        dev = torch.device("cuda", local_rank % ndev)
+        backend = "gloo" if shared_gpu else "nccl"
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from instantsplat_amd import _lib
     from instantsplat_amd.arguments import OptimizationParams
@@ -83,11 +113,15 @@ def main():
 
     psnr_before = evaluate_psnr(st)
 
+    def dev_sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
     def sync():
-        torch.cuda.synchronize(dev)
+        dev_sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            dev_sync()
 
     # Sync-free driver: identical arithmetic and results to the reference-style loop (tests/ops_util.py::
     # check_run_ahead_equals_sync_loop), losses kept in a device ring, instance buffers sized from verified counts.
@@ -110,7 +144,7 @@ def main():
         kern[name] = (tot_ms.value / max(n.value, 1), n.value)
     L.mi355gs_profile_end()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -118,7 +152,7 @@ def main():
 
     # ---- the same loop with the reference's two host read-backs per iteration (loss.item(), instance count)
     n_sync = min(args.steps, 100)
-    for _ in range(5):
+    for _ in range(5 if not emulated else 1):
         train_iteration(st, fused_step=True)
     sync()
     ts = time.perf_counter()
@@ -135,14 +169,14 @@ def main():
     # ---- rasterize ms/frame (reference render.py:172-186 methodology, with an explicit synchronize)
     with torch.no_grad():
         cam = st.cameras[0]
-        for _ in range(5):
+        for _ in range(5 if not emulated else 1):
             render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
-        torch.cuda.synchronize(dev)
+        dev_sync()
         tr = time.perf_counter()
-        nfr = 50
+        nfr = 50 if not emulated else 1
         for _ in range(nfr):
             render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
-        torch.cuda.synchronize(dev)
+        dev_sync()
         raster_ms = 1e3 * (time.perf_counter() - tr) / nfr
 
     # ---- instance statistics of the trained scene (algorithmic bytes of the composite kernels)
@@ -159,7 +193,7 @@ def main():
     psnr_after = evaluate_psnr(st)
 
     # ---- final metric reduction: the only collective on the path
-    red = torch.tensor([psnr_after, 1.0, float(args.steps), elapsed], dtype=torch.float64, device=dev)
+    red = torch.tensor([psnr_after, 1.0, float(args.steps), elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
     mean_psnr = float(red[0] / red[1])
@@ -221,7 +255,9 @@ def main():
         out = {
             "metric": "train_iters_per_sec", "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not emulated else "synthetic — EMULATED KERNELS ON CPU (plumbing test mode, not a measurement)",
+            "collective_backend": (backend if world > 1 else None), "ranks_share_a_gpu": shared_gpu,
             "config": {"workload": f"BASELINE configs[2]: {V}-view sparse scene, {P} Gaussians, {res}x{res}, joint pose+Gaussian "
                                    f"optimisation (PerPointAdam, lambda_dssim 0.2, SH degree {args.sh_degree}"
                                    f"{' as in the reference first 1000 iterations' if args.sh_degree == 0 else ' (exploratory)'}"
