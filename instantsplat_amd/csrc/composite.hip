@@ -9,6 +9,29 @@
 // resident) through the depth-sorted per-tile index list.
 #include "common.h"
 
+// ---- measurement build only (make probe -> lib/libmi355gs_probe.so, loaded by tools/probe_composite.py, never by the
+// package): per-wave clocks and counts from inside the composite kernels.  The product library is compiled without it.
+#ifdef GS_PROBE
+__device__ unsigned long long* g_probe_buf = nullptr;
+__device__ unsigned int g_probe_cap = 0;
+extern "C" int mi355gs_probe_set(void* buf, unsigned int capacity_rows) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_probe_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_probe_cap), &capacity_rows, sizeof(capacity_rows)) == hipSuccess ? 0 : -1;
+}
+#define GS_PROBE_ROW 8
+#define GS_PROBE_CLOCK() ((unsigned long long)wall_clock64())
+#define GS_PROBE_STORE(row, c0, c1, c2, c3, c4, c5, c6, c7)                                          \
+  do {                                                                                                 \
+    if (g_probe_buf && (row) < g_probe_cap && (threadIdx.x & 63) == 0) {                               \
+      unsigned long long* p_ = g_probe_buf + (size_t)(row) * GS_PROBE_ROW;                            \
+      p_[0] = (c0); p_[1] = (c1); p_[2] = (c2); p_[3] = (c3); p_[4] = (c4); p_[5] = (c5); p_[6] = (c6); p_[7] = (c7); \
+    }                                                                                                  \
+  } while (0)
+#else
+#define GS_PROBE_CLOCK() 0ull
+#define GS_PROBE_STORE(...) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BATCH = 512;
@@ -75,6 +98,16 @@ __device__ __forceinline__ bool quad_hit(const float4& q0, const float4& q1, con
   return best >= -tau;
 }
 
+// log2 of the Gaussian falloff at offset (dx, dy): (d * (A, C)) * d summed, then fma(B dx, dy, sum) — the operation order of
+// the forward's packed form, with FMA contraction of the two squares switched off.  The backward must reproduce the
+// forward's alpha bit for bit, or a pair within rounding of alpha = 1/255 is blended by one pass and skipped by the other.
+__device__ __forceinline__ float gs_power2(float dx, float dy, float A, float C, float B) {
+#pragma clang fp contract(off)
+  const float sx = (dx * A) * dx, sy = (dy * C) * dy;
+  const float sum = sx + sy;
+  return fmaf(B * dx, dy, sum);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K6 forward
 // ------------------------------------------------------------------------------------------------
@@ -91,6 +124,8 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
+  [[maybe_unused]] unsigned long long pr_hits = 0, pr_wait = 0, pr_groups = 0, pr_walk = 0;
   // Backward units of this tile (segments of GS_SEG instances, see common.h): publish them, and leave every pixel's
   // (transmittance after the last blended Gaussian, accumulated colour) at each segment boundary for the backward.
   const uint32_t seg0 = seg_first[tile], nseg = seg_first[tile + 1] - seg0;
@@ -99,14 +134,16 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
       unit_tile[seg0 + sg] = make_uint2((uint32_t)(tile % gx) | ((uint32_t)(tile / gx) << 16), sg);
   uint32_t next_boundary = 0;  // boundaries [0, next_boundary) of this tile have been stored by this wave
 
-  // Tr: live transmittance, forced to 0 once the pixel is finished (T < 1e-4 reached, or outside the image);
-  // Tfin: transmittance after the last blended Gaussian (the value the reference stores as final_T)
-  float Tr = q.inside ? 1.0f : 0.0f, Tfin = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  // Tr: live transmittance while the pixel is still blending; once it is finished (T < 1e-4 would be reached) it holds MINUS
+  // the transmittance after the last blended Gaussian, so |Tr| is always the value the reference stores as final_T and the
+  // sign is the "done" flag (outside the image: -1 from the start)
+  float Tr = q.inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
 
   for (uint32_t base = start; base < end; base += BATCH) {
-    const int wave_done = __all(Tr == 0.0f);
+    const int wave_done = __all(Tr < 0.0f);
     if (lane == 0) s_done[wave] = wave_done;
+    [[maybe_unused]] const unsigned long long pr_w0 = GS_PROBE_CLOCK();
     __syncthreads();  // also fences the previous batch's LDS reads against the stores below
     if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
 #pragma unroll
@@ -118,6 +155,9 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
       }
     }
     __syncthreads();
+#ifdef GS_PROBE
+    pr_wait += GS_PROBE_CLOCK() - pr_w0;
+#endif
     if (wave_done) continue;
     const int cnt = (int)min((uint32_t)BATCH, end - base);
     for (int k = 0; k < cnt; k += 64) {
@@ -125,53 +165,71 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
       bool hit = false;
       if (i < cnt) hit = quad_hit(s_q0[i], s_q1[i], q);
       unsigned long long mask = __ballot(hit);
-      if (mask) {
-        // Software-pipelined walk over the hit mask, unrolled by two with ping-pong record registers: the next
-        // record's LDS reads are issued before the current record's math and no register copies are needed to
-        // rotate the prefetch.  The math is predicated (no exec-mask branches).
-        auto blend_one = [&](const float4& a0, const float4& a1, const float4& a2, int i2) {
+#ifdef GS_PROBE
+      pr_hits += __popcll(mask); pr_groups += 1;
+      const unsigned long long pr_k0 = GS_PROBE_CLOCK();
+#endif
+      // Walk over the hit mask, FOUR hits per step.  A hit has two parts: its alpha at this lane's pixel (record reads,
+      // exponent, v_exp_f32, threshold tests: ~50 issue cycles, independent of every other hit) and the transmittance
+      // recurrence (w = alpha T, T' = T - w, stop test, selects: a dependent chain through Tr).  Done hit by hit, the
+      // alpha of hit k+1 waited for the recurrence of hit k and the wave issued one instruction per dependency latency
+      // — with at most four waves per SIMD, and fewer once the light quadrants of a tile have finished, the kernel ran at
+      // ~45 % of its VALU issue bound (84 cycles/hit x 1.0 M hits = 37 us of an 84 us kernel; tools/isa_cost.py).  With the
+      // four alphas computed side by side the wave has four independent chains in flight, then four short recurrence steps.
+      // A group with fewer than four hits left is padded with alpha = 0, which is a no-op for every state variable
+      // (a live T >= 1e-4 stays, a finished one stays finished; w == 0 leaves colour and `last` alone).
+      while (mask) {
+        int idx[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          idx[u] = mask ? k + __ffsll(mask) - 1 : (u ? idx[u - 1] : k);
+          live[u] = mask != 0;   // wave-uniform: folds into the lane masks below as scalar logic
+          mask &= mask - 1;      // 0 stays 0
+        }
+        float al[4];
+        bool valid[4];
+        float4 col[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 a0 = s_q0[idx[u]], a1 = s_q1[idx[u]];
+          col[u] = s_q2[idx[u]];
           const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
           const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
           const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
           const float alpha = fminf(0.99f, a1.w * __builtin_amdgcn_exp2f(power2));
-          // a skipped Gaussian is a transparent one; a finished pixel carries Tr == 0, so `stop` (and nothing else)
-          // also covers "already done" and no separate flag is tested here
-          const float al = (power2 <= 0.0f && alpha >= ALPHA_MIN) ? alpha : 0.0f;
-          const float w0 = al * Tr;
+          // a skipped Gaussian is a transparent one (and so is the padding of a short group)
+          valid[u] = live[u] && power2 <= 0.0f && alpha >= ALPHA_MIN;
+          al[u] = valid[u] ? alpha : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          // A finished pixel carries its final transmittance NEGATED (outside the image: -1): w0 and test_T are then
+          // negative, so `stop` (and nothing else) also covers "already done", and one select updates the state.
+          const float w0 = al[u] * Tr;
           const float test_T = Tr - w0;  // T (1 - alpha)
           const bool stop = test_T < T_MIN;
           const float w = stop ? 0.0f : w0;
-          C0 += a2.x * w; C1 += a2.y * w; C2 += a2.z * w;
-          last = (w > 0.0f) ? (base - start) + (uint32_t)i2 + 1u : last;  // blended: alpha > 0 and not the stopping one
-          Tfin = stop ? Tfin : test_T;
-          Tr = stop ? 0.0f : test_T;
-        };
-        int iA = k + __ffsll(mask) - 1, iB = iA;
-        float4 A0 = s_q0[iA], A1 = s_q1[iA], A2 = s_q2[iA], B0 = A0, B1 = A1, B2 = A2;
-        for (;;) {
-          mask &= mask - 1;
-          const bool moreB = mask != 0;
-          if (moreB) iB = k + __ffsll(mask) - 1;
-          B0 = s_q0[iB]; B1 = s_q1[iB]; B2 = s_q2[iB];
-          blend_one(A0, A1, A2, iA);
-          if (!moreB) break;
-          mask &= mask - 1;
-          const bool moreA = mask != 0;
-          if (moreA) iA = k + __ffsll(mask) - 1;
-          A0 = s_q0[iA]; A1 = s_q1[iA]; A2 = s_q2[iA];
-          blend_one(B0, B1, B2, iB);
-          if (!moreA) break;
+          C0 += col[u].x * w; C1 += col[u].y * w; C2 += col[u].z * w;
+          // blended <=> alpha passed the tests and this is not the stopping Gaussian (w > 0 exactly then): mask logic
+          // on the two compare results instead of a third compare
+          last = (valid[u] && !stop) ? (base - start) + (uint32_t)idx[u] + 1u : last;
+          Tr = stop ? -fabsf(Tr) : test_T;
         }
       }
+#ifdef GS_PROBE
+      pr_walk += GS_PROBE_CLOCK() - pr_k0;
+#endif
       const uint32_t pos = (base - start) + (uint32_t)k + 64u;  // instances of the tile blended so far
       if (pos % GS_SEG == 0u) {
         next_boundary = pos / GS_SEG;
-        if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(Tfin, C0, C1, C2);
+        if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
       }
-      if (__all(Tr == 0.0f)) break;
+      if (__all(Tr < 0.0f)) break;
     }
   }
   // boundaries this wave never reached (all its pixels were finished, or the tile ended): the state no longer changes
+  const float Tfin = fabsf(Tr);
   for (uint32_t sg = next_boundary; sg + 1u < nseg; ++sg)
     if (seg0 + sg < max_units) bstate[(size_t)(seg0 + sg) * 256 + tid] = make_float4(Tfin, C0, C1, C2);
   if (q.inside) {
@@ -182,6 +240,8 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
     out_color[plane + pix] = C1 + Tfin * bg[1];
     out_color[2 * plane + pix] = C2 + Tfin * bg[2];
   }
+  GS_PROBE_STORE((uint32_t)tile * 4u + (uint32_t)wave, pr_t0, GS_PROBE_CLOCK(), pr_hits, pr_wait, pr_groups, (unsigned long long)(end - start),
+                 (unsigned long long)gs_physical_cu(), pr_walk);
 }
 
 __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity,
@@ -203,9 +263,19 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
 // them per pixel).  Gaussians whose box misses the wave's quadrant, or that lie behind every
 // pixel's last contributor, are skipped wave-wide.
 // ------------------------------------------------------------------------------------------------
-// One workgroup = one UNIT: segment `seg` (GS_SEG instances) of one tile's list.  The state a back-to-front replay would
-// carry into the segment comes from the forward's boundary record instead: T is the forward's own product, and the colour
-// behind is dL/dC . (final colour - colour accumulated in front of the boundary).
+// One WAVE = one UNIT: segment `seg` (GS_SEG instances) of one tile's list; a workgroup carries four independent units.
+// The state a back-to-front replay would carry into the segment comes from the forward's boundary record instead: T is the
+// forward's own product, and the colour behind is dL/dC . (final colour - colour accumulated in front of the boundary).
+//
+// A lane owns FOUR pixels, one in each 8x8 quadrant of the tile (same lane -> (x, y) offset inside every quadrant), so
+//  * culling stays wave-uniform per quadrant (four ballots, one scalar mask walk over their union), and
+//  * the nine moments of a Gaussian are first accumulated in registers over the lane's pixels (plain FMAs) and cross the
+//    lanes ONCE per (Gaussian, tile) instead of once per (Gaussian, quadrant): the 64-lane transposed reduction is
+//    ~125 issue cycles (8 v_permlane*_swap at 8 cycles, 9 DPP / select ops at 4; tools/ubench/valu_rate.hip) against
+//    ~100 for one quadrant's pixel math, and a Gaussian touches 1.5-2 quadrants of a tile on the benchmark scenes —
+//    round 1 paid the reduction (and nine atomics) for every one of them.
+constexpr int BW_UNITS = 4;  // units (waves) per workgroup
+
 __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
@@ -214,150 +284,182 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
                                                         const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
                                                         const uint2* __restrict__ unit_tile, const float4* __restrict__ bstate,
                                                         const uint32_t* __restrict__ meta, uint32_t max_units) {
-  constexpr int BATCH = GS_SEG;
-  __shared__ float4 s_q0[BATCH];
-  __shared__ float4 s_q1[BATCH];
-  __shared__ float4 s_q2[BATCH];
-  __shared__ uint32_t s_max[4];
-  const uint32_t unit = blockIdx.x;
-  if (unit >= min(meta[1], max_units)) return;
+  __shared__ float4 s_q0[BW_UNITS][GS_SEG];
+  __shared__ float4 s_q1[BW_UNITS][GS_SEG];
+  __shared__ float4 s_q2[BW_UNITS][GS_SEG];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t unit = blockIdx.x * (uint32_t)BW_UNITS + (uint32_t)wave;
+  if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
   const uint2 entry = unit_tile[unit];
   const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
   const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
   const int tile = ty * gx + tx;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const Quad q = make_quad_xy(tx, ty, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t boff = seg * GS_SEG;  // contributor index (0-based) of this unit's first instance
   if (end <= start + boff) return;
+  float4* __restrict__ q0s = s_q0[wave];
+  float4* __restrict__ q1s = s_q1[wave];
+  float4* __restrict__ q2s = s_q2[wave];
 
-  const size_t pix = (size_t)q.py * W + q.px, plane = (size_t)W * H;
-  const float T_final = q.inside ? final_T[pix] : 0.f;
-  const uint32_t last = q.inside ? n_contrib[pix] : 0u;
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-  if (q.inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[plane + pix]; g2 = dL_dpix[2 * plane + pix]; }
-  const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-  const gs_v2f g01 = {g0, g1};
-
+  // ---- the lane's four pixels
+  const int px0 = tx * GS_TILE + (lane & 7), py0 = ty * GS_TILE + (lane >> 3);
+  const float fx0 = (float)px0, fy0 = (float)py0;
+  const size_t plane = (size_t)W * H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  float Tr[4], behind[4], g0[4], g1[4], g2[4];
+  int lim[4];          // instances of this segment with index < lim lie at or in front of the pixel's last contributor
+  uint32_t wmaxq[4];   // wave-wide max of `last` per quadrant
+  size_t pixq[4];
+  bool insideq[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int px = px0 + (qd & 1) * 8, py = py0 + (qd >> 1) * 8;
+    insideq[qd] = px < W && py < H;
+    pixq[qd] = (size_t)py * W + px;
+    const float T_final = insideq[qd] ? final_T[pixq[qd]] : 0.f;
+    const uint32_t last = insideq[qd] ? n_contrib[pixq[qd]] : 0u;
+    g0[qd] = g1[qd] = g2[qd] = 0.f;
+    if (insideq[qd]) { g0[qd] = dL_dpix[pixq[qd]]; g1[qd] = dL_dpix[plane + pixq[qd]]; g2[qd] = dL_dpix[2 * plane + pixq[qd]]; }
+    Tr[qd] = T_final;
+    behind[qd] = T_final * (bg0 * g0[qd] + bg1 * g1[qd] + bg2 * g2[qd]);  // dL/dC . (everything behind, background included)
+    lim[qd] = (int)last - (int)boff;
+    wmaxq[qd] = gs_wave_max_u32(last);
+  }
   // the tile only needs instances [0, max over pixels of last)
-  const uint32_t wmax = gs_wave_max_u32(last);
-  if (lane == 0) s_max[wave] = wmax;
-  __syncthreads();
-  const uint32_t tile_max = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), end - start);
+  const uint32_t tile_max = min(max(max(wmaxq[0], wmaxq[1]), max(wmaxq[2], wmaxq[3])), end - start);
   if (tile_max <= boff) return;  // every pixel's last contributor lies in front of this segment
-
-  const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
-  const bool out_lane = (lane & 14) == 0 || lane == 2;                 // the nine lanes that hold a finished sum
-  const int out_comp = lane == 2 ? 8 : (lane >> 4) + 4 * (lane & 1);   // ... and which of the nine it is
-  float Tr = T_final;
-  float behind = T_final * bg_dot;  // dL/dC . (everything composited behind the current Gaussian, background included)
   if (boff + GS_SEG < tile_max) {
     // not the deepest active segment: resume from the forward's record at this segment's far boundary
     const uint32_t slot = seg_first[tile] + seg;
     if (slot < max_units) {
-      const float4 b = bstate[(size_t)slot * 256 + tid];
-      Tr = b.x;
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-      if (q.inside) { c0 = out_color[pix]; c1 = out_color[plane + pix]; c2 = out_color[2 * plane + pix]; }
-      behind = (c0 - b.y) * g0 + (c1 - b.z) * g1 + (c2 - b.w) * g2;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 b = bstate[(size_t)slot * 256 + qd * 64 + lane];
+        Tr[qd] = b.x;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (insideq[qd]) { c0 = out_color[pixq[qd]]; c1 = out_color[plane + pixq[qd]]; c2 = out_color[2 * plane + pixq[qd]]; }
+        behind[qd] = (c0 - b.y) * g0[qd] + (c1 - b.z) * g1[qd] + (c2 - b.w) * g2[qd];
+      }
     }
   }
 
+  // ---- stage the unit's records (lane i <- instance boff + i); only this wave reads them back
+  const int cnt = (int)min((uint32_t)GS_SEG, tile_max - boff);
+  if (lane < cnt) {
+    const uint32_t id = list[start + boff + lane];
+    const GsRec* r = recs + id;
+    const float4 c = r->q2;  // (r, g, b, depth): depth is not used here, its slot carries the Gaussian's index
+    q0s[lane] = r->q0; q1s[lane] = r->q1; q2s[lane] = make_float4(c.x, c.y, c.z, __uint_as_float(id));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- cull: record `lane` against the four quadrant boxes; instances behind every pixel of a quadrant are dropped too
+  unsigned long long mq[4];
   {
+    float4 r0 = make_float4(0.f, 0.f, -1.f, -1.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < cnt) { r0 = q0s[lane]; r1 = q1s[lane]; }
 #pragma unroll
-    for (int sl = tid; sl < BATCH; sl += 256) {
-      if (boff + sl < tile_max) {
-        const uint32_t id = list[start + boff + sl];
-        const GsRec* r = recs + id;
-        const float4 c = r->q2;  // (r, g, b, depth): depth is not used here, its slot carries the Gaussian's index
-        s_q0[sl] = r->q0; s_q1[sl] = r->q1; s_q2[sl] = make_float4(c.x, c.y, c.z, __uint_as_float(id));
-      }
+    for (int qd = 0; qd < 4; ++qd) {
+      Quad q;
+      q.x0 = (float)(tx * GS_TILE + (qd & 1) * 8); q.x1 = q.x0 + 7.f;
+      q.y0 = (float)(ty * GS_TILE + (qd >> 1) * 8); q.y1 = q.y0 + 7.f;
+      const bool hit = lane < cnt && boff + (uint32_t)lane < wmaxq[qd] && quad_hit(r0, r1, q);
+      mq[qd] = __ballot(hit);
     }
-    __syncthreads();
-    if (boff >= wmax) return;  // nothing in this segment is in front of any of this wave's pixels' last contributor
-    const int cnt = (int)min((uint32_t)BATCH, tile_max - boff);
-    for (int k = ((cnt - 1) >> 6) << 6; k >= 0; k -= 64) {
-      if (boff + (uint32_t)k >= wmax) continue;
-      const int i = k + lane;
-      bool hit = false;
-      if (i < cnt && boff + (uint32_t)i < wmax) hit = quad_hit(s_q0[i], s_q1[i], q);
-      unsigned long long mask = __ballot(hit);
-      if (mask) {
-        // back-to-front walk over the hit mask, unrolled by two with ping-pong record registers (see the forward kernel)
-        auto replay_one = [&](const float4& a0, const float4& a1, const float4& a2, const int i2) {
-          const uint32_t id = __float_as_uint(a2.w);
-          const uint32_t contributor = boff + (uint32_t)i2 + 1u;  // 1-based position in the tile list
-          const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
-          const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
-          const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
-          // opacity * G, unclamped: the reference clamps alpha to 0.99 but lets dL/dalpha through to G unchanged, so
-          // G * dL/dG = (opacity G) dL/dalpha needs the unclamped product.  power2 > 0 can make it inf; such lanes are
-          // invalid and every use below selects, never multiplies, them away.
-          const float au = a1.w * __builtin_amdgcn_exp2f(power2);
-          const bool valid = contributor <= last && power2 <= 0.0f && au >= ALPHA_MIN;
-          if (__any(valid)) {
-            // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T and the colour behind then
-            // evolve exactly as if it had been skipped, so the replay state needs no per-field selects.
-            const float av = valid ? au : 0.f;
-            const float al = fminf(0.99f, av);
-            const float inv_one_m = __builtin_amdgcn_rcpf(1.f - al);  // v_rcp_f32 (1 ulp) instead of two IEEE divisions
-            Tr = Tr * inv_one_m;                                       // transmittance in front of this Gaussian
-            // dC/dalpha_k = c_k T_k - (sum_{j behind k} c_j alpha_j T_j + T_final bg) / (1 - alpha_k).  Contracted with
-            // dL/dC first, the "colour behind" term is ONE running scalar (behind) instead of the reference's three-channel
-            // accum_rec / last_color / last_alpha recursion (same quantity: accum_rec_k = sum_{j>k} c_j alpha_j T_j / T_{k+1}).
-            const float cg = a2.x * g0 + a2.y * g1 + a2.z * g2;
-            const float dL_dalpha = Tr * cg - behind * inv_one_m;
-            const float dchannel = al * Tr;
-            behind += cg * dchannel;
-            // Moments of w = G * dL/dG over the wave's pixels: every screen-space gradient of this Gaussian is a fixed
-            // linear combination of them (coefficients = its own conic / opacity), applied once per Gaussian in
-            // k_preprocess_bwd instead of once per pixel here:
-            //   dL/dconic = (-1/2 sum w dx^2, -sum w dx dy, -1/2 sum w dy^2),  dL/dopacity = sum w / opacity,
-            //   dL/dmean2D = -(a sum w dx + b sum w dy, c sum w dy + b sum w dx) * (W/2, H/2)
-            const float w = av * dL_dalpha;
-            const gs_v2f t01 = gs_v2f{w, w} * d;               // sum w dx, sum w dy
-            const gs_v2f t24 = t01 * d;                        // sum w dx^2, sum w dy^2
-            const float t0 = t01[0], t1 = t01[1], t2 = t24[0], t4 = t24[1];
-            const float t3 = t0 * d[1];                        // sum w dx dy
-            const float t5 = w;                                // sum w
-            const gs_v2f t67 = gs_v2f{dchannel, dchannel} * g01;
-            const float t6 = t67[0], t7 = t67[1], t8 = gs_opaque(dchannel * g2);  // dL/drgb
-            // Nine values x 64 lanes -> nine sums, transposed so that every step halves the number of live values:
-            // rows first (v_permlane16/32_swap pair steps, two ops per pair), then lane bits 0 and 1 inside the row (DPP
-            // quad_perm pair steps), then the four quads of the row (row_ror:4, row_ror:8) on the single survivor.
-            const float u0 = gs_pair_reduce_rows16(t0, t1), u1 = gs_pair_reduce_rows16(t2, t3);
-            const float u2 = gs_pair_reduce_rows16(t4, t5), u3 = gs_pair_reduce_rows16(t6, t7);
-            const float u4 = gs_pair_reduce_rows16(t8, t8);
-            const float v0 = gs_pair_reduce_rows32(u0, u1);  // row r holds component r     (t0..t3)
-            const float v1 = gs_pair_reduce_rows32(u2, u3);  // row r holds component 4 + r (t4..t7)
-            const float v2 = gs_pair_reduce_rows32(u4, u4);  // every row holds component 8
-            const float y0 = gs_pair_reduce<0xB1>(bit0, v0, v1);
-            const float y1 = v2 + gs_dpp<0xB1>(v2);
-            float mine = gs_pair_reduce<0x4E>(bit1, y0, y1);
-            mine += gs_dpp<0x124>(mine);
-            mine += gs_dpp<0x128>(mine);
-            // lanes 16r and 16r+1 now hold components r and 4+r, lane 2 holds component 8
-            if (out_lane) atomicAdd(reinterpret_cast<float*>(grads + id) + out_comp, mine);
-          }
-        };
-        int iA = k + 63 - __clzll((long long)mask), iB = iA;
-        float4 A0 = s_q0[iA], A1 = s_q1[iA], A2 = s_q2[iA], B0 = A0, B1 = A1, B2 = A2;
-        for (;;) {
-          mask &= ~(1ull << (iA - k));
-          const bool moreB = mask != 0;
-          if (moreB) iB = k + 63 - __clzll((long long)mask);
-          B0 = s_q0[iB]; B1 = s_q1[iB]; B2 = s_q2[iB];
-          replay_one(A0, A1, A2, iA);
-          if (!moreB) break;
-          mask &= ~(1ull << (iB - k));
-          const bool moreA = mask != 0;
-          if (moreA) iA = k + 63 - __clzll((long long)mask);
-          A0 = s_q0[iA]; A1 = s_q1[iA]; A2 = s_q2[iA];
-          replay_one(B0, B1, B2, iB);
-          if (!moreA) break;
+  }
+  unsigned long long many = (mq[0] | mq[1]) | (mq[2] | mq[3]);
+  if (!many) return;
+
+  const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
+  const bool out_lane = (lane & 14) == 0 || lane == 2;                 // the nine lanes that hold a finished sum
+  const int out_comp = lane == 2 ? 8 : (lane >> 4) + 4 * (lane & 1);   // ... and which of the nine it is
+
+  // One (Gaussian, tile) step of the back-to-front replay: the pixels of every quadrant the Gaussian reaches, then ONE
+  // reduction + one row of nine atomics.
+  auto replay_one = [&](const float4& a0, const float4& a1, const float4& a2, const int i2) {
+    const uint32_t id = __float_as_uint(a2.w);
+    const float dx0 = a0.x - fx0, dy0 = a0.y - fy0;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m7 = 0.f, m8 = 0.f;
+    bool any_valid = false;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      if ((mq[qd] >> i2) & 1ull) {   // wave-uniform: scalar bit test
+        const float dx = (qd & 1) ? dx0 - 8.f : dx0, dy = (qd >> 1) ? dy0 - 8.f : dy0;
+        const float power2 = gs_power2(dx, dy, a1.x, a1.y, a1.z);  // log2 of the falloff, the forward's bits
+        // opacity * G, unclamped: the reference clamps alpha to 0.99 but lets dL/dalpha through to G unchanged, so
+        // G * dL/dG = (opacity G) dL/dalpha needs the unclamped product.  power2 > 0 can make it inf; such lanes are
+        // invalid and every use below selects, never multiplies, them away.
+        const float au = a1.w * __builtin_amdgcn_exp2f(power2);
+        const bool valid = i2 < lim[qd] && power2 <= 0.0f && au >= ALPHA_MIN;
+        if (__any(valid)) {
+          any_valid = true;
+          // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T and the colour behind then
+          // evolve exactly as if it had been skipped, so the replay state needs no per-field selects.
+          const float av = valid ? au : 0.f;
+          const float al = __builtin_amdgcn_fmed3f(av, 0.0f, 0.99f);     // min(0.99, av) for av >= 0: one v_med3_f32
+          const float inv_one_m = __builtin_amdgcn_rcpf(1.f - al);        // v_rcp_f32 (1 ulp) instead of two IEEE divisions
+          Tr[qd] = Tr[qd] * inv_one_m;                                    // transmittance in front of this Gaussian
+          // dC/dalpha_k = c_k T_k - (sum_{j behind k} c_j alpha_j T_j + T_final bg) / (1 - alpha_k).  Contracted with
+          // dL/dC first, the "colour behind" term is ONE running scalar (behind) instead of the reference's three-channel
+          // accum_rec / last_color / last_alpha recursion (same quantity: accum_rec_k = sum_{j>k} c_j alpha_j T_j / T_{k+1}).
+          const float cg = a2.x * g0[qd] + a2.y * g1[qd] + a2.z * g2[qd];
+          const float dL_dalpha = Tr[qd] * cg - behind[qd] * inv_one_m;
+          const float dchannel = al * Tr[qd];
+          behind[qd] += cg * dchannel;
+          // Moments of w = G * dL/dG over the Gaussian's pixels: every screen-space gradient of this Gaussian is a fixed
+          // linear combination of them (coefficients = its own conic / opacity), applied once per Gaussian in
+          // k_preprocess_bwd instead of once per pixel here:
+          //   dL/dconic = (-1/2 sum w dx^2, -sum w dx dy, -1/2 sum w dy^2),  dL/dopacity = sum w / opacity,
+          //   dL/dmean2D = -(a sum w dx + b sum w dy, c sum w dy + b sum w dx) * (W/2, H/2)
+          const float w = av * dL_dalpha;
+          const float wdx = w * dx, wdy = w * dy;
+          m0 += wdx; m1 += wdy;
+          m2 = fmaf(wdx, dx, m2); m3 = fmaf(wdx, dy, m3); m4 = fmaf(wdy, dy, m4);
+          m5 += w;
+          m6 = fmaf(dchannel, g0[qd], m6); m7 = fmaf(dchannel, g1[qd], m7); m8 = fmaf(dchannel, g2[qd], m8);  // dL/drgb
         }
       }
     }
+    if (any_valid) {
+      // Nine values x 64 lanes -> nine sums, transposed so that every step halves the number of live values:
+      // rows first (v_permlane16/32_swap pair steps, two ops per pair), then lane bits 0 and 1 inside the row (DPP
+      // quad_perm pair steps), then the four quads of the row (row_ror:4, row_ror:8) on the single survivor.
+      const float u0 = gs_pair_reduce_rows16(m0, m1), u1 = gs_pair_reduce_rows16(m2, m3);
+      const float u2 = gs_pair_reduce_rows16(m4, m5), u3 = gs_pair_reduce_rows16(m6, m7);
+      const float m8o = gs_opaque(m8);
+      const float u4 = gs_pair_reduce_rows16(m8o, m8o);
+      const float v0 = gs_pair_reduce_rows32(u0, u1);  // row r holds component r     (m0..m3)
+      const float v1 = gs_pair_reduce_rows32(u2, u3);  // row r holds component 4 + r (m4..m7)
+      const float v2 = gs_pair_reduce_rows32(u4, u4);  // every row holds component 8
+      const float y0 = gs_pair_reduce<0xB1>(bit0, v0, v1);
+      const float y1 = v2 + gs_dpp<0xB1>(v2);
+      float mine = gs_pair_reduce<0x4E>(bit1, y0, y1);
+      mine += gs_dpp<0x124>(mine);
+      mine += gs_dpp<0x128>(mine);
+      // lanes 16r and 16r+1 now hold components r and 4+r, lane 2 holds component 8
+      if (out_lane) atomicAdd(reinterpret_cast<float*>(grads + id) + out_comp, mine);
+    }
+  };
+
+  // back-to-front walk over the union mask, unrolled by two with ping-pong record registers: the next record's LDS reads
+  // (wave-uniform addresses: broadcasts) are issued before the current record's math
+  int iA = 63 - __clzll((long long)many), iB = iA;
+  float4 A0 = q0s[iA], A1 = q1s[iA], A2 = q2s[iA], B0 = A0, B1 = A1, B2 = A2;
+  for (;;) {
+    many &= ~(1ull << iA);
+    const bool moreB = many != 0;
+    if (moreB) iB = 63 - __clzll((long long)many);
+    B0 = q0s[iB]; B1 = q1s[iB]; B2 = q2s[iB];
+    replay_one(A0, A1, A2, iA);
+    if (!moreB) break;
+    many &= ~(1ull << iB);
+    const bool moreA = many != 0;
+    if (moreA) iA = 63 - __clzll((long long)many);
+    A0 = q0s[iA]; A1 = q1s[iA]; A2 = q2s[iA];
+    replay_one(B0, B1, B2, iB);
+    if (!moreA) break;
   }
 }
 
@@ -398,13 +500,14 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
   return 0;
 }
 
-// one workgroup per backward unit; the grid covers every unit the buffers can hold, workgroups past the frame's count exit
+// one wave per backward unit (BW_UNITS per workgroup); the grid covers every unit the buffers can hold, waves past the
+// frame's count exit
 int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint32_t* seg_first, const uint2* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units) {
-  hipLaunchKernelGGL(k_composite_bwd, dim3(max_units), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,
+  hipLaunchKernelGGL(k_composite_bwd, dim3((max_units + BW_UNITS - 1) / BW_UNITS), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,
                      n_contrib, dL_dpix, grads, out_color, seg_first, unit_tile, bstate, meta, max_units);
   return 0;
 }

@@ -392,7 +392,10 @@ template <class T> static inline T __hip_atomic_load(const T* p, int, int) { ret
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
-static inline void __builtin_amdgcn_wave_barrier() {}
+static inline unsigned long long __ballot(int pred);
+static inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }   // the fibers of a wave meet here
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
