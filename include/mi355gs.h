@@ -112,6 +112,12 @@ int mi355gs_raster_mark_visible(void* stream, int P, const float* means3D, const
  * (SURVEY.md 8d).  stats: device int64[2]. */
 int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, int64_t* stats);
 
+/* Tuning / test knob of the segmented backward (csrc/common.h, GS_MIN_UNITS): a frame's backward units are lengthened
+ * (2, 4, 8 chunks of 64 instances) only while at least `min_units` of them remain.  Returns the previous value;
+ * min_units <= 0 only queries.  Process-wide; the default (12288) is what every measurement uses — tests lower it to
+ * run the multi-chunk path on small scenes. */
+int mi355gs_tune_min_units(int min_units);
+
 /* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that
  * cannot see the kernels (they are enqueued inside this library) can still attribute time to them.
  * kind: 0 = composite forward, 1 = composite backward.  profile_read synchronises the recorded events

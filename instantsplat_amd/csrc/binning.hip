@@ -90,30 +90,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     __syncthreads();
   }
   if (seg_first) {
-    // first backward unit of every tile: exclusive scan of ceil(count / GS_SEG) (same two-level scan as below)
-    uint32_t lseg = 0;
-    for (int i = lo; i < hi; ++i) lseg += (count[i] + GS_SEG - 1) / GS_SEG;
-    uint32_t iseg = lseg;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t o = __shfl_up(iseg, d);
-      if (lane >= d) iseg += o;
-    }
+    // Backward units (common.h): first unit of every tile = exclusive scan of ceil(count / unit length), for each of the
+    // four unit lengths the host may pick once it knows the frame's instance capacity (same two-level scan as below)
     __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
-    if (lane == 63) seg_wave[wave] = iseg;
-    __syncthreads();
-    uint32_t soff = 0, stot = 0;
+    for (int level = 0; level < GS_UNIT_LEVELS; ++level) {
+      const uint32_t seg_len = (uint32_t)GS_SEG << level;
+      uint32_t* __restrict__ sf = seg_first + (size_t)level * (T + 1);
+      uint32_t lseg = 0;
+      for (int i = lo; i < hi; ++i) lseg += (count[i] + seg_len - 1) / seg_len;
+      uint32_t iseg = lseg;
 #pragma unroll
-    for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w) {
-      if (w < wave) soff += seg_wave[w];
-      stot += seg_wave[w];
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(iseg, d);
+        if (lane >= d) iseg += o;
+      }
+      __syncthreads();   // seg_wave of the previous level has been read
+      if (lane == 63) seg_wave[wave] = iseg;
+      __syncthreads();
+      uint32_t soff = 0, stot = 0;
+#pragma unroll
+      for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w) {
+        if (w < wave) soff += seg_wave[w];
+        stot += seg_wave[w];
+      }
+      uint32_t srun = soff + iseg - lseg;
+      for (int i = lo; i < hi; ++i) {
+        sf[i] = srun;
+        srun += (count[i] + seg_len - 1) / seg_len;
+      }
+      if (tid == 0) { sf[T] = stot; meta[4 + level] = stot; }
     }
-    uint32_t srun = soff + iseg - lseg;
-    for (int i = lo; i < hi; ++i) {
-      seg_first[i] = srun;
-      srun += (count[i] + GS_SEG - 1) / GS_SEG;
-    }
-    if (tid == 0) { seg_first[T] = stot; meta[1] = stot; }
   }
   uint32_t run = wave_off + incl - local;
   for (int i = lo; i < hi; ++i) {
@@ -564,6 +570,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles(int T, const uint32
 }
 
 }  // namespace
+
+static int g_min_units = GS_MIN_UNITS;
+extern "C" int mi355gs_tune_min_units(int min_units) {
+  const int old = g_min_units;
+  if (min_units > 0) g_min_units = min_units;
+  return old;
+}
+int gs_unit_level(int64_t capacity) {
+  int level = 0;
+  while (level + 1 < GS_UNIT_LEVELS && capacity / ((int64_t)(2 * GS_SEG) << level) >= (int64_t)g_min_units) ++level;
+  return level;
+}
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
                          GsSched* sched, uint32_t* meta, uint32_t* seg_first) {

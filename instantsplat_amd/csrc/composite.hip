@@ -116,7 +116,8 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
                                                    const GsRec* __restrict__ recs, const float* __restrict__ bg,
                                                    float* __restrict__ out_color, float* __restrict__ final_T,
                                                    uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_first,
-                                                   uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
+                                                   uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units,
+                                                   uint32_t seg_len) {
   __shared__ float4 s_q0[BATCH];
   __shared__ float4 s_q1[BATCH];
   __shared__ float4 s_q2[BATCH];
@@ -126,7 +127,7 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
   [[maybe_unused]] unsigned long long pr_hits = 0, pr_wait = 0, pr_groups = 0, pr_walk = 0;
-  // Backward units of this tile (segments of GS_SEG instances, see common.h): publish them, and leave every pixel's
+  // Backward units of this tile (segments of seg_len instances, see common.h): publish them, and leave every pixel's
   // (transmittance after the last blended Gaussian, accumulated colour) at each segment boundary for the backward.
   const uint32_t seg0 = seg_first[tile], nseg = seg_first[tile + 1] - seg0;
   for (uint32_t sg = tid; sg < nseg; sg += 256)
@@ -221,8 +222,8 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
       pr_walk += GS_PROBE_CLOCK() - pr_k0;
 #endif
       const uint32_t pos = (base - start) + (uint32_t)k + 64u;  // instances of the tile blended so far
-      if (pos % GS_SEG == 0u) {
-        next_boundary = pos / GS_SEG;
+      if (pos % seg_len == 0u) {
+        next_boundary = pos / seg_len;
         if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
       }
       if (__all(Tr < 0.0f)) break;
@@ -250,10 +251,11 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
                                                         float* __restrict__ out_color, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order,
                                                         GsSched* sched, int NB, const uint32_t* __restrict__ seg_first,
-                                                        uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units) {
+                                                        uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units,
+                                                        uint32_t seg_len) {
   GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
                           composite_fwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T, n_contrib,
-                                             seg_first, unit_tile, bstate, max_units))
+                                             seg_first, unit_tile, bstate, max_units, seg_len))
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,6 +278,9 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
 //    round 1 paid the reduction (and nine atomics) for every one of them.
 constexpr int BW_UNITS = 4;  // units (waves) per workgroup
 
+// CHUNKS: 64-instance chunks per unit (1, or 0 = the run-time value `chunks` for the longer units of big frames; the
+// one-chunk instantiation keeps 74 VGPRs / six waves per SIMD, the loop over chunks costs 15 more)
+template <int CHUNKS>
 __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
@@ -283,19 +288,20 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
                                                         const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
                                                         const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
                                                         const uint2* __restrict__ unit_tile, const float4* __restrict__ bstate,
-                                                        const uint32_t* __restrict__ meta, uint32_t max_units) {
+                                                        const uint32_t* __restrict__ n_units, uint32_t max_units, uint32_t chunks_rt) {
   __shared__ float4 s_q0[BW_UNITS][GS_SEG];
   __shared__ float4 s_q1[BW_UNITS][GS_SEG];
   __shared__ float4 s_q2[BW_UNITS][GS_SEG];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t unit = blockIdx.x * (uint32_t)BW_UNITS + (uint32_t)wave;
-  if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
+  if (unit >= min(n_units[0], max_units)) return;  // wave-uniform; no workgroup barrier below
   const uint2 entry = unit_tile[unit];
   const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
   const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
   const int tile = ty * gx + tx;
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  const uint32_t boff = seg * GS_SEG;  // contributor index (0-based) of this unit's first instance
+  const uint32_t chunks = CHUNKS ? (uint32_t)CHUNKS : chunks_rt, seg_len = chunks * GS_SEG;   // instances per unit
+  const uint32_t boff = seg * seg_len;  // contributor index (0-based) of this unit's first instance
   if (end <= start + boff) return;
   float4* __restrict__ q0s = s_q0[wave];
   float4* __restrict__ q1s = s_q1[wave];
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
   const size_t plane = (size_t)W * H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   float Tr[4], behind[4], g0[4], g1[4], g2[4];
-  int lim[4];          // instances of this segment with index < lim lie at or in front of the pixel's last contributor
+  int lastq[4];        // the pixel's last contributor (1-based position in the tile list; 0: none)
   uint32_t wmaxq[4];   // wave-wide max of `last` per quadrant
   size_t pixq[4];
   bool insideq[4];
@@ -322,14 +328,14 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
     if (insideq[qd]) { g0[qd] = dL_dpix[pixq[qd]]; g1[qd] = dL_dpix[plane + pixq[qd]]; g2[qd] = dL_dpix[2 * plane + pixq[qd]]; }
     Tr[qd] = T_final;
     behind[qd] = T_final * (bg0 * g0[qd] + bg1 * g1[qd] + bg2 * g2[qd]);  // dL/dC . (everything behind, background included)
-    lim[qd] = (int)last - (int)boff;
-    wmaxq[qd] = gs_wave_max_u32(last);
+    lastq[qd] = (int)last;
+    wmaxq[qd] = __builtin_amdgcn_readfirstlane(gs_wave_max_u32(last));   // wave-uniform: keep it in an SGPR
   }
   // the tile only needs instances [0, max over pixels of last)
   const uint32_t tile_max = min(max(max(wmaxq[0], wmaxq[1]), max(wmaxq[2], wmaxq[3])), end - start);
   if (tile_max <= boff) return;  // every pixel's last contributor lies in front of this segment
-  if (boff + GS_SEG < tile_max) {
-    // not the deepest active segment: resume from the forward's record at this segment's far boundary
+  if (boff + seg_len < tile_max) {
+    // not the deepest active unit of the tile: resume from the forward's record at this unit's far boundary
     const uint32_t slot = seg_first[tile] + seg;
     if (slot < max_units) {
 #pragma unroll
@@ -343,42 +349,15 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
     }
   }
 
-  // ---- stage the unit's records (lane i <- instance boff + i); only this wave reads them back
-  const int cnt = (int)min((uint32_t)GS_SEG, tile_max - boff);
-  if (lane < cnt) {
-    const uint32_t id = list[start + boff + lane];
-    const GsRec* r = recs + id;
-    const float4 c = r->q2;  // (r, g, b, depth): depth is not used here, its slot carries the Gaussian's index
-    q0s[lane] = r->q0; q1s[lane] = r->q1; q2s[lane] = make_float4(c.x, c.y, c.z, __uint_as_float(id));
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // ---- cull: record `lane` against the four quadrant boxes; instances behind every pixel of a quadrant are dropped too
-  unsigned long long mq[4];
-  {
-    float4 r0 = make_float4(0.f, 0.f, -1.f, -1.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < cnt) { r0 = q0s[lane]; r1 = q1s[lane]; }
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      Quad q;
-      q.x0 = (float)(tx * GS_TILE + (qd & 1) * 8); q.x1 = q.x0 + 7.f;
-      q.y0 = (float)(ty * GS_TILE + (qd >> 1) * 8); q.y1 = q.y0 + 7.f;
-      const bool hit = lane < cnt && boff + (uint32_t)lane < wmaxq[qd] && quad_hit(r0, r1, q);
-      mq[qd] = __ballot(hit);
-    }
-  }
-  unsigned long long many = (mq[0] | mq[1]) | (mq[2] | mq[3]);
-  if (!many) return;
-
   const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
   const bool out_lane = (lane & 14) == 0 || lane == 2;                 // the nine lanes that hold a finished sum
   const int out_comp = lane == 2 ? 8 : (lane >> 4) + 4 * (lane & 1);   // ... and which of the nine it is
+  unsigned long long mq[4];  // per quadrant: which of the staged chunk's records reach it
+  uint32_t cb = 0;           // contributor index (0-based) of the staged chunk's first instance
 
   // One (Gaussian, tile) step of the back-to-front replay: the pixels of every quadrant the Gaussian reaches, then ONE
   // reduction + one row of nine atomics.
-  auto replay_one = [&](const float4& a0, const float4& a1, const float4& a2, const int i2) {
+  auto replay_one = [&](const float2& a0, const float4& a1, const float4& a2, const int i2) {
     const uint32_t id = __float_as_uint(a2.w);
     const float dx0 = a0.x - fx0, dy0 = a0.y - fy0;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m7 = 0.f, m8 = 0.f;
@@ -392,7 +371,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
         // G * dL/dG = (opacity G) dL/dalpha needs the unclamped product.  power2 > 0 can make it inf; such lanes are
         // invalid and every use below selects, never multiplies, them away.
         const float au = a1.w * __builtin_amdgcn_exp2f(power2);
-        const bool valid = i2 < lim[qd] && power2 <= 0.0f && au >= ALPHA_MIN;
+        // (contributor = cb + i2 + 1 <= last: the instance lies at or in front of the pixel's last contributor)
+        const bool valid = (int)cb + i2 < lastq[qd] && power2 <= 0.0f && au >= ALPHA_MIN;
         if (__any(valid)) {
           any_valid = true;
           // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T and the colour behind then
@@ -443,23 +423,59 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
     }
   };
 
-  // back-to-front walk over the union mask, unrolled by two with ping-pong record registers: the next record's LDS reads
-  // (wave-uniform addresses: broadcasts) are issued before the current record's math
-  int iA = 63 - __clzll((long long)many), iB = iA;
-  float4 A0 = q0s[iA], A1 = q1s[iA], A2 = q2s[iA], B0 = A0, B1 = A1, B2 = A2;
-  for (;;) {
-    many &= ~(1ull << iA);
-    const bool moreB = many != 0;
-    if (moreB) iB = 63 - __clzll((long long)many);
-    B0 = q0s[iB]; B1 = q1s[iB]; B2 = q2s[iB];
-    replay_one(A0, A1, A2, iA);
-    if (!moreB) break;
-    many &= ~(1ull << iB);
-    const bool moreA = many != 0;
-    if (moreA) iA = 63 - __clzll((long long)many);
-    A0 = q0s[iA]; A1 = q1s[iA]; A2 = q2s[iA];
-    replay_one(B0, B1, B2, iB);
-    if (!moreA) break;
+  // ---- the unit's chunks of GS_SEG instances, deepest first
+#pragma unroll 1
+  for (int c = (int)chunks - 1; c >= 0; --c) {
+    cb = boff + (uint32_t)c * GS_SEG;
+    if (cb >= tile_max) continue;
+    // stage the chunk's records (lane i <- instance cb + i); only this wave reads them back
+    const int cnt = (int)min((uint32_t)GS_SEG, tile_max - cb);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the previous chunk's broadcast reads are done
+    if (lane < cnt) {
+      const uint32_t id = list[start + cb + lane];
+      const GsRec* r = recs + id;
+      const float4 col = r->q2;  // (r, g, b, depth): depth is not used here, its slot carries the Gaussian's index
+      q0s[lane] = r->q0; q1s[lane] = r->q1; q2s[lane] = make_float4(col.x, col.y, col.z, __uint_as_float(id));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // cull: record `lane` against the four quadrant boxes; instances behind every pixel of a quadrant are dropped too
+    {
+      float4 r0 = make_float4(0.f, 0.f, -1.f, -1.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < cnt) { r0 = q0s[lane]; r1 = q1s[lane]; }
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        Quad q;
+        q.x0 = (float)(tx * GS_TILE + (qd & 1) * 8); q.x1 = q.x0 + 7.f;
+        q.y0 = (float)(ty * GS_TILE + (qd >> 1) * 8); q.y1 = q.y0 + 7.f;
+        const bool hit = lane < cnt && cb + (uint32_t)lane < wmaxq[qd] && quad_hit(r0, r1, q);
+        mq[qd] = __ballot(hit);
+      }
+    }
+    unsigned long long many = (mq[0] | mq[1]) | (mq[2] | mq[3]);
+    if (!many) continue;
+    // back-to-front walk over the union mask, unrolled by two with ping-pong record registers: the next record's LDS reads
+    // (wave-uniform addresses: broadcasts) are issued before the current record's math
+    auto xy = [&](int i) { const float4& r = q0s[i]; return make_float2(r.x, r.y); };   // the walk only needs the centre
+    int iA = 63 - __clzll((long long)many), iB = iA;
+    float2 A0 = xy(iA), B0 = A0;
+    float4 A1 = q1s[iA], A2 = q2s[iA], B1 = A1, B2 = A2;
+    for (;;) {
+      many &= ~(1ull << iA);
+      const bool moreB = many != 0;
+      if (moreB) iB = 63 - __clzll((long long)many);
+      B0 = xy(iB); B1 = q1s[iB]; B2 = q2s[iB];
+      replay_one(A0, A1, A2, iA);
+      if (!moreB) break;
+      many &= ~(1ull << iB);
+      const bool moreA = many != 0;
+      if (moreA) iA = 63 - __clzll((long long)many);
+      A0 = xy(iA); A1 = q1s[iA]; A2 = q2s[iA];
+      replay_one(B0, B1, B2, iB);
+      if (!moreA) break;
+    }
   }
 }
 
@@ -493,10 +509,11 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
                             uint32_t* n_contrib, const uint32_t* order, GsSched* sched, const uint32_t* seg_first, uint2* unit_tile,
-                            float4* bstate, uint32_t max_units) {
+                            float4* bstate, uint32_t max_units, int level) {
   const int NB = gs_num_cus();
   hipLaunchKernelGGL(k_composite_fwd, dim3(gs_grid_persistent(T, NB)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
-                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB, seg_first, unit_tile, bstate, max_units);
+                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB, seg_first + (size_t)level * (T + 1), unit_tile, bstate, max_units,
+                     (uint32_t)GS_SEG << level);
   return 0;
 }
 
@@ -506,8 +523,14 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint32_t* seg_first, const uint2* unit_tile, const float4* bstate, const uint32_t* meta,
-                            uint32_t max_units) {
-  hipLaunchKernelGGL(k_composite_bwd, dim3((max_units + BW_UNITS - 1) / BW_UNITS), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,
-                     n_contrib, dL_dpix, grads, out_color, seg_first, unit_tile, bstate, meta, max_units);
+                            uint32_t max_units, int T, int level) {
+  const dim3 grid((max_units + BW_UNITS - 1) / BW_UNITS);
+  const uint32_t* sf = seg_first + (size_t)level * (T + 1);
+  if (level == 0)
+    hipLaunchKernelGGL(k_composite_bwd<1>, grid, dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T, n_contrib,
+                       dL_dpix, grads, out_color, sf, unit_tile, bstate, meta + 4 + level, max_units, 1u);
+  else
+    hipLaunchKernelGGL(k_composite_bwd<0>, grid, dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T, n_contrib,
+                       dL_dpix, grads, out_color, sf, unit_tile, bstate, meta + 4 + level, max_units, 1u << level);
   return 0;
 }

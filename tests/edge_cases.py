@@ -3,7 +3,7 @@ import math
 
 import torch
 
-from tests.util import assert_no_worse_than_fp32_oracle, assert_raster_parity, run_custom_case
+from tests.util import assert_no_worse_than_fp32_oracle, assert_raster_parity, run_custom_case, run_blob_case
 
 
 def _base(n, seed):
@@ -124,6 +124,31 @@ def check_long_tile_lists(dev, n):
     # the gradients by ~1e-3 (seen for n = 12000: one such pair).  Ordering itself is checked exactly by
     # check_tile_lists_sorted.
     assert_raster_parity(dict(ref=out["ref"], dut=out["dut"]), fwd_tol=5e-4, grad_tol=3e-3)
+
+
+def check_multi_chunk_units(dev, n=6000, min_units=4):
+    """The backward's units are lengthened to 2, 4 or 8 chunks of 64 instances once a frame has more than ~12 k of them
+    (csrc/common.h, GS_MIN_UNITS; C4 runs at 8).  Lowering the knob makes small scenes take that path: the forward then
+    leaves boundary records only every chunks * 64 instances and a backward wave replays several chunks in a row — image and
+    every gradient must be what the one-chunk path gives (bit for bit in the forward; the backward's float atomics land in a
+    different order on the GPU)."""
+    from instantsplat_amd import _lib
+    L = _lib.lib()
+    cuda = torch.device(dev).type == "cuda"
+    res = {}
+    old = L.mi355gs_tune_min_units(0)
+    try:
+        for mu in (1 << 30, min_units):     # never lengthen / lengthen as far as GS_MAX_CHUNKS allows
+            L.mi355gs_tune_min_units(mu)
+            res[mu] = run_blob_case(dev, n, 96, 64, 1, scale_mean=0.12, seed=9)
+            assert_raster_parity(res[mu], grad_tol=2e-4)
+    finally:
+        L.mi355gs_tune_min_units(old)
+    a, b = res[1 << 30]["dut"], res[min_units]["dut"]
+    assert torch.equal(a["color"], b["color"]) and torch.equal(a["radii"], b["radii"])
+    for k in a["grads"]:
+        d = float((a["grads"][k] - b["grads"][k]).abs().max())
+        assert d <= (1e-5 if cuda else 1e-6) * max(1.0, float(a["grads"][k].abs().max())), (k, d)
 
 
 def check_tile_lists_sorted(dev, n):

@@ -33,6 +33,10 @@ def test_long_tile_lists(emu, n):
     edge_cases.check_long_tile_lists(emu, n)
 
 
+def test_multi_chunk_backward_units(emu):
+    edge_cases.check_multi_chunk_units(emu)
+
+
 @pytest.mark.parametrize("n,longer_than", [(600, 0), (3000, 2048), (12000, 8192)])
 def test_tile_lists_sorted(emu, n, longer_than):
     assert edge_cases.check_tile_lists_sorted(emu, n) > longer_than

@@ -34,6 +34,10 @@ def test_long_tile_lists(gpu, n):
     edge_cases.check_long_tile_lists(gpu, n)
 
 
+def test_multi_chunk_backward_units(gpu):
+    edge_cases.check_multi_chunk_units(gpu)
+
+
 @pytest.mark.parametrize("n,longer_than", [(600, 0), (3000, 2048), (12000, 8192), (40000, 8192)])
 def test_tile_lists_sorted(gpu, n, longer_than):
     assert edge_cases.check_tile_lists_sorted(gpu, n) > longer_than
