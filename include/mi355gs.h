@@ -10,7 +10,13 @@
  *     binding passes torch.cuda.current_stream().cuda_stream); calls return after enqueueing unless
  *     stated otherwise;
  *   - all floating point is fp32, all tensors contiguous and on the same device;
- *   - return value: 0 on success, a negative MI355GS_E* code otherwise (mi355gs_error_string()).
+ *   - return value: 0 on success, a negative MI355GS_E* code otherwise (mi355gs_error_string());
+ *   - state: the per-operator entry points keep nothing between calls.  Exceptions, all host-side and documented at their
+ *     declarations: the opt-in event timing (mi355gs_profile_*), the process-wide tuning knob mi355gs_tune_min_units, and
+ *     the trainer handle.  Threading: calls may be made from any host thread, one call at a time per stream; the
+ *     composite entry points (mi355gs_posed_*, mi355gs_trainer_*) pass per-call context to the operator entry points
+ *     they re-enter through a THREAD-LOCAL hook block (csrc/common.h, GsFusedStepHooks), set and cleared inside the call —
+ *     so concurrent calls from different threads do not see each other's context, and nothing of it survives the call.
  *
  * Each entry point names the reference interface it replaces. The reference's three native
  * operators are un-vendored git submodules (reference .gitmodules:1-12), so the citations are
@@ -26,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 3
+#define MI355GS_ABI_VERSION 4
 
 /* error codes */
 #define MI355GS_OK 0
@@ -47,7 +53,8 @@ const char* mi355gs_error_string(int code);
  *   geom    : per-Gaussian records written by preprocess, read by render and backward
  *   tiles   : per-tile counters / offsets; per-pixel final transmittance and contributor counts
  *   binning : per-instance sort keys and the depth-sorted per-tile Gaussian index lists; the backward's work units
- *             (segments of 256 instances of a tile's list) and the per-pixel state the forward leaves at their boundaries
+ *             (runs of 64, 128, 256 or 512 instances of a tile's list — csrc/common.h GS_SEG, gs_unit_level — chosen from
+ *             the capacity passed to the render / backward calls) and the per-pixel state the forward leaves at their boundaries
  * The forward is split in two so the caller can size `binning` exactly (one 4-byte D2H read of
  * *num_rendered between the calls, as the reference operator does internally) or skip the read
  * and pass a capacity bound (no host sync; overflow is reported through *num_rendered > capacity).
@@ -135,16 +142,28 @@ int mi355gs_profile_end(void);
  *   reduced in a fixed order so the result is run-to-run deterministic)
  *   ssim_mean / l1_mean: device float[1] each (either may be null): mean SSIM map, mean |img1-img2|
  *   dm_dmu1, dm_dsigma1_sq, dm_dsigma12 [B,C,H,W]: saved partials for backward (all null = inference)
+ *   padding_valid: 0 = fused_ssim(padding="same") (the reference's use); 1 = padding="valid": the map is computed the same
+ *   way but only the region where the window lies inside the image (5 px in from every edge) is averaged and passes
+ *   gradient (l1_mean / l1_grad_scale must then be null; H, W > 10)
  * ---------------------------------------------------------------------------------------------- */
 size_t mi355gs_ssim_scratch_bytes(int B, int C, int H, int W);
 int mi355gs_ssim_forward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,
                          float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
-                         void* scratch, float* ssim_mean, float* l1_mean);
+                         void* scratch, float* ssim_mean, float* l1_mean, int padding_valid);
 /* dL_dimg1 = ssim_grad_scale * d(ssim_mean)/dimg1 + l1_grad_scale * d(l1_mean)/dimg1
  * (scales are read from device scalars so no host sync is needed; null = 0). */
 int mi355gs_ssim_backward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,
                           const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
-                          const float* ssim_grad_scale, const float* l1_grad_scale, float* dL_dimg1);
+                          const float* ssim_grad_scale, const float* l1_grad_scale, float* dL_dimg1, int padding_valid);
+/* The reference's training loss (train.py:171-176) on the same two kernels: loss = (1 - lambda) * L1 + lambda * (1 - SSIM).
+ * forward: ssim_mean / l1_mean (optional) and loss: device float[1] each.  backward: dL_dimg1 = *grad_loss * dloss/dimg1
+ * (grad_loss: device float[1], what autograd hands the binding). */
+int mi355gs_l1_ssim_loss_forward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2, float* dm_dmu1,
+                                 float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float lambda_dssim, float* ssim_mean,
+                                 float* l1_mean, float* loss);
+int mi355gs_l1_ssim_loss_backward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,
+                                  const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* grad_loss,
+                                  float lambda_dssim, float* dL_dimg1);
 
 /* ------------------------------------------------------------------------------------------------
  * simple-knn
@@ -190,6 +209,35 @@ int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* ro
                           const float* pose, const float* g_means, const float* g_rot, const float* g_scales,
                           const float* g_opac, float* d_xyz, float* d_rot, float* d_scaling, float* d_opacity_logit,
                           float* d_pose, float* scratch);
+
+/* ------------------------------------------------------------------------------------------------
+ * InstantSplat's render() as the operator sees it: Gaussians in the WORLD frame with RAW parameters plus the learnable
+ * camera pose — the projection kernels apply the camera-frame transform and the activations themselves, and their backward
+ * goes all the way to the raw-parameter gradients and dL/dpose[7]: no camera-frame intermediates in HBM, three launches fewer
+ * per iteration than mi355gs_pose_forward + mi355gs_raster_* + mi355gs_pose_backward, ONE autograd node in the binding.
+ * replaces: everything reference gaussian_renderer/__init__.py:81-135 does between the GaussianModel and the image for the
+ *   default pipeline (SH colours, scale/rotation covariance): get_camera_from_tensor, the [4,4]@[4,P] transform,
+ *   quadmultiply, sigmoid / exp, cat(f_dc, f_rest), GaussianRasterizer.forward — and their autograd.
+ *   xyz[P,3], f_dc[P,1,3], f_rest[P,15,3] (may be null while D == 0: only the DC coefficient is read), opacity_logit[P,1],
+ *   log_scales[P,3], rotation[P,4] raw (w,x,y,z), pose[7] = (qw,qx,qy,qz,tx,ty,tz), all on the device.
+ *   view_identity[16] / origin[3]: device constants (identity matrix, zeros) — InstantSplat hands the operator an
+ *   identity view and a camera at the origin (reference :55-59); kept as arguments because the library owns no memory.
+ *   Stage 2 of the forward is mi355gs_raster_forward_render, unchanged.
+ *   backward: pose_scratch = device float[16 * ((P + 255) / 256) + 32]; d_f_rest may be null while D == 0 (the reference's
+ *   gradient for it is all zero then); d_* receive dL/d(raw parameter), d_pose[7] dL/dpose.
+ * ---------------------------------------------------------------------------------------------- */
+int mi355gs_posed_forward_preprocess(void* stream, int P, int D, int W, int H, const float* xyz, const float* f_dc,
+                                     const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,
+                                     const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
+                                     const float* origin, float tanfovx, float tanfovy, int32_t* radii, void* geom, void* tiles,
+                                     int32_t* num_rendered, int debug);
+int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float* bg, const float* xyz, const float* f_dc,
+                           const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,
+                           const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
+                           const float* origin, float tanfovx, float tanfovy, const void* geom, void* tiles, const void* binning,
+                           int64_t capacity, const int32_t* radii, const float* out_color, const float* dL_dpix,
+                           void* grad_scratch, float* pose_scratch, float* d_xyz, float* d_means2D, float* d_f_dc, float* d_f_rest,
+                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int debug);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole train iteration in one call

@@ -38,14 +38,20 @@ _SIGNATURES = {
     "mi355gs_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "mi355gs_profile_end": (c_int, []),
     "mi355gs_ssim_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "mi355gs_ssim_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mi355gs_ssim_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi355gs_ssim_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
+    "mi355gs_ssim_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
+    "mi355gs_l1_ssim_loss_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "mi355gs_l1_ssim_loss_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P]),
     "mi355gs_knn_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_knn_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "mi355gs_adam_step": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int]),
     "mi355gs_adam_multi_step": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P]),
     "mi355gs_pose_forward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_pose_backward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi355gs_posed_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
+                                                 c_float, c_float, _P, _P, _P, _P, c_int]),
+    "mi355gs_posed_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_float,
+                                       c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_trainer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
     "mi355gs_trainer_create": (c_void_p, [c_int, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_trainer_step": (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
@@ -109,6 +115,26 @@ def require_device(*tensors: torch.Tensor | None):
         elif t.device != dev:
             raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
     return dev
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """Context for a library call: the HIP launches inside libmi355gs.so go to the process's CURRENT device, so when the
+    tensors live on another one (cuda:1 while cuda:0 is current) the call is wrapped in torch.cuda.device(device).  The
+    common case — tensors on the current device — costs one comparison."""
+    if device is not None and device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
+        return torch.cuda.device(device)
+    return _NO_GUARD
 
 
 def stream_ptr(device) -> c_void_p:

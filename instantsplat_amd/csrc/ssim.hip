@@ -42,7 +42,9 @@ __device__ __forceinline__ float ssim_rcp(float x) {
 
 __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                    float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                   float* __restrict__ dm_dsigma12, float* __restrict__ partial /*[nblocks,2]*/) {
+                                                   float* __restrict__ dm_dsigma12, float* __restrict__ partial /*[nblocks,2]*/,
+                                                   int crop /* 0: "same" padding; HALO: "valid" — the SSIM map only counts (and only
+                                                               passes gradient) where the 11x11 window lies inside the image */) {
   __shared__ float s_x[TH][SXP];
   __shared__ float s_y[TH][SXP];
   __shared__ gs_v2f s_h[5][TH][TS];  // row-pass results, columns (c, c + 16) as one pair
@@ -114,9 +116,12 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __r
     for (int half = 0; half < 2; ++half) {
       const int gx = ox + lx + half * TS;
       if (gx < W && gy < H) {
-        val += m[half];
+        const bool counted = gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
+        val += counted ? m[half] : 0.f;
         const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
-        if (dm_dmu1) { dm_dmu1[o] = d1[half]; dm_dsigma1_sq[o] = d2[half]; dm_dsigma12[o] = d3[half]; }
+        if (dm_dmu1) {
+          dm_dmu1[o] = counted ? d1[half] : 0.f; dm_dsigma1_sq[o] = counted ? d2[half] : 0.f; dm_dsigma12[o] = counted ? d3[half] : 0.f;
+        }
         l1 += fabsf(s_x[ly + HALO][lx + half * TS + HALO] - s_y[ly + HALO][lx + half * TS + HALO]);
       }
     }
@@ -267,16 +272,20 @@ size_t mi355gs_ssim_scratch_bytes(int B, int C, int H, int W) {
 }
 
 int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, float* dm_dmu1,
-                         float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float* ssim_mean, float* l1_mean) {
+                         float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float* ssim_mean, float* l1_mean, int padding_valid) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch) return MI355GS_EINVAL;
+  const int crop = padding_valid ? HALO : 0;
+  if (padding_valid && (l1_mean || H <= 2 * HALO || W <= 2 * HALO)) return MI355GS_EINVAL;
   if ((dm_dmu1 == nullptr) != (dm_dsigma1_sq == nullptr) || (dm_dmu1 == nullptr) != (dm_dsigma12 == nullptr)) return MI355GS_EINVAL;
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
   const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
-  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch);
+  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch, crop);
   GS_CHECK_LAUNCH("ssim_fwd");
-  const double inv_n = 1.0 / ((double)B * C * H * W);
+  // one finishing launch normalises both sums by the same count: with "valid" padding that is the cropped map's, so the L1
+  // mean (a "same"-padding quantity of the training loss) is only offered with padding_valid == 0
+  const double inv_n = 1.0 / ((double)B * C * (H - 2 * crop) * (W - 2 * crop));
   hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
                      l1_mean, (float*)nullptr, 0.f);
   GS_CHECK_LAUNCH("ssim_finish");
@@ -285,17 +294,57 @@ int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float*
 
 int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
                           const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* ssim_grad_scale,
-                          const float* l1_grad_scale, float* dL_dimg1) {
+                          const float* l1_grad_scale, float* dL_dimg1, int padding_valid) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dL_dimg1) return MI355GS_EINVAL;
   if (ssim_grad_scale && (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)) return MI355GS_EINVAL;
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
   const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
-  const float inv_n = (float)(1.0 / ((double)B * C * H * W));
+  const int crop = padding_valid ? HALO : 0;
+  if (padding_valid && (l1_grad_scale || H <= 2 * HALO || W <= 2 * HALO)) return MI355GS_EINVAL;
+  // the forward zeroed the saved partials outside the counted region, so the same kernel serves both paddings
+  const float inv_n = (float)(1.0 / ((double)B * C * (H - 2 * crop) * (W - 2 * crop)));
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
                      ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1,
                      (const float*)nullptr, 0, 0.0, 0.f, (float*)nullptr);
+  GS_CHECK_LAUNCH("ssim_bwd");
+  return MI355GS_OK;
+}
+
+// The training loss of reference train.py:171-176 in the same two kernels: loss = (1-l) * L1 + l * (1 - SSIM) leaves the finishing
+// kernel as a third scalar, and the backward takes dL/dloss from a device scalar with the two weights applied on the way in —
+// no elementwise torch kernels around the operator in the binding.
+int mi355gs_l1_ssim_loss_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, float* dm_dmu1,
+                                 float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float lambda_dssim, float* ssim_mean,
+                                 float* l1_mean, float* loss) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !loss) return MI355GS_EINVAL;
+  if (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12) return MI355GS_EINVAL;
+  if ((size_t)B * C > 65535) return MI355GS_EINVAL;
+  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
+  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch, 0);
+  GS_CHECK_LAUNCH("ssim_fwd");
+  const double inv_n = 1.0 / ((double)B * C * H * W);
+  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
+                     l1_mean, loss, lambda_dssim);
+  GS_CHECK_LAUNCH("ssim_finish");
+  return MI355GS_OK;
+}
+
+int mi355gs_l1_ssim_loss_backward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
+                                  const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* grad_loss, float lambda_dssim,
+                                  float* dL_dimg1) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dL_dimg1 || !grad_loss) return MI355GS_EINVAL;
+  if (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12) return MI355GS_EINVAL;
+  if ((size_t)B * C > 65535) return MI355GS_EINVAL;
+  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
+  const float inv_n = (float)(1.0 / ((double)B * C * H * W));
+  hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, grad_loss,
+                     grad_loss, -lambda_dssim, 1.0f - lambda_dssim, dL_dimg1, (const float*)nullptr, 0, 0.0, 0.f, (float*)nullptr);
   GS_CHECK_LAUNCH("ssim_bwd");
   return MI355GS_OK;
 }
@@ -307,7 +356,7 @@ int gs_loss_forward(hipStream_t stream, int C, int H, int W, const float* img1, 
                     void* scratch) {
   const int debug = 0;
   const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, C);
-  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm1, dm2, dm3, (float*)scratch);
+  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm1, dm2, dm3, (float*)scratch, 0);
   GS_CHECK_LAUNCH("ssim_fwd");
   return MI355GS_OK;
 }

@@ -93,6 +93,49 @@ __global__ void k_trainer_consts(float* consts) {
 
 extern "C" {
 
+// ---- render() with the pose inside the operator (include/mi355gs.h): the same posed projection kernels the one-call step
+// uses, reached through the same thread-local hook, as two stateless entry points for the autograd binding.
+int mi355gs_posed_forward_preprocess(void* stream, int P, int D, int W, int H, const float* xyz, const float* f_dc,
+                                     const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,
+                                     const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
+                                     const float* origin, float tanfovx, float tanfovy, int32_t* radii, void* geom, void* tiles,
+                                     int32_t* num_rendered, int debug) {
+  if (!pose || D < 0 || D > 3 || (D > 0 && !f_rest)) return MI355GS_EINVAL;
+  struct Scope { ~Scope() { g_fused = GsFusedStepHooks(); } } scope;
+  g_fused.posed.pose = pose;
+  return mi355gs_raster_forward_preprocess(stream, P, D, D == 0 ? 1 : 16, W, H, xyz, f_dc, D == 0 ? nullptr : f_rest, nullptr,
+                                           opacity_logit, log_scales, scale_modifier, rotation, nullptr, view_identity, projmatrix,
+                                           origin, tanfovx, tanfovy, 0, radii, geom, tiles, num_rendered, debug);
+}
+
+int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const float* bg, const float* xyz, const float* f_dc,
+                           const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,
+                           const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
+                           const float* origin, float tanfovx, float tanfovy, const void* geom, void* tiles, const void* binning,
+                           int64_t capacity, const int32_t* radii, const float* out_color, const float* dL_dpix,
+                           void* grad_scratch, float* pose_scratch, float* d_xyz, float* d_means2D, float* d_f_dc, float* d_f_rest,
+                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int debug) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!pose || !pose_scratch || !d_pose || D < 0 || D > 3 || (D > 0 && (!f_rest || !d_f_rest))) return MI355GS_EINVAL;
+  if (P <= 0) return hipMemsetAsync(d_pose, 0, 7 * sizeof(float), stream) == hipSuccess ? MI355GS_OK : MI355GS_ELAUNCH;
+  const int rows = (P + 255) / 256;
+  int rc;
+  {
+    struct Scope { ~Scope() { g_fused = GsFusedStepHooks(); } } scope;
+    g_fused.posed.pose = pose;
+    g_fused.posed.acc = pose_scratch + (size_t)16 * rows;   // unused with `partial` set; kept valid
+    g_fused.posed.partial = pose_scratch;                   // one row of 16 pose sums per projection workgroup
+    rc = mi355gs_raster_backward(stream, P, D, D == 0 ? 1 : 16, W, H, bg, xyz, f_dc, D == 0 ? nullptr : f_rest, nullptr, opacity_logit,
+                                 log_scales, scale_modifier, rotation, nullptr, view_identity, projmatrix, origin, tanfovx, tanfovy,
+                                 geom, tiles, binning, capacity, radii, out_color, dL_dpix, grad_scratch, d_xyz, d_means2D, d_f_dc,
+                                 D == 0 ? nullptr : d_f_rest, nullptr, d_opacity_logit, d_log_scales, d_rotation, nullptr, debug);
+  }
+  if (rc) return rc;
+  gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, nullptr);
+  GS_CHECK_LAUNCH("pose_finish");
+  return MI355GS_OK;
+}
+
 size_t mi355gs_trainer_workspace_bytes(int P, int W, int H, int V, int64_t capacity) {
   if (P < 0 || W <= 0 || H <= 0 || V <= 0 || capacity < 0) return 0;
   Trainer t;

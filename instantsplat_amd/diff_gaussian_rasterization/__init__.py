@@ -114,6 +114,31 @@ class binning_hint:
         BinningPolicy.current_key, BinningPolicy.current_tag = self.prev
 
 
+def size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug):
+    """Stage 2 of the forward for both bindings (operator-level and posed): size the instance buffers according to the
+    BinningPolicy — the reference operator's own blocking 4-byte read-back, or a verified bound with no host sync — allocate
+    them and enqueue binning + composite.  Returns (capacity handed to the library, binning scratch)."""
+    key = BinningPolicy.current_key
+    if BinningPolicy.mode == "bounded" and key is not None and key in BinningPolicy.known:
+        R = int(BinningPolicy.slack * BinningPolicy.known[key]) + BinningPolicy.pad  # capacity, no host sync
+        if dev.type == "cuda":
+            pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(num_rendered, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        else:  # emulated kernels on CPU tensors (tests): the count is already there
+            pinned, ev = num_rendered, None
+        BinningPolicy.pending.append((ev, pinned, R, key, BinningPolicy.current_tag))
+    else:
+        R = int(num_rendered.item())  # the reference operator's own blocking read-back
+        if key is not None:
+            BinningPolicy.known[key] = R
+    binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R, W, H), dev)
+    _lib.check(L.mi355gs_raster_forward_render(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
+                                               _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render")
+    return R, binning
+
+
 def _empty_bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
 
@@ -156,25 +181,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos),
                 float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _lib.ptr(radii), _lib.ptr(geom),
                 _lib.ptr(tiles), _lib.ptr(num_rendered), debug), "raster_forward_preprocess")
-            key = BinningPolicy.current_key
-            if BinningPolicy.mode == "bounded" and key is not None and key in BinningPolicy.known:
-                R = int(BinningPolicy.slack * BinningPolicy.known[key]) + BinningPolicy.pad  # capacity, no host sync
-                if dev.type == "cuda":
-                    pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                    pinned.copy_(num_rendered, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(dev))
-                else:  # emulated kernels on CPU tensors (tests): the count is already there
-                    pinned, ev = num_rendered, None
-                BinningPolicy.pending.append((ev, pinned, R, key, BinningPolicy.current_tag))
-            else:
-                R = int(num_rendered.item())  # the reference operator's own blocking read-back
-                if key is not None:
-                    BinningPolicy.known[key] = R
-            binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R, W, H), dev)
-            _lib.check(L.mi355gs_raster_forward_render(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
-                                                       _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render")
-            return R, binning
+            return size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug)
 
         if s.debug:
             try:

@@ -12,7 +12,7 @@ import torch
 from .. import _lib
 
 
-def _run_forward(img1, img2, train):
+def _run_forward(img1, img2, train, valid=False):
     L = _lib.lib()
     a, b = _lib.f32c(img1), _lib.f32c(img2)
     if a.dim() != 4 or a.shape != b.shape:
@@ -22,29 +22,35 @@ def _run_forward(img1, img2, train):
     new = lambda: torch.empty_like(a)
     dm1, dm2, dm3 = (new(), new(), new()) if train else (None, None, None)
     scratch = torch.empty(int(L.mi355gs_ssim_scratch_bytes(B, C, H, W)), dtype=torch.uint8, device=dev)
+    if valid and (H <= 10 or W <= 10):
+        raise RuntimeError('fused_ssim(padding="valid") needs images larger than the 11x11 window')
     out = torch.empty(2, dtype=torch.float32, device=dev)  # [ssim_mean, l1_mean]
-    _lib.check(L.mi355gs_ssim_forward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1), _lib.ptr(dm2),
-                                      _lib.ptr(dm3), _lib.ptr(scratch), _lib.ptr(out[0:1]), _lib.ptr(out[1:2])), "ssim_forward")
+    with _lib.on_device(dev):
+        _lib.check(L.mi355gs_ssim_forward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1), _lib.ptr(dm2),
+                                          _lib.ptr(dm3), _lib.ptr(scratch), _lib.ptr(out[0:1]), None if valid else _lib.ptr(out[1:2]),
+                                          1 if valid else 0), "ssim_forward")
     return a, b, dm1, dm2, dm3, out
 
 
-def _run_backward(a, b, dm1, dm2, dm3, ssim_scale, l1_scale):
+def _run_backward(a, b, dm1, dm2, dm3, ssim_scale, l1_scale, valid=False):
     L = _lib.lib()
     dev = a.device
     B, C, H, W = a.shape
     grad = torch.empty_like(a)
-    _lib.check(L.mi355gs_ssim_backward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1), _lib.ptr(dm2),
-                                       _lib.ptr(dm3), _lib.ptr(ssim_scale), _lib.ptr(l1_scale), _lib.ptr(grad)), "ssim_backward")
+    with _lib.on_device(dev):
+        _lib.check(L.mi355gs_ssim_backward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1), _lib.ptr(dm2),
+                                           _lib.ptr(dm3), _lib.ptr(ssim_scale), _lib.ptr(l1_scale), _lib.ptr(grad), 1 if valid else 0),
+                   "ssim_backward")
     return grad
 
 
 class _FusedSSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img1, img2, train):
-        a, b, dm1, dm2, dm3, out = _run_forward(img1, img2, train)
+    def forward(ctx, img1, img2, train, valid=False):
+        a, b, dm1, dm2, dm3, out = _run_forward(img1, img2, train, valid)
         if train:
             ctx.save_for_backward(a, b, dm1, dm2, dm3)
-        ctx.train = train
+        ctx.train, ctx.valid = train, valid
         return out[0].clone()
 
     @staticmethod
@@ -53,30 +59,58 @@ class _FusedSSIM(torch.autograd.Function):
             raise RuntimeError("fused_ssim was called with train=False; no gradient is available")
         a, b, dm1, dm2, dm3 = ctx.saved_tensors
         scale = _lib.f32c(g.reshape(1))
-        return _run_backward(a, b, dm1, dm2, dm3, scale, None), None, None
+        return _run_backward(a, b, dm1, dm2, dm3, scale, None, ctx.valid), None, None, None
 
 
 def fused_ssim(img1, img2, padding="same", train=True):
-    if padding != "same":
-        raise NotImplementedError('only padding="same" (the reference\'s use, train.py:173) is implemented')
-    return _FusedSSIM.apply(img1, img2, train)
+    """padding="same" (the reference's use, train.py:173): zero padding, mean over the whole map.  padding="valid": the
+    mean (and the gradient) only covers the region where the 11x11 window lies inside the image."""
+    if padding not in ("same", "valid"):
+        raise ValueError(f'padding must be "same" or "valid", got {padding!r}')
+    return _FusedSSIM.apply(img1, img2, train, padding == "valid")
 
 
 class _FusedL1SSIM(torch.autograd.Function):
+    """(1-lambda)*L1 + lambda*(1-SSIM) with the weighted sum formed inside the library (mi355gs_l1_ssim_loss_*): one call each
+    way and no elementwise torch kernels around it."""
+
     @staticmethod
     def forward(ctx, img1, img2, lambda_dssim):
-        a, b, dm1, dm2, dm3, out = _run_forward(img1, img2, True)
+        L = _lib.lib()
+        a, b = _lib.f32c(img1), _lib.f32c(img2)
+        if a.dim() != 4 or a.shape != b.shape:
+            raise RuntimeError("fused_ssim expects two [B,C,H,W] tensors of equal shape")
+        dev = _lib.require_device(a, b)
+        B, C, H, W = a.shape
+        dm1, dm2, dm3 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        scratch = torch.empty(int(L.mi355gs_ssim_scratch_bytes(B, C, H, W)), dtype=torch.uint8, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)   # [ssim_mean, l1_mean]
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        lam = float(lambda_dssim)
+        p0 = out.data_ptr()
+        with _lib.on_device(dev):
+            _lib.check(L.mi355gs_l1_ssim_loss_forward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1),
+                                                      _lib.ptr(dm2), _lib.ptr(dm3), _lib.ptr(scratch), lam, p0, p0 + 4, _lib.ptr(loss)),
+                       "l1_ssim_loss_forward")
         ctx.save_for_backward(a, b, dm1, dm2, dm3)
-        ctx.lam = float(lambda_dssim)
-        loss = (1.0 - ctx.lam) * out[1] + ctx.lam * (1.0 - out[0])
+        ctx.lam = lam
         ctx.mark_non_differentiable(out)
         return loss, out
 
     @staticmethod
     def backward(ctx, g, _):
         a, b, dm1, dm2, dm3 = ctx.saved_tensors
-        g = _lib.f32c(g.reshape(1))
-        return _run_backward(a, b, dm1, dm2, dm3, (-ctx.lam) * g, (1.0 - ctx.lam) * g), None, None
+        L = _lib.lib()
+        dev = a.device
+        B, C, H, W = a.shape
+        g = _lib.f32c(g)
+        _lib.require_device(g)
+        grad = torch.empty_like(a)
+        with _lib.on_device(dev):
+            _lib.check(L.mi355gs_l1_ssim_loss_backward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1),
+                                                       _lib.ptr(dm2), _lib.ptr(dm3), _lib.ptr(g), ctx.lam, _lib.ptr(grad)),
+                       "l1_ssim_loss_backward")
+        return grad, None, None
 
 
 def fused_l1_ssim_loss(img1, img2, lambda_dssim=0.2):

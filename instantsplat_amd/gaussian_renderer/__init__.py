@@ -12,7 +12,7 @@ import math
 import torch
 
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-from ..fused import pose_activations, sh_features
+from ..fused import pose_activations, render_posed, sh_features
 from ..pose_utils import get_camera_from_tensor, quadmultiply
 from ..sh_utils import eval_sh
 
@@ -26,8 +26,10 @@ def _identity_view(dev):
     return _IDENTITY[dev]
 
 
-# False = always take the op-by-op PyTorch glue below (kept for A/B tests against the fused path)
-FUSED_GLUE = True
+# "posed" (default): one autograd node for the whole render body (fused.render_posed); True: the round-1 fused glue (pose /
+# activation kernel + SH view + operator, three nodes); False: the op-by-op PyTorch glue below.  The latter two are kept
+# for A/B tests: all three must give the same image and gradients.
+FUSED_GLUE = "posed"
 
 
 def _operator_inputs(viewpoint_camera, pc, pipe, camera_pose, scaling_modifier, override_color, dev):
@@ -54,12 +56,10 @@ def _operator_inputs(viewpoint_camera, pc, pipe, camera_pose, scaling_modifier, 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, camera_pose=None):
     dev = pc.get_xyz.device
-    # zero tensor whose gradient receives the screen-space mean gradients (the reference's `viewspace_points`)
-    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # zero tensor whose .grad receives the screen-space mean gradients (the reference's `viewspace_points`, :39-48).  The
+    # reference makes it a non-leaf (`zeros + 0`) and asks autograd to retain its gradient; a leaf gets the same .grad
+    # without the extra elementwise kernel and the two autograd nodes.
+    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True)
 
     view_identity, origin = _identity_view(dev)      # reference :55-59: identity view matrix, camera at the origin
     projmatrix = viewpoint_camera.projection_matrix  # identity @ projection
@@ -71,7 +71,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         scale_modifier=scaling_modifier, viewmatrix=view_identity, projmatrix=projmatrix, sh_degree=pc.active_sh_degree,
         campos=origin, prefiltered=False, debug=pipe.debug))
 
-    if FUSED_GLUE and override_color is None and not (pipe.compute_cov3D_python or pipe.convert_SHs_python):
+    default_pipeline = override_color is None and not (pipe.compute_cov3D_python or pipe.convert_SHs_python)
+    if FUSED_GLUE == "posed" and default_pipeline and pc.max_sh_degree == 3:
+        # the whole differentiable body as one autograd node: the projection kernels take the raw parameters + the pose
+        image, radii = render_posed(pc, camera_pose, screenspace_points, rasterizer.raster_settings)
+    elif FUSED_GLUE and default_pipeline:
         # one HIP launch each way for the pose transform + activations (and the pose-gradient reduction)
         means3D, rot_cam, scales_act, opacity = pose_activations(pc._xyz, pc._rotation, pc._scaling, pc._opacity, camera_pose)
         shs_dc, shs_rest = sh_features(pc)

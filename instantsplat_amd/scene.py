@@ -39,6 +39,46 @@ class GaussianModel:
         self.optimizer = None
         self.spatial_lr_scale = 0
         self.P = None
+        # densification statistics of the reference's model (scene/gaussian_model.py:55-57).  Densification is disabled in
+        # InstantSplat (train.py:195-206), so they only exist to keep capture() / restore() tuples interchangeable.
+        self.max_radii2D = self.xyz_gradient_accum = self.denom = e
+
+    # ---- checkpoint tuple (reference :65-99): same 13 entries in the same order, so a chkpnt<iteration>.pth written by
+    # either side loads on the other
+    def capture(self):
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
+                self.spatial_lr_scale, self.P)
+
+    def restore(self, model_args, training_args, confidence_lr=None):
+        """Reference :82-99.  Like the reference it rebuilds the optimizer with `training_setup` — which on a run started
+        with --pp_optimizer silently drops the per-point multiplier (the state dict restores moments and steps, not the
+        optimizer class); pass `confidence_lr` to rebuild the per-point optimizer instead (not in the reference)."""
+        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity,
+         self.max_radii2D, xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale, self.P) = model_args
+        if confidence_lr is not None:
+            self.training_setup_pp(training_args, confidence_lr)
+        else:
+            self.training_setup(training_args)
+        self.xyz_gradient_accum, self.denom = xyz_gradient_accum, denom
+        opt_dict = dict(opt_dict, param_groups=[dict(g) for g in opt_dict["param_groups"]])
+        if confidence_lr is None:
+            for g in opt_dict["param_groups"]:       # plain Adam has no multiplier: do not let the saved groups re-introduce it
+                g["per_point_lr"] = None
+        self.optimizer.load_state_dict(opt_dict)
+
+    # ---- PLY (reference :247-326; io_formats writes / reads the same binary layout without `plyfile`)
+    def save_ply(self, path):
+        import os
+        from .io_formats import save_gaussian_ply
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        save_gaussian_ply(path, self)
+
+    def load_ply(self, path, device="cuda"):
+        from .io_formats import load_gaussian_ply
+        for k, v in load_gaussian_ply(path, self.max_sh_degree, device).items():
+            setattr(self, k, nn.Parameter(v.requires_grad_(True)))
+        self.active_sh_degree = self.max_sh_degree
 
     # ---- activations (reference :101-124)
     @property
@@ -95,6 +135,7 @@ class GaussianModel:
         self._scaling = nn.Parameter(scales.requires_grad_(True))
         self._rotation = nn.Parameter(rots.requires_grad_(True))
         self._opacity = nn.Parameter(opacities.requires_grad_(True))
+        self.max_radii2D = torch.zeros((n,), device=device)
 
     # ---- optimiser (reference :173-243)
     def _groups(self, o, per_point_lr):
@@ -110,6 +151,9 @@ class GaussianModel:
                 {"params": [self.P], "lr": o.rotation_lr * 0.1, "name": "pose"}]
 
     def _schedulers(self, o):
+        n = self._xyz.shape[0]   # reference :175-176 / :205-206 (statistics of the disabled densification, kept for capture())
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self._xyz.device)
+        self.denom = torch.zeros((n, 1), device=self._xyz.device)
         self.xyz_scheduler_args = get_expon_lr_func(o.position_lr_init * self.spatial_lr_scale,
                                                     o.position_lr_final * self.spatial_lr_scale,
                                                     lr_delay_mult=o.position_lr_delay_mult, max_steps=o.position_lr_max_steps)

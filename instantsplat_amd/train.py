@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import math
 import random
+import struct
 import time
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -148,7 +149,10 @@ def _fused_synced_iteration(st: TrainState):
     saved = (st.iteration, list(st.viewpoint_stack), st.rng.getstate(), st.gaussians.active_sh_degree,
              [st.gaussians.optimizer.state[p]["step"] for p in tr.params], [g["lr"] for g in st.gaussians.optimizer.param_groups])
     cam = tr.step(st._loss_slot, defer_optimizer=True, verify_async=False)
-    loss, r = torch.cat([st._loss_slot, tr.num_rendered.to(torch.float32)]).tolist()   # the iteration's one host read-back
+    # the iteration's one host read-back: loss bits and instance count travel together as int32 (a float32 detour would
+    # round counts above 2^24, reachable at 1 M Gaussians / 1080p, and could hide an overflow of a few instances)
+    bits, r = torch.cat([st._loss_slot.view(torch.int32), tr.num_rendered]).tolist()
+    loss = struct.unpack("<f", struct.pack("<i", bits))[0]
     BinningPolicy.known[("train", cam.uid)] = int(r)
     if r > tr.capacity:   # dropped instances: discard, redo exactly, and grow the buffers for the next iterations
         st.iteration, st.viewpoint_stack, st.gaussians.active_sh_degree = saved[0], saved[1], saved[3]
@@ -199,7 +203,20 @@ class FusedTrainer:
         grp = g.optimizer.param_groups
         if any(x["weight_decay"] != 0 or x["betas"] != grp[0]["betas"] or x["eps"] != grp[0]["eps"] for x in grp):
             return False
-        return [x["name"] for x in grp] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "pose"]
+        if [x["name"] for x in grp] != ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "pose"]:
+            return False
+        # The library gets raw pointers: everything it will index with the trainer's fixed (W, H, device) must really have
+        # that shape, dtype, layout and device, or a mismatched view becomes an out-of-bounds read instead of an error.
+        dev = g._xyz.device
+        W, H = int(st.cameras[0].image_width), int(st.cameras[0].image_height)
+        ok = lambda t, shape: (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev
+                               and tuple(t.shape) == shape)
+        for cam in st.cameras:
+            if int(cam.image_width) != W or int(cam.image_height) != H or not ok(cam.projection_matrix, (4, 4)):
+                return False
+            if cam.uid >= len(st.gt_images) or not ok(st.gt_images[cam.uid], (3, H, W)):
+                return False
+        return ok(st.background, (3,))
 
     def __init__(self, st: TrainState, capacity: int):
         self.st, self.capacity = st, int(capacity)
@@ -425,37 +442,77 @@ def evaluate_psnr(st: TrainState) -> float:
     return float(torch.stack(vals).mean())
 
 
+def _save_outputs(st: TrainState, iteration: int, model_path: str, colmap_ids):
+    """What the reference writes at a saving iteration (train.py:220-223, scene/__init__.py:97-99): the Gaussians as
+    point_cloud/iteration_<it>/point_cloud.ply and the optimised poses as pose/ours_<it>/pose_optimized.npy."""
+    import os
+    from .io_formats import save_pose
+    st.gaussians.save_ply(os.path.join(model_path, "point_cloud", f"iteration_{iteration}", "point_cloud.ply"))
+    os.makedirs(os.path.join(model_path, "pose", f"ours_{iteration}"), exist_ok=True)
+    save_pose(os.path.join(model_path, "pose", f"ours_{iteration}", "pose_optimized.npy"), st.gaussians.P, colmap_ids)
+
+
 def training(scene: PointmapScene, device, iterations: int = 1000, log_every: int = 0, run_ahead: bool = True,
-             fused_loss: bool = True) -> dict:
+             fused_loss: bool = True, model_path: str | None = None, saving_iterations=(), checkpoint_iterations=(),
+             start_checkpoint: str | None = None) -> dict:
     """Train one scene. run_ahead=True uses the sync-free driver (identical results, see RunAhead);
-    run_ahead=False reproduces the reference's per-iteration host read-backs."""
+    run_ahead=False reproduces the reference's per-iteration host read-backs.
+
+    model_path / saving_iterations / checkpoint_iterations / start_checkpoint: the reference's outputs and resume
+    (train.py:103-110,220-227): pose/ours_<it>/pose_org.npy before training, point_cloud.ply + pose_optimized.npy at every saving
+    iteration, chkpnt<it>.pth = torch.save((gaussians.capture(), it)) at every checkpoint iteration, and a run started from
+    such a file continues at its iteration with its optimizer state."""
+    import os
+    from .io_formats import save_pose
     opt = OptimizationParams(iterations=iterations, pp_optimizer=True, optim_pose=True)
     st = setup_training(scene, device, opt=opt)
+    first_iter = 0
+    if start_checkpoint:
+        model_params, first_iter = torch.load(start_checkpoint, map_location=device, weights_only=False)
+        # (the reference's restore() falls back to plain Adam here; a run started with --pp_optimizer keeps its multiplier)
+        st.gaussians.restore(model_params, opt, confidence_lr=getattr(st.gaussians, "per_point_lr", None))
+        st.iteration = int(first_iter)
+    colmap_ids = [int(c.colmap_id) for c in st.cameras]
+    saving, checkpoints = set(int(i) for i in saving_iterations), set(int(i) for i in checkpoint_iterations)
+    if (saving or checkpoints) and not model_path:
+        raise ValueError("saving_iterations / checkpoint_iterations need a model_path")
+    for it in sorted(saving):   # reference train.py:107-110: the initial poses, once per saving iteration
+        os.makedirs(os.path.join(model_path, "pose", f"ours_{it}"), exist_ok=True)
+        save_pose(os.path.join(model_path, "pose", f"ours_{it}", "pose_org.npy"), st.gaussians.P, colmap_ids)
     psnr0 = evaluate_psnr(st)
     is_cuda = torch.device(device).type == "cuda"
     if is_cuda:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     first = last = None
-    if run_ahead:
-        ra = RunAhead(st, fused_loss=fused_loss)
-        for i in range(iterations):
+    ra = RunAhead(st, fused_loss=fused_loss) if run_ahead else None
+    for i in range(int(first_iter), iterations):
+        if ra is not None:
             ema = ra.step()
             if first is None and ema is not None:
                 first = st.last_loss
             if log_every and ema is not None and (i + 1) % log_every == 0:
                 print(f"[iter {i + 1}] ema loss {ema:.6f}")
-        ra.flush()
-        last = st.last_loss
-        BinningPolicy.reset("exact")
-    else:
-        for i in range(iterations):
+        else:
             last = train_iteration(st, fused_loss=fused_loss)
             first = last if first is None else first
             if log_every and (i + 1) % log_every == 0:
                 print(f"[iter {i + 1}] loss {last:.6f}")
+        it = i + 1
+        if it in saving or it in checkpoints:
+            if ra is not None:
+                ra.flush()   # the window up to here is verified (and replayed if a frame overflowed) before anything is written
+            if it in saving:
+                _save_outputs(st, it, model_path, colmap_ids)
+            if it in checkpoints:
+                torch.save((st.gaussians.capture(), it), os.path.join(model_path, f"chkpnt{it}.pth"))
+    if ra is not None:
+        ra.flush()
+        last = st.last_loss
+        BinningPolicy.reset("exact")
     if is_cuda:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dict(seconds=dt, iters_per_sec=iterations / dt, first_loss=first, last_loss=last, psnr_before=psnr0,
+    n_done = max(iterations - int(first_iter), 1)
+    return dict(seconds=dt, iters_per_sec=n_done / dt, first_loss=first, last_loss=last, psnr_before=psnr0,
                 psnr_after=evaluate_psnr(st), state=st)

@@ -556,6 +556,32 @@ np.savez_compressed(OUT, **out8)
 _run_reference_training("loopb", False, False, 8)
 student = _run_reference_training("loop", True, True, TL_ITERS)
 
+# ---- checkpoint contents: GaussianModel.capture() of the reference's own class after the run above (scene/gaussian_model.py:65-80):
+# the 13 entries in order, and the optimizer state_dict inside it (per-parameter step / exp_avg / exp_avg_sq, param-group keys)
+cap = student.capture()
+oc = dict(np.load(OUT))
+oc["capture_len"] = np.array(len(cap))
+oc["capture_active_sh_degree"] = np.array(cap[0])
+for i_, name_ in zip(range(1, 7), ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")):
+    oc["capture" + name_] = cap[i_].detach().numpy().copy()
+oc["capture_max_radii2D"], oc["capture_xyz_gradient_accum"], oc["capture_denom"] = (cap[7].numpy().copy(), cap[8].numpy().copy(),
+                                                                                     cap[9].numpy().copy())
+sd_ = cap[10]
+oc["capture_opt_group_keys"] = np.array(sorted(sd_["param_groups"][0].keys()))
+oc["capture_opt_group_names"] = np.array([g_["name"] for g_ in sd_["param_groups"]])
+oc["capture_opt_group_lrs"] = np.array([g_["lr"] for g_ in sd_["param_groups"]], dtype=np.float64)
+oc["capture_opt_group_params"] = np.array([g_["params"][0] for g_ in sd_["param_groups"]])
+oc["capture_opt_state_ids"] = np.array(sorted(sd_["state"].keys()))
+for k_, st_ in sd_["state"].items():
+    oc[f"capture_opt_state{k_}_keys"] = np.array(sorted(st_.keys()))
+    oc[f"capture_opt_state{k_}_step"] = np.array(int(st_["step"]))
+    oc[f"capture_opt_state{k_}_exp_avg"] = st_["exp_avg"].numpy().copy()
+    oc[f"capture_opt_state{k_}_exp_avg_sq"] = st_["exp_avg_sq"].numpy().copy()
+oc["capture_spatial_lr_scale"] = np.array(float(cap[11]))
+oc["capture_P"] = cap[12].detach().numpy().copy()
+np.savez_compressed(OUT, **oc)
+print("added capture() vectors:", len(oc), "arrays; optimizer groups", list(oc["capture_opt_group_names"]), "state ids", list(oc["capture_opt_state_ids"]))
+
 # ---- test-view pose tracking (reference render.py:99-186, `render_set_optimize`): Gaussians frozen, Adam on (t, q) with
 # weight decay and cosine annealing, masked L1, best-loss pose kept — again the reference's own function, taken from its
 # file and run around the C oracle operator, on the student the training run above produced.

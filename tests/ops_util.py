@@ -69,16 +69,16 @@ def check_ssim_golden(dev):
         assert float((x.grad.cpu() - g2).norm() / g2.norm()) <= 1e-5
 
 
-def check_ssim_random(dev, H, W, seed=0):
+def check_ssim_random(dev, H, W, seed=0, padding="same"):
     from instantsplat_amd.fused_ssim import fused_ssim
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(1, 3, H, W, generator=g)
     y = (x + 0.2 * torch.randn(1, 3, H, W, generator=g)).clamp(0, 1)
     xr = x.clone().requires_grad_(True)
-    vr = ssim_ref.ssim(xr, y)
+    vr = ssim_ref.ssim(xr, y, padding=padding)
     vr.backward()
     xd = x.to(dev).requires_grad_(True)
-    vd = fused_ssim(xd, y.to(dev))
+    vd = fused_ssim(xd, y.to(dev), padding=padding)
     vd.backward()
     assert abs(float(vd) - float(vr)) <= 1e-6
     assert float((xd.grad.cpu() - xr.grad).norm() / xr.grad.norm()) <= 1e-5
@@ -196,38 +196,53 @@ def check_pose_activations(dev, P=777, seed=0):
         assert float((a - b).norm() / (b.norm() + 1e-30)) <= 1e-5, k
 
 
-def check_fused_render_equals_unfused(dev):
-    """The fused glue and the op-by-op glue (both on the HIP rasterizer) give the same image and gradients."""
+def check_fused_render_equals_unfused(dev, degree=0):
+    """The three glues of render() — one posed autograd node (default), the round-1 fused glue (pose/activation kernel + SH
+    view + operator) and the op-by-op PyTorch glue, all on the HIP rasterizer — give the same image and the same gradients
+    for all seven tensors, at SH degree 0 (f_rest gets an all-zero gradient) and above (f_rest is differentiated)."""
     import instantsplat_amd.gaussian_renderer as gr
     from instantsplat_amd.synthetic import syn_pointmap
     from instantsplat_amd.train import setup_training
     sc = syn_pointmap(3, 24, 24, 64, 64, seed=5)
-    st = setup_training(sc, dev)
+    st = generic_start(setup_training(sc, dev))
     g = st.gaussians
+    g.active_sh_degree = degree
+    if degree:
+        gen = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            g._features_rest.copy_(0.05 * torch.randn(g._features_rest.shape, generator=gen).to(dev))
     names = dict(xyz=g._xyz, f_dc=g._features_dc, f_rest=g._features_rest, opacity=g._opacity, scaling=g._scaling,
                  rotation=g._rotation, pose=g.P)
     out = {}
-    for fused in (True, False):
+    default = gr.FUSED_GLUE
+    assert default == "posed"
+    for fused in ("posed", True, False):
         gr.FUSED_GLUE = fused
         try:
             for t in names.values():
                 t.grad = None
             cam = st.cameras[2]
-            img = gr.render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))["render"]
+            pkg = gr.render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+            img = pkg["render"]
             (img * st.gt_images[cam.uid]).sum().backward()
-            out[fused] = (img.detach().cpu(), {k: (None if t.grad is None else t.grad.detach().cpu().clone()) for k, t in names.items()})
+            out[fused] = (img.detach().cpu(), {k: (None if t.grad is None else t.grad.detach().cpu().clone()) for k, t in names.items()},
+                          pkg["radii"].cpu(), pkg["viewspace_points"].grad.detach().cpu().clone())
         finally:
-            gr.FUSED_GLUE = True
-    assert float((out[True][0] - out[False][0]).abs().max()) <= 1e-5
-    gscale = max(float(out[False][1][k].abs().max()) for k in ("xyz", "scaling", "opacity"))
-    for k in names:
-        a, b = out[True][1][k], out[False][1][k]
-        if k == "rotation":   # mathematically zero at the isotropic initialisation: only rounding noise on both sides
-            assert float((a - b).abs().max()) <= 1e-5 * gscale
-        elif float(b.norm()) == 0:
-            assert float(a.norm()) == 0, k
-        else:
-            assert float((a - b).norm() / b.norm()) <= 1e-4, (k, float((a - b).norm() / b.norm()))
+            gr.FUSED_GLUE = default
+    cuda = torch.device(dev).type == "cuda"
+    for fused in ("posed", True):
+        assert torch.equal(out[fused][2], out[False][2]), fused
+        bound("render_glues/image[%s]" % fused, (out[fused][0] - out[False][0]).abs().max(), 1e-5)
+        bound("render_glues/grad_viewspace_points[%s]" % fused, rel_l2(out[fused][3], out[False][3]), 1e-4)
+        for k in names:
+            a, b = out[fused][1][k], out[False][1][k]
+            if float(b.norm()) == 0:
+                assert float(a.norm()) == 0, (fused, k)
+            else:
+                bound("render_glues/grad_%s[%s]" % (k, fused), rel_l2(a, b), 1e-4)
+    assert (float(out["posed"][1]["f_rest"].abs().max()) > 0) == (degree > 0)
+    if not cuda:   # the posed node and the three-node glue run the same kernels' arithmetic: bit for bit under the emulator
+        assert torch.equal(out["posed"][0], out[True][0])
 
 
 def check_run_ahead_equals_sync_loop(dev, iters=23, force_overflow=False, Wm=20, W=48):
@@ -727,3 +742,86 @@ def check_pose_tracking_matches_reference_function(dev):
     bound("pose_tracking_ref/final_render", (res["render"].cpu() - T("track_final_render")).abs().max(), 2e-4)
     for t in (g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation):
         assert not t.requires_grad
+
+
+def check_capture_matches_reference_class(dev):
+    """GaussianModel.capture() after the recorded 12-iteration run vs the tuple the reference's own class returned after
+    the same run (tests/golden `capture_*`, scene/gaussian_model.py:65-80): 13 entries in the reference's order, parameter
+    values, densification placeholders, and the optimizer state_dict inside it (group keys / names / lrs, per-parameter
+    step, exp_avg, exp_avg_sq) — what makes chkpnt<iteration>.pth interchangeable."""
+    from instantsplat_amd.train import train_iteration
+    G, st, _ = _reference_loop_start(dev, "loop")
+    for _ in range(int(G["loop_flags"][2])):
+        train_iteration(st)
+    cap = st.gaussians.capture()
+    assert len(cap) == int(G["capture_len"]) == 13
+    assert cap[0] == int(G["capture_active_sh_degree"])
+    for i, name in zip(range(1, 7), ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")):
+        ref = torch.from_numpy(G["capture" + name])
+        assert tuple(cap[i].shape) == tuple(ref.shape) and isinstance(cap[i], torch.nn.Parameter), name
+        bound("capture/param" + name, rel_l2(cap[i], ref), 2e-5)
+    for i, name in ((7, "max_radii2D"), (8, "xyz_gradient_accum"), (9, "denom")):
+        ref = torch.from_numpy(G["capture_" + name])
+        assert tuple(cap[i].shape) == tuple(ref.shape) and float(cap[i].abs().max()) == float(ref.abs().max()) == 0.0, name
+    sd = cap[10]
+    assert sorted(sd["param_groups"][0].keys()) == list(G["capture_opt_group_keys"])
+    assert [g["name"] for g in sd["param_groups"]] == list(G["capture_opt_group_names"])
+    assert [g["params"][0] for g in sd["param_groups"]] == list(G["capture_opt_group_params"])
+    assert np.allclose([g["lr"] for g in sd["param_groups"]], G["capture_opt_group_lrs"], rtol=1e-12, atol=0)
+    assert sorted(sd["state"].keys()) == list(G["capture_opt_state_ids"])
+    for k, s_ in sd["state"].items():
+        assert sorted(s_.keys()) == list(G[f"capture_opt_state{k}_keys"])
+        assert int(s_["step"]) == int(G[f"capture_opt_state{k}_step"])
+        for m in ("exp_avg", "exp_avg_sq"):
+            ref = torch.from_numpy(G[f"capture_opt_state{k}_{m}"])
+            if float(ref.abs().max()) == 0.0:
+                assert float(s_[m].abs().max()) == 0.0, (k, m)
+            else:
+                bound(f"capture/opt_state_{m}[{k}]", rel_l2(s_[m], ref), 5e-5)
+    assert abs(float(cap[11]) - float(G["capture_spatial_lr_scale"])) <= 1e-6 * float(G["capture_spatial_lr_scale"])
+    bound("capture/P", rel_l2(cap[12], torch.from_numpy(G["capture_P"])), 1e-6)
+
+
+def check_checkpoint_save_and_resume(dev, tmp_path, Wm=10, W=24):
+    """training(model_path=..., saving_iterations, checkpoint_iterations, start_checkpoint): the files the reference writes
+    (train.py:107-110,220-227) appear with their formats, and a run resumed from chkpnt<k>.pth starts at iteration k with the
+    parameters, poses, optimizer moments / step counts and learning-rate schedule the interrupted run had there."""
+    import os
+    from instantsplat_amd.io_formats import load_gaussian_ply
+    from instantsplat_amd.scene import GaussianModel
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import training
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=19)
+    mp = str(tmp_path)
+    r = training(sc, dev, iterations=9, model_path=mp, saving_iterations=(6, 9), checkpoint_iterations=(6,))
+    g = r["state"].gaussians
+    for it in (6, 9):
+        assert os.path.exists(os.path.join(mp, "point_cloud", f"iteration_{it}", "point_cloud.ply"))
+        org, optd = (np.load(os.path.join(mp, "pose", f"ours_{it}", n + ".npy")) for n in ("pose_org", "pose_optimized"))
+        assert org.shape == optd.shape == (3, 4, 4) and float(np.abs(org - optd).max()) > 0
+    ply = load_gaussian_ply(os.path.join(mp, "point_cloud", "iteration_9", "point_cloud.ply"), 3, "cpu")
+    for k, v in ply.items():
+        assert torch.equal(v, getattr(g, k).detach().cpu()), k
+    m2 = GaussianModel(3)
+    m2.load_ply(os.path.join(mp, "point_cloud", "iteration_9", "point_cloud.ply"), device=dev)
+    assert m2.active_sh_degree == 3 and torch.equal(m2._features_rest.detach().cpu(), g._features_rest.detach().cpu())
+    ck_params, ck_iter = torch.load(os.path.join(mp, "chkpnt6.pth"), map_location="cpu", weights_only=False)
+    assert ck_iter == 6 and len(ck_params) == 13
+    # resume: zero further iterations -> the restored state itself
+    r2 = training(sc, dev, iterations=6, start_checkpoint=os.path.join(mp, "chkpnt6.pth"))
+    g2 = r2["state"].gaussians
+    assert r2["state"].iteration == 6
+    for i, name in zip(range(1, 7), ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")):
+        assert torch.equal(getattr(g2, name).detach().cpu(), ck_params[i].detach().cpu()), name
+    assert torch.equal(g2.P.detach().cpu(), ck_params[12].detach().cpu())
+    sd = g2.optimizer.state_dict()
+    for k, s_ in ck_params[10]["state"].items():
+        assert int(sd["state"][k]["step"]) == int(s_["step"]) == 6
+        assert torch.equal(sd["state"][k]["exp_avg"].cpu(), s_["exp_avg"].cpu()) and torch.equal(sd["state"][k]["exp_avg_sq"].cpu(), s_["exp_avg_sq"].cpu())
+    assert g2.optimizer.param_groups[0].get("per_point_lr") is not None     # the per-point multiplier survives the resume
+    # and it keeps training from there: iterations 7..9 run, the loss stays finite, parameters move
+    r3 = training(sc, dev, iterations=9, start_checkpoint=os.path.join(mp, "chkpnt6.pth"))
+    assert r3["state"].iteration == 9 and r3["last_loss"] == r3["last_loss"]
+    assert float((r3["state"].gaussians._xyz.detach().cpu() - ck_params[1].detach().cpu()).abs().max()) > 0
+    steps = [int(r3["state"].gaussians.optimizer.state[p]["step"]) for p in (r3["state"].gaussians._xyz, r3["state"].gaussians.P)]
+    assert steps == [8, 8]   # 6 restored + iterations 7 and 8 (the last iteration, 9, skips the optimizer)

@@ -20,6 +20,15 @@ def test_ssim_ragged_sizes(emu):
     ops_util.check_ssim_random(emu, 33, 17)   # not multiples of the 16x16 tile
 
 
+def test_ssim_valid_padding(emu):
+    ops_util.check_ssim_random(emu, 33, 40, padding="valid")
+    ops_util.check_ssim_random(emu, 12, 11, padding="valid")   # a 2x1 valid region
+    with pytest.raises(RuntimeError, match="larger than the 11x11 window"):
+        ops_util.check_ssim_random(emu, 10, 40, padding="valid")
+    with pytest.raises(ValueError):
+        ops_util.check_ssim_random(emu, 20, 20, padding="reflect")
+
+
 @pytest.mark.parametrize("n,dup", [(1, False), (3, False), (300, False), (700, True), (9000, False)])
 def test_knn_matches_kdtree(emu, n, dup):
     ops_util.check_knn(emu, n, duplicates=dup)
@@ -29,8 +38,9 @@ def test_pose_activations_match_autograd(emu):
     ops_util.check_pose_activations(emu)
 
 
-def test_fused_render_equals_unfused(emu):
-    ops_util.check_fused_render_equals_unfused(emu)
+@pytest.mark.parametrize("degree", [0, 2])
+def test_fused_render_equals_unfused(emu, degree):
+    ops_util.check_fused_render_equals_unfused(emu, degree)
 
 
 def test_run_ahead_equals_sync_loop(emu):
@@ -83,7 +93,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.mi355gs_abi_version.restype = ctypes.c_int
-    assert lib.mi355gs_abi_version() == 3
+    assert lib.mi355gs_abi_version() == 4
 
 
 def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
@@ -128,3 +138,11 @@ def test_oracle_trainer_matches_reference_function(emu):
 
 def test_pose_tracking_matches_reference_function(emu):
     ops_util.check_pose_tracking_matches_reference_function(emu)
+
+
+def test_capture_matches_reference_class(emu):
+    ops_util.check_capture_matches_reference_class(emu)
+
+
+def test_checkpoint_save_and_resume(emu, tmp_path):
+    ops_util.check_checkpoint_save_and_resume(emu, tmp_path)

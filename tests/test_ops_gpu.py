@@ -16,6 +16,11 @@ def test_ssim_sizes(gpu, H, W):
     ops_util.check_ssim_random(gpu, H, W)
 
 
+@pytest.mark.parametrize("H,W", [(40, 53), (512, 512)])
+def test_ssim_valid_padding(gpu, H, W):
+    ops_util.check_ssim_random(gpu, H, W, padding="valid")
+
+
 @pytest.mark.parametrize("n,dup", [(1, False), (3, False), (300, False), (5000, True), (60000, False)])
 def test_knn_matches_kdtree(gpu, n, dup):
     ops_util.check_knn(gpu, n, duplicates=dup)
@@ -25,8 +30,9 @@ def test_pose_activations_match_autograd(gpu):
     ops_util.check_pose_activations(gpu)
 
 
-def test_fused_render_equals_unfused(gpu):
-    ops_util.check_fused_render_equals_unfused(gpu)
+@pytest.mark.parametrize("degree", [0, 2])
+def test_fused_render_equals_unfused(gpu, degree):
+    ops_util.check_fused_render_equals_unfused(gpu, degree)
 
 
 def test_run_ahead_equals_sync_loop(gpu):

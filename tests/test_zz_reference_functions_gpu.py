@@ -24,3 +24,11 @@ def test_teacher_forced_gradients_match_reference_function(gpu, run, fused_loss)
 
 def test_pose_tracking_matches_reference_function(gpu):
     ops_util.check_pose_tracking_matches_reference_function(gpu)
+
+
+def test_capture_matches_reference_class(gpu):
+    ops_util.check_capture_matches_reference_class(gpu)
+
+
+def test_checkpoint_save_and_resume(gpu, tmp_path):
+    ops_util.check_checkpoint_save_and_resume(gpu, tmp_path)
