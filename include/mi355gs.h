@@ -130,6 +130,11 @@ int mi355gs_tune_min_units(int min_units);
  * kind: 0 = composite forward, 1 = composite backward.  profile_read synchronises the recorded events
  * and returns the summed milliseconds and launch count since profile_begin. */
 int mi355gs_profile_begin(void);
+/* While `counters` (device uint64[8], zeroed by the caller) is non-null, every composite-backward launch runs its counting
+ * instantiation and ADDS: [0] (Gaussian, tile) steps, [1] quadrant bodies evaluated, [2] of those with at least one valid
+ * pixel, [3] valid (pixel, Gaussian) pairs, [4] steps that ended in a reduction + atomics, [5] waves that did work.
+ * null switches back to the shipped kernel (which has no counters).  Process-wide, measurement only. */
+int mi355gs_profile_work_counters(void* counters);
 int mi355gs_profile_read(int kind, double* total_ms, int* launches);
 int mi355gs_profile_end(void);
 

@@ -18,7 +18,7 @@ int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uin
                             float*, float*, uint32_t*, const uint32_t*, GsSched*, const uint32_t*, uint2*, float4*, uint32_t, int);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint32_t*, const uint2*,
-                            const float4*, const uint32_t*, uint32_t, int, int);
+                            const float4*, const uint32_t*, uint32_t, int, int, unsigned long long*);
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
 // ---- optional per-kernel timing (HIP events on the launch stream)
@@ -26,6 +26,7 @@ namespace {
 constexpr int PROF_KINDS = 2, PROF_MAX = 8192;
 struct ProfState {
   bool on = false;
+  unsigned long long* work_counters = nullptr;   // device uint64[8] or null (mi355gs_profile_work_counters)
   hipEvent_t ev[PROF_KINDS][PROF_MAX][2];
   int created[PROF_KINDS] = {0, 0};
   int used[PROF_KINDS] = {0, 0};
@@ -196,7 +197,8 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
       gs_launch_composite_bwd(stream, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                               (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
                               dL_dpix, grads, out_color, (const uint32_t*)(t + tl.seg_first), (const uint2*)(b + bl.unit_tile),
-                              (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, tl.T, bl.level);
+                              (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, tl.T, bl.level,
+                              g_prof.work_counters);
     }
     GS_CHECK_LAUNCH("composite_bwd");
   }
@@ -225,6 +227,11 @@ int mi355gs_raster_frame_stats(void* stream_, int W, int H, const void* tiles, i
 int mi355gs_profile_begin(void) {
   g_prof.on = true;
   g_prof.used[0] = g_prof.used[1] = 0;
+  return MI355GS_OK;
+}
+
+int mi355gs_profile_work_counters(void* counters) {
+  g_prof.work_counters = (unsigned long long*)counters;
   return MI355GS_OK;
 }
 

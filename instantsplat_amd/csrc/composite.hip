@@ -280,7 +280,10 @@ constexpr int BW_UNITS = 4;  // units (waves) per workgroup
 
 // CHUNKS: 64-instance chunks per unit (1, or 0 = the run-time value `chunks` for the longer units of big frames; the
 // one-chunk instantiation keeps 74 VGPRs / six waves per SIMD, the loop over chunks costs 15 more)
-template <int CHUNKS>
+// COUNT: the measurement instantiation (mi355gs_profile_work_counters): the same kernel also adds up, per wave, how many
+// (Gaussian, tile) steps it ran, how many quadrant bodies, and how many lanes of those bodies were valid pixels — the inputs
+// of the VALU-issue model bench.py reports next to the HBM roofline.  The shipped launches use COUNT = false: no counters exist.
+template <int CHUNKS, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
                                                         const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
                                                         const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
                                                         const uint2* __restrict__ unit_tile, const float4* __restrict__ bstate,
-                                                        const uint32_t* __restrict__ n_units, uint32_t max_units, uint32_t chunks_rt) {
+                                                        const uint32_t* __restrict__ n_units, uint32_t max_units, uint32_t chunks_rt,
+                                                        unsigned long long* __restrict__ counters) {
   __shared__ float4 s_q0[BW_UNITS][GS_SEG];
   __shared__ float4 s_q1[BW_UNITS][GS_SEG];
   __shared__ float4 s_q2[BW_UNITS][GS_SEG];
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
   const int out_comp = lane == 2 ? 8 : (lane >> 4) + 4 * (lane & 1);   // ... and which of the nine it is
   unsigned long long mq[4];  // per quadrant: which of the staged chunk's records reach it
   uint32_t cb = 0;           // contributor index (0-based) of the staged chunk's first instance
+  [[maybe_unused]] unsigned long long c_steps = 0, c_quads = 0, c_quads_valid = 0, c_lanes = 0, c_reduced = 0;
 
   // One (Gaussian, tile) step of the back-to-front replay: the pixels of every quadrant the Gaussian reaches, then ONE
   // reduction + one row of nine atomics.
@@ -373,8 +378,10 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
         const float au = a1.w * __builtin_amdgcn_exp2f(power2);
         // (contributor = cb + i2 + 1 <= last: the instance lies at or in front of the pixel's last contributor)
         const bool valid = (int)cb + i2 < lastq[qd] && power2 <= 0.0f && au >= ALPHA_MIN;
+        if constexpr (COUNT) { c_quads += 1; c_lanes += __popcll(__ballot(valid)); }
         if (__any(valid)) {
           any_valid = true;
+          if constexpr (COUNT) c_quads_valid += 1;
           // A lane that must skip this Gaussian treats it as fully transparent (alpha 0): T and the colour behind then
           // evolve exactly as if it had been skipped, so the replay state needs no per-field selects.
           const float av = valid ? au : 0.f;
@@ -402,6 +409,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
         }
       }
     }
+    if constexpr (COUNT) { c_steps += 1; c_reduced += any_valid ? 1 : 0; }
     if (any_valid) {
       // Nine values x 64 lanes -> nine sums, transposed so that every step halves the number of live values:
       // rows first (v_permlane16/32_swap pair steps, two ops per pair), then lane bits 0 and 1 inside the row (DPP
@@ -477,6 +485,12 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
       if (!moreA) break;
     }
   }
+  if constexpr (COUNT) {
+    if (lane == 0 && counters) {
+      atomicAdd(counters + 0, c_steps); atomicAdd(counters + 1, c_quads); atomicAdd(counters + 2, c_quads_valid);
+      atomicAdd(counters + 3, c_lanes); atomicAdd(counters + 4, c_reduced); atomicAdd(counters + 5, 1ull);
+    }
+  }
 }
 
 // per-tile max of n_contrib -> R_eff (roofline accounting only)
@@ -523,14 +537,14 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint32_t* seg_first, const uint2* unit_tile, const float4* bstate, const uint32_t* meta,
-                            uint32_t max_units, int T, int level) {
+                            uint32_t max_units, int T, int level, unsigned long long* counters) {
   const dim3 grid((max_units + BW_UNITS - 1) / BW_UNITS);
   const uint32_t* sf = seg_first + (size_t)level * (T + 1);
-  if (level == 0)
-    hipLaunchKernelGGL(k_composite_bwd<1>, grid, dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T, n_contrib,
-                       dL_dpix, grads, out_color, sf, unit_tile, bstate, meta + 4 + level, max_units, 1u);
-  else
-    hipLaunchKernelGGL(k_composite_bwd<0>, grid, dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T, n_contrib,
-                       dL_dpix, grads, out_color, sf, unit_tile, bstate, meta + 4 + level, max_units, 1u << level);
+#define GS_BWD(CH, CNT)                                                                                                               \
+  hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
+                     n_contrib, dL_dpix, grads, out_color, sf, unit_tile, bstate, meta + 4 + level, max_units, 1u << level, counters)
+  if (counters) { if (level == 0) GS_BWD(1, true); else GS_BWD(0, true); }
+  else { if (level == 0) GS_BWD(1, false); else GS_BWD(0, false); }
+#undef GS_BWD
   return 0;
 }
