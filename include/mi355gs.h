@@ -160,16 +160,12 @@ int mi355gs_ssim_forward(void* stream, int B, int C, int H, int W, const float* 
 int mi355gs_ssim_backward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,
                           const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                           const float* ssim_grad_scale, const float* l1_grad_scale, float* dL_dimg1, int padding_valid);
-/* The reference's training loss (train.py:171-176) on the same two kernels: loss = (1 - lambda) * L1 + lambda * (1 - SSIM).
- * forward: ssim_mean / l1_mean (optional) and loss: device float[1] each.  backward: dL_dimg1 = *grad_loss * dloss/dimg1
- * (grad_loss: device float[1], what autograd hands the binding). */
-int mi355gs_l1_ssim_loss_forward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2, float* dm_dmu1,
-                                 float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float lambda_dssim, float* ssim_mean,
-                                 float* l1_mean, float* loss);
-int mi355gs_l1_ssim_loss_backward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2,
-                                  const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* grad_loss,
-                                  float lambda_dssim, float* dL_dimg1);
-
+/* The reference's training loss (train.py:171-176), loss = (1 - lambda) * L1 + lambda * (1 - SSIM), and dloss_dimg1 [B,C,H,W]
+ * (the gradient for dL/dloss = 1) from ONE pass over the two images: the SSIM partial-derivative maps never leave LDS, about a
+ * third of the traffic of mi355gs_ssim_forward + _backward.  ssim_mean / l1_mean (optional) and loss: device float[1] each.
+ * The binding's forward calls this and keeps the gradient; its backward multiplies it by the incoming dL/dloss. */
+int mi355gs_l1_ssim_loss_fused(void* stream, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
+                               float lambda_dssim, float* ssim_mean, float* l1_mean, float* loss, float* dloss_dimg1);
 /* ------------------------------------------------------------------------------------------------
  * simple-knn
  * replaces: simple_knn._C.distCUDA2(points) at reference scene/gaussian_model.py:156 —

@@ -111,9 +111,28 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
 }
 
 __global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __restrict__ pose, const float* __restrict__ partial, int nrows,
-                                                               float* __restrict__ d_pose, float* __restrict__ pose_gate) {
+                                                               float* __restrict__ d_pose, float* __restrict__ pose_gate,
+                                                               const float* __restrict__ loss_partial, int loss_nblocks,
+                                                               double loss_inv_n, float lambda_dssim, float* __restrict__ loss) {
   __shared__ float s_sum[64][17];
   __shared__ float s_tot[16];
+  // One-call train step: this single-workgroup, latency-bound kernel also sums the loss kernel's per-workgroup partials into the
+  // loss VALUE (reference train.py:176; only ever read by the host) — in a fixed order, double accumulation — instead of a
+  // finishing launch of its own.
+  if (loss) {
+    __shared__ double s_la[16], s_lb[16];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < loss_nblocks; i += 1024) { a += (double)loss_partial[2 * i]; b += (double)loss_partial[2 * i + 1]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+    if ((threadIdx.x & 63) == 0) { s_la[threadIdx.x >> 6] = a; s_lb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double ta = 0.0, tb = 0.0;
+      for (int w = 0; w < 16; ++w) { ta += s_la[w]; tb += s_lb[w]; }
+      *loss = (1.0f - lambda_dssim) * (float)(tb * loss_inv_n) + lambda_dssim * (1.0f - (float)(ta * loss_inv_n));
+    }
+  }
   const int k = threadIdx.x & 15, g = threadIdx.x >> 4;  // 64 row groups x 16 sums; a wave reads 4 consecutive rows (256 B)
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;           // independent loads in flight: this kernel is pure latency
   int r = g;
@@ -144,8 +163,10 @@ __global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __re
 // dL/dpose from per-workgroup rows of the 16 pose sums (internal entry for the one-call train step, whose backward
 // projection kernel stores one row per workgroup instead of issuing atomics): deterministic tree sum, then pose_finish
 int gs_launch_pose_finish_partials(hipStream_t stream, const float* pose, const float* partial, int nrows, float* d_pose,
-                                   float* pose_gate) {
-  hipLaunchKernelGGL(k_pose_finish_partials, dim3(1), dim3(1024), 0, stream, pose, partial, nrows, d_pose, pose_gate);
+                                   float* pose_gate, const float* loss_partial, int loss_nblocks, double loss_inv_n,
+                                   float lambda_dssim, float* loss) {
+  hipLaunchKernelGGL(k_pose_finish_partials, dim3(1), dim3(1024), 0, stream, pose, partial, nrows, d_pose, pose_gate, loss_partial,
+                     loss_nblocks, loss_inv_n, lambda_dssim, loss);
   return 0;
 }
 

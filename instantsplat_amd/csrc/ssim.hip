@@ -164,25 +164,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
                                                    const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
                                                    const float* __restrict__ dm_dsigma12, const float* __restrict__ ssim_scale,
                                                    const float* __restrict__ l1_scale, float ssim_scale_host, float l1_scale_host,
-                                                   float* __restrict__ dL_dimg1, const float* __restrict__ fwd_partial, int fwd_nblocks,
-                                                   double fwd_inv_n, float lambda_dssim, float* __restrict__ loss) {
-  // Fused train step: the loss value itself (only ever read by the host) is reduced here by workgroup 0 from the forward
-  // kernel's per-block partial sums, instead of by a launch of its own between forward and backward.
-  if (loss && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-    __shared__ double s_fa[4], s_fb[4];
-    const int t = threadIdx.y * TS + threadIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int i = t; i < fwd_nblocks; i += 256) { a += (double)fwd_partial[2 * i]; b += (double)fwd_partial[2 * i + 1]; }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-    if ((t & 63) == 0) { s_fa[t >> 6] = a; s_fb[t >> 6] = b; }
-    __syncthreads();
-    if (t == 0) {
-      const double ta = (s_fa[0] + s_fa[1]) + (s_fa[2] + s_fa[3]), tb = (s_fb[0] + s_fb[1]) + (s_fb[2] + s_fb[3]);
-      const float sm = (float)(ta * fwd_inv_n), lm = (float)(tb * fwd_inv_n);
-      *loss = (1.0f - lambda_dssim) * lm + lambda_dssim * (1.0f - sm);  // reference train.py:176
-    }
-  }
+                                                   float* __restrict__ dL_dimg1) {
   __shared__ float s_a[TH][SXP];
   __shared__ float s_b[TH][SXP];
   __shared__ float s_c[TH][SXP];
@@ -260,6 +242,219 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, float inv_n, con
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The training loss and its gradient in ONE pass: loss = (1-l) * L1 + l * (1 - SSIM) (reference train.py:171-176) and
+// dloss/dimg1.  The two-kernel formulation above writes the three SSIM partial-derivative maps (36 B per pixel-channel) to
+// HBM and reads them back with a 2.1x halo amplification — 75 % of its traffic (profiles/r02_pmc_c4_*: 193 + 228 MB per 1080p
+// frame).  Here a workgroup owns a 32x32 output tile and recomputes the forward on the tile + window radius (42x42) from
+// inputs staged over tile + 2 radii (52x52); the maps only ever exist in LDS.
+//   A  stage x, y over 52x52 (zero outside the image)                                   -> s_x, s_y
+//   B  forward row pass: rows 0..51, columns 0..41, five moments                        -> s_h
+//   C  forward column pass + SSIM formula on 42x42: value (tile pixels only), d1..d3     -> s_d (over s_x / s_y), zero outside the image
+//   D  backward row pass on d1..d3: rows 0..41, columns 0..31                           -> s_e (over s_h)
+//   E  backward column pass on the 32x32 tile + gradient + L1 term                      -> global
+// Every pass is a register sliding window: a thread produces a run of 6 / 7 / 8 / 4 consecutive outputs along the pass
+// direction from run + 10 inputs read once (the per-tap formulation read each input 11 times from LDS).
+constexpr int FT = 32;             // fused output tile edge
+constexpr int FR1 = FT + 2 * HALO;  // 42
+constexpr int FR2 = FT + 4 * HALO;  // 52
+// LDS pitches (floats), chosen with the lane -> item mappings below so that no pass has bank conflicts: a row pass reads pairs
+// (8-byte loads) with the ROW index varying fastest across lanes, which is conflict-free when the pitch is 2 x odd; a column pass
+// and every store walk consecutive columns across lanes, conflict-free for any pitch, and an odd pitch keeps the row passes'
+// scattered 4-byte stores (consecutive rows across lanes) on distinct banks too.  (First version: pitches 56 / 44 / 32 with the
+// column group varying fastest — the backward row pass's stores were 16-way conflicts.)
+constexpr int FXP = 58;            // staged inputs (52 wide), read in pairs by the forward row pass
+constexpr int FHP = 43;            // row-pass moments (42 wide), stored one float at a time, read down columns
+constexpr int FDP = 46;            // d1..d3 (42 wide), read in pairs by the backward row pass
+constexpr int FEP = 33;            // backward row-pass results (32 wide), stored one float at a time, read down columns
+constexpr int FTHREADS = 512;      // eight waves per workgroup: the tile's LDS (69 KB) allows two workgroups per CU, so this is
+                                   // what puts four waves on every SIMD
+constexpr int F_STAGE_ITERS = (FR2 * FXP + FTHREADS - 1) / FTHREADS;   // 6
+constexpr int FER = FT * FT / FTHREADS;   // output rows per thread in the last pass (2)
+
+__global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                        float ks /* d loss / d ssim_mean / N */, float kl /* d loss / d l1_mean / N */,
+                                                        float* __restrict__ dL_dimg1, float* __restrict__ partial /*[nblocks,2]*/) {
+  __shared__ float s_xy[2][FR2][FXP];        // x, y staged; later d1..d3 [3][FR1][FDP] (5796 <= 6032 floats)
+  __shared__ float s_h[5][FR2][FHP];         // row-pass moments; later the backward row pass [3][FR1][FEP]
+  static_assert(3 * FR1 * FDP <= 2 * FR2 * FXP && 3 * FR1 * FEP <= 5 * FR2 * FHP, "aliased LDS buffers must fit");
+  __shared__ float s_red[2][FTHREADS / 64];
+  float (*s_d)[FR1][FDP] = reinterpret_cast<float (*)[FR1][FDP]>(&s_xy[0][0][0]);
+  float (*s_e)[FR1][FEP] = reinterpret_cast<float (*)[FR1][FEP]>(&s_h[0][0][0]);
+  const int tid = threadIdx.x;
+  const int plane = blockIdx.z;
+  const int ox = blockIdx.x * FT, oy = blockIdx.y * FT;
+  const size_t po = (size_t)plane * H * W;
+  const float* p1 = img1 + po;
+  const float* p2 = img2 + po;
+  // the thread's own output pixels (phase E: column ec, rows er0..er0+FER-1), requested first, used last
+  const int ec = tid & 31, er0 = (tid >> 5) * FER;
+  float ex[FER], ey[FER];
+#pragma unroll
+  for (int j = 0; j < FER; ++j) {
+    const size_t o = (size_t)min(oy + er0 + j, H - 1) * W + min(ox + ec, W - 1);
+    ex[j] = p1[o]; ey[j] = p2[o];
+  }
+  // ---- A: staging, every load to a clamped (valid) address and in flight before the first LDS write
+  {
+    float vx[F_STAGE_ITERS], vy[F_STAGE_ITERS];
+#pragma unroll
+    for (int j = 0; j < F_STAGE_ITERS; ++j) {
+      const int i = tid + FTHREADS * j, r = i / FXP, c = i - r * FXP;
+      const size_t o = (size_t)min(max(oy + r - 2 * HALO, 0), H - 1) * W + min(max(ox + c - 2 * HALO, 0), W - 1);
+      vx[j] = p1[o]; vy[j] = p2[o];
+    }
+#pragma unroll
+    for (int j = 0; j < F_STAGE_ITERS; ++j) {
+      const int i = tid + FTHREADS * j, r = i / FXP, c = i - r * FXP;
+      const int gy = oy + r - 2 * HALO, gx = ox + c - 2 * HALO;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      if (i < FR2 * FXP) { s_xy[0][r][c] = in ? vx[j] : 0.f; s_xy[1][r][c] = in ? vy[j] : 0.f; }
+    }
+  }
+  __syncthreads();
+  // ---- B: forward row pass, item = (row, 6 consecutive columns): 16 inputs of x and y -> 6 x 5 outputs
+  for (int i = tid; i < FR2 * 7; i += FTHREADS) {
+    const int r = i % FR2, c0 = (i / FR2) * 6;   // rows vary fastest across lanes
+    float x[16], y[16];
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+      const float2 a = *reinterpret_cast<const float2*>(&s_xy[0][r][c0 + t]);
+      const float2 b = *reinterpret_cast<const float2*>(&s_xy[1][r][c0 + t]);
+      x[t] = a.x; x[t + 1] = a.y; y[t] = b.x; y[t + 1] = b.y;
+    }
+    float sx[6], sy[6], sxx[6], syy[6], sxy[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { sx[j] = sy[j] = sxx[j] = syy[j] = sxy[j] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float xx = x[t] * x[t], yy = y[t] * y[t], xy = x[t] * y[t];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int k = t - j;   // tap index of input t for output j
+        if (k >= 0 && k < 11) {
+          const float w = gw(k);
+          sx[j] = fmaf(w, x[t], sx[j]); sy[j] = fmaf(w, y[t], sy[j]);
+          sxx[j] = fmaf(w, xx, sxx[j]); syy[j] = fmaf(w, yy, syy[j]); sxy[j] = fmaf(w, xy, sxy[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      s_h[0][r][c0 + j] = sx[j]; s_h[1][r][c0 + j] = sy[j]; s_h[2][r][c0 + j] = sxx[j]; s_h[3][r][c0 + j] = syy[j];
+      s_h[4][r][c0 + j] = sxy[j];
+    }
+  }
+  __syncthreads();
+  // ---- C: forward column pass + SSIM formula, item = (column, 7 consecutive rows): 17 inputs per moment -> 7 outputs
+  float val = 0.f;
+  if (tid < FR1 * 6) {
+    const int c = tid % FR1, r0 = (tid / FR1) * 7;
+    float mo[5][7];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      float v[17];
+#pragma unroll
+      for (int t = 0; t < 17; ++t) v[t] = s_h[m][r0 + t][c];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a = fmaf(gw(k), v[j + k], a);
+        mo[m][j] = a;
+      }
+    }
+    const int gx = ox + c - HALO;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int r = r0 + j, gy = oy + r - HALO;
+      const float mu1 = mo[0][j], mu2 = mo[1][j];
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float s1 = mo[2][j] - mu1_sq, s2 = mo[3][j] - mu2_sq, s12 = mo[4][j] - mu12;
+      const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2, Cc = 2.f * mu12 + C1, Dd = 2.f * s12 + C2;
+      const float invA = ssim_rcp(A), invB = ssim_rcp(B), invAB = invA * invB;
+      const float m = Cc * Dd * invAB;
+      const float t = mu1 * 2.f * Cc * Dd * invAB;
+      const float d1 = (mu2 * 2.f * Dd) * invAB - (mu2 * 2.f * Cc) * invAB - t * invA + t * invB;
+      const float d2 = -m * invB;
+      const float d3 = 2.f * Cc * invAB;
+      const bool in_img = gx >= 0 && gx < W && gy >= 0 && gy < H;
+      // (the staged inputs stay readable until the barrier below: s_d aliases them, and phase C reads only s_h)
+      mo[0][j] = in_img ? d1 : 0.f; mo[1][j] = in_img ? d2 : 0.f; mo[2][j] = in_img ? d3 : 0.f;
+      const bool in_tile = c >= HALO && c < HALO + FT && r >= HALO && r < HALO + FT;
+      val += (in_img && in_tile) ? m : 0.f;
+    }
+    // all phase-B readers of s_xy are past the barrier above, so the maps may overwrite it
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { s_d[0][r0 + j][c] = mo[0][j]; s_d[1][r0 + j][c] = mo[1][j]; s_d[2][r0 + j][c] = mo[2][j]; }
+  }
+  __syncthreads();
+  // ---- D: backward row pass, item = (row, 8 consecutive columns): 18 inputs per map -> 8 outputs
+  if (tid < FR1 * 4) {
+    const int r = tid % FR1, c0 = (tid / FR1) * 8;   // rows vary fastest across lanes
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      float v[18];
+#pragma unroll
+      for (int t = 0; t < 18; t += 2) {
+        const float2 a = *reinterpret_cast<const float2*>(&s_d[m][r][c0 + t]);
+        v[t] = a.x; v[t + 1] = a.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a = fmaf(gw(k), v[j + k], a);
+        s_e[m][r][c0 + j] = a;   // s_e aliases s_h: every phase-C reader of s_h is past the barrier above
+      }
+    }
+  }
+  __syncthreads();
+  // ---- E: backward column pass on the tile, item = (column, FER rows): FER + 10 inputs per map -> FER outputs; gradient + L1
+  float l1 = 0.f;
+  {
+    float out[3][FER];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      float v[FER + 10];
+#pragma unroll
+      for (int t = 0; t < FER + 10; ++t) v[t] = s_e[m][er0 + t][ec];
+#pragma unroll
+      for (int j = 0; j < FER; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a = fmaf(gw(k), v[j + k], a);
+        out[m][j] = a;
+      }
+    }
+    const int gx = ox + ec;
+#pragma unroll
+    for (int j = 0; j < FER; ++j) {
+      const int gy = oy + er0 + j;
+      if (gx < W && gy < H) {
+        const float x = ex[j], y = ey[j], d = x - y;
+        l1 += fabsf(d);
+        const float g = ks * (out[0][j] + 2.f * x * out[1][j] + y * out[2][j]) + kl * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        dL_dimg1[po + (size_t)gy * W + gx] = g;
+      }
+    }
+  }
+  val = gs_wave_sum(val);
+  l1 = gs_wave_sum(l1);
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) { s_red[0][wave] = val; s_red[1][wave] = l1; }
+  __syncthreads();
+  if (tid == 0) {
+    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int w = 0; w < FTHREADS / 64; ++w) { ta += s_red[0][w]; tb += s_red[1][w]; }
+    partial[2 * b] = ta;
+    partial[2 * b + 1] = tb;
+  }
+}
+
 }  // namespace
 
 static inline int ssim_nblocks(int B, int C, int H, int W) { return B * C * ((H + TS - 1) / TS) * ((W + TSX - 1) / TSX); }
@@ -306,71 +501,44 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
   // the forward zeroed the saved partials outside the counted region, so the same kernel serves both paddings
   const float inv_n = (float)(1.0 / ((double)B * C * (H - 2 * crop) * (W - 2 * crop)));
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
-                     ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1,
-                     (const float*)nullptr, 0, 0.0, 0.f, (float*)nullptr);
+                     ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1);
   GS_CHECK_LAUNCH("ssim_bwd");
   return MI355GS_OK;
 }
 
-// The training loss of reference train.py:171-176 in the same two kernels: loss = (1-l) * L1 + l * (1 - SSIM) leaves the finishing
-// kernel as a third scalar, and the backward takes dL/dloss from a device scalar with the two weights applied on the way in —
-// no elementwise torch kernels around the operator in the binding.
-int mi355gs_l1_ssim_loss_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, float* dm_dmu1,
-                                 float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float lambda_dssim, float* ssim_mean,
-                                 float* l1_mean, float* loss) {
+static inline int fused_nblocks(int B, int C, int H, int W) { return B * C * ((H + FT - 1) / FT) * ((W + FT - 1) / FT); }
+
+// loss = (1-l) * L1 + l * (1 - SSIM) AND dloss/dimg1 from one pass over the images (k_l1_ssim_fused): the binding's forward keeps
+// the gradient and its backward only scales it by the incoming dL/dloss.
+int mi355gs_l1_ssim_loss_fused(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
+                               float lambda_dssim, float* ssim_mean, float* l1_mean, float* loss, float* dloss_dimg1) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !loss) return MI355GS_EINVAL;
-  if (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12) return MI355GS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !loss || !dloss_dimg1) return MI355GS_EINVAL;
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
-  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
-  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch, 0);
-  GS_CHECK_LAUNCH("ssim_fwd");
   const double inv_n = 1.0 / ((double)B * C * H * W);
-  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
+  const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, B * C);
+  hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
+                     (float)((1.0 - (double)lambda_dssim) * inv_n), dloss_dimg1, (float*)scratch);
+  GS_CHECK_LAUNCH("l1_ssim_fused");
+  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, fused_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
                      l1_mean, loss, lambda_dssim);
   GS_CHECK_LAUNCH("ssim_finish");
   return MI355GS_OK;
 }
 
-int mi355gs_l1_ssim_loss_backward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
-                                  const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* grad_loss, float lambda_dssim,
-                                  float* dL_dimg1) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int debug = 0;
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dL_dimg1 || !grad_loss) return MI355GS_EINVAL;
-  if (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12) return MI355GS_EINVAL;
-  if ((size_t)B * C > 65535) return MI355GS_EINVAL;
-  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
-  const float inv_n = (float)(1.0 / ((double)B * C * H * W));
-  hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, grad_loss,
-                     grad_loss, -lambda_dssim, 1.0f - lambda_dssim, dL_dimg1, (const float*)nullptr, 0, 0.0, 0.f, (float*)nullptr);
-  GS_CHECK_LAUNCH("ssim_bwd");
-  return MI355GS_OK;
-}
-
 }  // extern "C"
 
-// internal entry for the fused train step: loss = (1-l)*L1 + l*(1-SSIM) forward, its gradient backward (d loss = 1)
-int gs_loss_forward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, float* dm1, float* dm2, float* dm3,
-                    void* scratch) {
+// one-call train step: loss gradient (d loss = 1) in one launch; the loss VALUE is finished later from `scratch`
+// (gs_loss_partials_info) by a kernel the step runs anyway
+int gs_loss_fused(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, float* dL_dimg1,
+                  void* scratch) {
   const int debug = 0;
-  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, C);
-  hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm1, dm2, dm3, (float*)scratch, 0);
-  GS_CHECK_LAUNCH("ssim_fwd");
+  const double inv_n = 1.0 / ((double)C * H * W);
+  const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, C);
+  hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
+                     (float)((1.0 - (double)lambda_dssim) * inv_n), dL_dimg1, (float*)scratch);
+  GS_CHECK_LAUNCH("l1_ssim_fused");
   return MI355GS_OK;
 }
-
-// also writes *loss from the forward's partial sums in `scratch` (see k_ssim_bwd)
-int gs_loss_backward(hipStream_t stream, int C, int H, int W, const float* img1, const float* img2, const float* dm1,
-                     const float* dm2, const float* dm3, float lambda_dssim, float* dL_dimg1, const void* scratch, float* loss) {
-  const int debug = 0;
-  const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, C);
-  const double inv_n_d = 1.0 / ((double)C * H * W);
-  const float inv_n = (float)inv_n_d;
-  hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm1, dm2, dm3, (const float*)nullptr,
-                     (const float*)nullptr, -lambda_dssim, 1.0f - lambda_dssim, dL_dimg1, (const float*)scratch, ssim_nblocks(1, C, H, W),
-                     inv_n_d, lambda_dssim, loss);
-  GS_CHECK_LAUNCH("ssim_bwd");
-  return MI355GS_OK;
-}
+int gs_loss_fused_nblocks(int C, int H, int W) { return fused_nblocks(1, C, H, W); }

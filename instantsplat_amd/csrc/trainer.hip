@@ -15,10 +15,9 @@
 #include <string.h>
 #include "common.h"
 
-int gs_loss_forward(hipStream_t, int, int, int, const float*, const float*, float*, float*, float*, void*);
-int gs_launch_pose_finish_partials(hipStream_t, const float*, const float*, int, float*, float*);
-int gs_loss_backward(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, float, float*,
-                     const void*, float*);
+int gs_loss_fused(hipStream_t, int, int, int, const float*, const float*, float, float*, void*);
+int gs_loss_fused_nblocks(int, int, int);
+int gs_launch_pose_finish_partials(hipStream_t, const float*, const float*, int, float*, float*, const float*, int, double, float, float*);
 
 namespace {
 
@@ -32,7 +31,7 @@ struct Trainer {
   const float* pplr;
   // workspace slices
   char *geom, *tiles, *binning, *grad_scratch, *ssim_scratch;
-  float *image, *dm1, *dm2, *dm3, *dL_dimg;
+  float *image, *dL_dimg;
   int32_t* radii;
   float *g_means2D, *g_colors;
   float *g_xyz, *g_rot, *g_scaling, *g_opacity, *g_fdc, *g_frest, *g_poses;
@@ -60,8 +59,7 @@ size_t carve(Trainer& t, void* workspace) {
   t.binning = c.take<char>(mi355gs_raster_binning_bytes(t.capacity, t.W, t.H));
   t.grad_scratch = c.take<char>(mi355gs_raster_grad_scratch_bytes(t.P));
   t.ssim_scratch = c.take<char>(mi355gs_ssim_scratch_bytes(1, 3, t.H, t.W));
-  t.image = c.take<float>(3 * npix); t.dm1 = c.take<float>(3 * npix); t.dm2 = c.take<float>(3 * npix);
-  t.dm3 = c.take<float>(3 * npix); t.dL_dimg = c.take<float>(3 * npix);
+  t.image = c.take<float>(3 * npix); t.dL_dimg = c.take<float>(3 * npix);
   t.radii = c.take<int32_t>(P);
   t.g_means2D = c.take<float>(3 * P); t.g_colors = c.take<float>(3 * P);
   t.g_xyz = c.take<float>(3 * P); t.g_rot = c.take<float>(4 * P); t.g_scaling = c.take<float>(3 * P); t.g_opacity = c.take<float>(P);
@@ -131,7 +129,7 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
                                  D == 0 ? nullptr : d_f_rest, nullptr, d_opacity_logit, d_log_scales, d_rotation, nullptr, debug);
   }
   if (rc) return rc;
-  gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, nullptr);
+  gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, nullptr, nullptr, 0, 0.0, 0.f, nullptr);
   GS_CHECK_LAUNCH("pose_finish");
   return MI355GS_OK;
 }
@@ -221,18 +219,17 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
                                               t->geom, t->tiles, num_rendered_out, 0)))
     return rc;
   if ((rc = mi355gs_raster_forward_render(stream, P, W, H, t->capacity, bg, t->geom, t->tiles, t->binning, t->image, 0))) return rc;
-  if ((rc = gs_loss_forward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, t->ssim_scratch))) return rc;
-  // ---- backward
-  if ((rc = gs_loss_backward(stream, 3, H, W, t->image, gt_image, t->dm1, t->dm2, t->dm3, lambda_dssim, t->dL_dimg, t->ssim_scratch,
-                             loss_out)))
-    return rc;
+  // ---- loss and its gradient in one launch (the SSIM partial-derivative maps never leave LDS); the loss VALUE, which only
+  // the host ever reads, is summed from the per-workgroup partials by the single-workgroup pose-finish kernel further down
+  if ((rc = gs_loss_fused(stream, 3, H, W, t->image, gt_image, lambda_dssim, t->dL_dimg, t->ssim_scratch))) return rc;
   // ---- backward: down to the raw-parameter gradients and the pose sums in one kernel, then the 7 pose gradients
   if ((rc = mi355gs_raster_backward(stream, P, D, M, W, H, bg, t->xyz, t->f_dc, rest, nullptr, t->opacity, t->scaling, 1.0f, t->rotation,
                                     nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, t->geom, t->tiles, t->binning,
                                     t->capacity, t->radii, t->image, t->dL_dimg, t->grad_scratch, t->g_xyz, t->g_means2D, t->g_fdc,
                                     g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0)))
     return rc;
-  gs_launch_pose_finish_partials(stream, pose, t->pose_partial, (P + 255) / 256, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6);
+  gs_launch_pose_finish_partials(stream, pose, t->pose_partial, (P + 255) / 256, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6,
+                                 (const float*)t->ssim_scratch, gs_loss_fused_nblocks(3, H, W), 1.0 / (3.0 * H * W), lambda_dssim, loss_out);
   GS_CHECK_LAUNCH("pose_finish");
   // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
   if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps);

@@ -71,8 +71,8 @@ def fused_ssim(img1, img2, padding="same", train=True):
 
 
 class _FusedL1SSIM(torch.autograd.Function):
-    """(1-lambda)*L1 + lambda*(1-SSIM) with the weighted sum formed inside the library (mi355gs_l1_ssim_loss_*): one call each
-    way and no elementwise torch kernels around it."""
+    """(1-lambda)*L1 + lambda*(1-SSIM): loss AND its gradient w.r.t. img1 come out of one pass over the images
+    (mi355gs_l1_ssim_loss_fused); backward only scales the kept gradient by the incoming dL/dloss."""
 
     @staticmethod
     def forward(ctx, img1, img2, lambda_dssim):
@@ -82,35 +82,23 @@ class _FusedL1SSIM(torch.autograd.Function):
             raise RuntimeError("fused_ssim expects two [B,C,H,W] tensors of equal shape")
         dev = _lib.require_device(a, b)
         B, C, H, W = a.shape
-        dm1, dm2, dm3 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
         scratch = torch.empty(int(L.mi355gs_ssim_scratch_bytes(B, C, H, W)), dtype=torch.uint8, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)   # [ssim_mean, l1_mean]
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        lam = float(lambda_dssim)
+        grad = torch.empty_like(a)
         p0 = out.data_ptr()
         with _lib.on_device(dev):
-            _lib.check(L.mi355gs_l1_ssim_loss_forward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1),
-                                                      _lib.ptr(dm2), _lib.ptr(dm3), _lib.ptr(scratch), lam, p0, p0 + 4, _lib.ptr(loss)),
-                       "l1_ssim_loss_forward")
-        ctx.save_for_backward(a, b, dm1, dm2, dm3)
-        ctx.lam = lam
+            _lib.check(L.mi355gs_l1_ssim_loss_fused(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(scratch),
+                                                    float(lambda_dssim), p0, p0 + 4, _lib.ptr(loss), _lib.ptr(grad)),
+                       "l1_ssim_loss_fused")
+        ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(out)
         return loss, out
 
     @staticmethod
     def backward(ctx, g, _):
-        a, b, dm1, dm2, dm3 = ctx.saved_tensors
-        L = _lib.lib()
-        dev = a.device
-        B, C, H, W = a.shape
-        g = _lib.f32c(g)
-        _lib.require_device(g)
-        grad = torch.empty_like(a)
-        with _lib.on_device(dev):
-            _lib.check(L.mi355gs_l1_ssim_loss_backward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(dm1),
-                                                       _lib.ptr(dm2), _lib.ptr(dm3), _lib.ptr(g), ctx.lam, _lib.ptr(grad)),
-                       "l1_ssim_loss_backward")
-        return grad, None, None
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
 
 
 def fused_l1_ssim_loss(img1, img2, lambda_dssim=0.2):
