@@ -49,8 +49,9 @@ def last_frame_stats():
         raise RuntimeError("keep_last_frame(True) was not set before the forward")
     tiles, W, H = _LAST_FRAME["tiles"], _LAST_FRAME["W"], _LAST_FRAME["H"]
     stats = torch.zeros(2, dtype=torch.int64, device=tiles.device)
-    _lib.check(_lib.lib().mi355gs_raster_frame_stats(_lib.stream_ptr(tiles.device), W, H, _lib.ptr(tiles), _lib.ptr(stats)),
-               "raster_frame_stats")
+    with _lib.on_device(tiles.device):
+        _lib.check(_lib.lib().mi355gs_raster_frame_stats(_lib.stream_ptr(tiles.device), W, H, _lib.ptr(tiles), _lib.ptr(stats)),
+                   "raster_frame_stats")
     r, reff = stats.tolist()
     return int(r), int(reff)
 
@@ -185,13 +186,15 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         if s.debug:
             try:
-                R, binning = run()
+                with _lib.on_device(dev):
+                    R, binning = run()
             except Exception:
                 torch.save(_cpu_deep_copy_tuple((means3D, sh_, col_, opac, sc_, rot_, cov_, tuple(s))), "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            R, binning = run()
+            with _lib.on_device(dev):
+                R, binning = run()
 
         if _KEEP_LAST_FRAME:
             _LAST_FRAME.update(tiles=tiles, W=W, H=H)
@@ -240,13 +243,15 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         if s.debug:
             try:
-                run()
+                with _lib.on_device(dev):
+                    run()
             except Exception:
                 torch.save(_cpu_deep_copy_tuple((means3D, sh_, col_, opac, sc_, rot_, cov_, radii, g, tuple(s))), "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         else:
-            run()
+            with _lib.on_device(dev):
+                run()
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcol if sh_ is None else None, dL_dopac.reshape(ctx.opacity_shape),
                 dL_dscales, dL_drot, dL_dcov, None, dL_dshr)
 
@@ -268,8 +273,9 @@ class GaussianRasterizer(nn.Module):
             pos, view, proj = _lib.f32c(positions), _lib.f32c(s.viewmatrix), _lib.f32c(s.projmatrix)
             dev = _lib.require_device(pos, view, proj)
             present = torch.zeros(pos.shape[0], dtype=torch.uint8, device=dev)
-            _lib.check(_lib.lib().mi355gs_raster_mark_visible(_lib.stream_ptr(dev), pos.shape[0], _lib.ptr(pos), _lib.ptr(view),
-                                                              _lib.ptr(proj), _lib.ptr(present)), "raster_mark_visible")
+            with _lib.on_device(dev):
+                _lib.check(_lib.lib().mi355gs_raster_mark_visible(_lib.stream_ptr(dev), pos.shape[0], _lib.ptr(pos), _lib.ptr(view),
+                                                                  _lib.ptr(proj), _lib.ptr(present)), "raster_mark_visible")
         return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,

@@ -24,9 +24,10 @@ class _PoseActivations(torch.autograd.Function):
         rot_cam = torch.empty_like(rot)
         scales = torch.empty_like(scaling)
         opac = torch.empty_like(opl)
-        _lib.check(L.mi355gs_pose_forward(_lib.stream_ptr(dev), P, _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(scaling), _lib.ptr(opl),
-                                          _lib.ptr(pose), _lib.ptr(means), _lib.ptr(rot_cam), _lib.ptr(scales), _lib.ptr(opac)),
-                   "pose_forward")
+        with _lib.on_device(dev):
+            _lib.check(L.mi355gs_pose_forward(_lib.stream_ptr(dev), P, _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(scaling), _lib.ptr(opl),
+                                              _lib.ptr(pose), _lib.ptr(means), _lib.ptr(rot_cam), _lib.ptr(scales), _lib.ptr(opac)),
+                       "pose_forward")
         ctx.save_for_backward(xyz, rot, scales, opac, pose)
         return means, rot_cam, scales, opac
 
@@ -41,10 +42,11 @@ class _PoseActivations(torch.autograd.Function):
         d_xyz, d_rot, d_scaling, d_opl = torch.empty_like(xyz), torch.empty_like(rot), torch.empty_like(scales), torch.empty_like(opac)
         d_pose = torch.empty(7, dtype=torch.float32, device=dev)
         scratch = torch.empty(32, dtype=torch.float32, device=dev)
-        _lib.check(L.mi355gs_pose_backward(_lib.stream_ptr(dev), P, _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(scales), _lib.ptr(opac),
-                                           _lib.ptr(pose), _lib.ptr(g_means), _lib.ptr(g_rot), _lib.ptr(g_scales), _lib.ptr(g_opac),
-                                           _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(d_scaling), _lib.ptr(d_opl), _lib.ptr(d_pose),
-                                           _lib.ptr(scratch)), "pose_backward")
+        with _lib.on_device(dev):
+            _lib.check(L.mi355gs_pose_backward(_lib.stream_ptr(dev), P, _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(scales), _lib.ptr(opac),
+                                               _lib.ptr(pose), _lib.ptr(g_means), _lib.ptr(g_rot), _lib.ptr(g_scales), _lib.ptr(g_opac),
+                                               _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(d_scaling), _lib.ptr(d_opl), _lib.ptr(d_pose),
+                                               _lib.ptr(scratch)), "pose_backward")
         return d_xyz, d_rot, d_scaling, d_opl, d_pose
 
 

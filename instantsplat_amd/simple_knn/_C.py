@@ -14,5 +14,6 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     out = torch.zeros(n, dtype=torch.float32, device=dev)
     L = _lib.lib()
     scratch = torch.empty(max(int(L.mi355gs_knn_scratch_bytes(n)), 1), dtype=torch.uint8, device=dev)
-    _lib.check(L.mi355gs_knn_dist2(_lib.stream_ptr(dev), n, _lib.ptr(pts), _lib.ptr(out), _lib.ptr(scratch)), "knn_dist2")
+    with _lib.on_device(dev):
+        _lib.check(L.mi355gs_knn_dist2(_lib.stream_ptr(dev), n, _lib.ptr(pts), _lib.ptr(out), _lib.ptr(scratch)), "knn_dist2")
     return out

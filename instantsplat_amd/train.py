@@ -287,12 +287,13 @@ class FusedTrainer:
             steps.append(max(s["step"], 1))
         b1, b2 = grp[0]["betas"]
         F7, I7 = ctypes.c_float * 7, ctypes.c_int32 * 7
-        _lib.check(_lib.lib().mi355gs_trainer_step(
-            ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), int(g.active_sh_degree),
-            _lib.ptr(st.gt_images[cam.uid]),
-            _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(bg),
-            F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"]), float(opt.lambda_dssim),
-            1 if (do_opt and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(self.num_rendered)), "trainer_step")
+        with _lib.on_device(self.dev):
+            _lib.check(_lib.lib().mi355gs_trainer_step(
+                ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), int(g.active_sh_degree),
+                _lib.ptr(st.gt_images[cam.uid]),
+                _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(bg),
+                F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"]), float(opt.lambda_dssim),
+                1 if (do_opt and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(self.num_rendered)), "trainer_step")
         self._pending_opt = (F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"])) if do_opt else None
         if not verify_async:
             return cam
@@ -310,8 +311,9 @@ class FusedTrainer:
     def apply_optimizer(self):
         if self._pending_opt is not None:
             lr, steps, b1, b2, eps = self._pending_opt
-            _lib.check(_lib.lib().mi355gs_trainer_optimizer_step(ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), lr, steps,
-                                                                 b1, b2, eps), "trainer_optimizer_step")
+            with _lib.on_device(self.dev):
+                _lib.check(_lib.lib().mi355gs_trainer_optimizer_step(ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), lr, steps,
+                                                                     b1, b2, eps), "trainer_optimizer_step")
             self._pending_opt = None
 
 
