@@ -124,6 +124,10 @@ int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, in
  * min_units <= 0 only queries.  Process-wide; the default (12288) is what every measurement uses — tests lower it to
  * run the multi-chunk path on small scenes. */
 int mi355gs_tune_min_units(int min_units);
+/* Tuning knob of the persistent forward composite: workgroups launched per CU (0 = the default, enough to hold every tile of a
+ * 512^2 frame at once; fewer = tiles are drawn dynamically by fewer resident workgroups).  Returns the previous value; n < 0
+ * only queries.  Process-wide, measurement only. */
+int mi355gs_tune_fwd_workgroups_per_cu(int n);
 
 /* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that
  * cannot see the kernels (they are enqueued inside this library) can still attribute time to them.

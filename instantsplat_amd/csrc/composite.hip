@@ -520,12 +520,20 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
   return 0;
 }
 
+static int g_fwd_wg_per_cu = 0;   // 0: default residency (gs_grid_persistent)
+extern "C" int mi355gs_tune_fwd_workgroups_per_cu(int n) {
+  const int old = g_fwd_wg_per_cu;
+  if (n >= 0) g_fwd_wg_per_cu = n;
+  return old;
+}
+
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
                             uint32_t* n_contrib, const uint32_t* order, GsSched* sched, const uint32_t* seg_first, uint2* unit_tile,
                             float4* bstate, uint32_t max_units, int level) {
   const int NB = gs_num_cus();
-  hipLaunchKernelGGL(k_composite_fwd, dim3(gs_grid_persistent(T, NB)), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
+  const int grid = g_fwd_wg_per_cu > 0 ? (T < g_fwd_wg_per_cu * NB ? T : g_fwd_wg_per_cu * NB) : gs_grid_persistent(T, NB);
+  hipLaunchKernelGGL(k_composite_fwd, dim3(grid), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
                      recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB, seg_first + (size_t)level * (T + 1), unit_tile, bstate, max_units,
                      (uint32_t)GS_SEG << level);
   return 0;
