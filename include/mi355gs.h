@@ -53,8 +53,8 @@ const char* mi355gs_error_string(int code);
  *   geom    : per-Gaussian records written by preprocess, read by render and backward
  *   tiles   : per-tile counters / offsets; per-pixel final transmittance and contributor counts
  *   binning : per-instance sort keys and the depth-sorted per-tile Gaussian index lists; the backward's work units
- *             (runs of 64, 128, 256 or 512 instances of a tile's list — csrc/common.h GS_SEG, gs_unit_level — chosen from
- *             the capacity passed to the render / backward calls) and the per-pixel state the forward leaves at their boundaries
+ *             (runs of 64, 128, 256 or 512 instances of a tile's list — csrc/common.h GS_SEG, gs_unit_level_for — chosen
+ *             on the device from the frame's instance count; the capacity passed to the render / backward calls bounds it) and the per-pixel state the forward leaves at their boundaries
  * The forward is split in two so the caller can size `binning` exactly (one 4-byte D2H read of
  * *num_rendered between the calls, as the reference operator does internally) or skip the read
  * and pass a capacity bound (no host sync; overflow is reported through *num_rendered > capacity).
@@ -122,7 +122,8 @@ int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, in
 /* Tuning / test knob of the segmented backward (csrc/common.h, GS_MIN_UNITS): a frame's backward units are lengthened
  * (2, 4, 8 chunks of 64 instances) only while at least `min_units` of them remain.  Returns the previous value;
  * min_units <= 0 only queries.  Process-wide; the default (12288) is what every measurement uses — tests lower it to
- * run the multi-chunk path on small scenes. */
+ * run the multi-chunk path on small scenes.  It also enters the buffer-size queries: set it before sizing a frame's buffers
+ * and keep it until that frame's backward has been enqueued. */
 int mi355gs_tune_min_units(int min_units);
 /* Tuning knob of the persistent forward composite: workgroups launched per CU (0 = the default, enough to hold every tile of a
  * 512^2 frame at once; fewer = tiles are drawn dynamically by fewer resident workgroups).  Returns the previous value; n < 0

@@ -15,10 +15,10 @@ int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*,
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t,
                       const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            float*, float*, uint32_t*, const uint32_t*, GsSched*, const uint32_t*, uint2*, float4*, uint32_t, int);
+                            float*, float*, uint32_t*, const uint32_t*, GsSched*, const uint32_t*, uint2*, float4*, uint32_t, const uint32_t*);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint32_t*, const uint2*,
-                            const float4*, const uint32_t*, uint32_t, int, int, unsigned long long*);
+                            const float4*, const uint32_t*, uint32_t, bool, unsigned long long*);
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
 // ---- optional per-kernel timing (HIP events on the launch stream)
@@ -155,7 +155,7 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
     gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
                             (const uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched), (const uint32_t*)(t + tl.seg_first),
-                            (uint2*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, bl.level);
+                            (uint2*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, (const uint32_t*)(t + tl.meta));
   }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;
@@ -197,7 +197,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
       gs_launch_composite_bwd(stream, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                               (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
                               dL_dpix, grads, out_color, (const uint32_t*)(t + tl.seg_first), (const uint2*)(b + bl.unit_tile),
-                              (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, tl.T, bl.level,
+                              (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, bl.may_loop,
                               g_prof.work_counters);
     }
     GS_CHECK_LAUNCH("composite_bwd");

@@ -28,7 +28,7 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ sched_words,
                                                                int n_sched_words, uint32_t* __restrict__ meta,
-                                                               uint32_t* __restrict__ seg_first) {
+                                                               uint32_t* __restrict__ seg_first, uint32_t min_units) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -90,36 +90,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     __syncthreads();
   }
   if (seg_first) {
-    // Backward units (common.h): first unit of every tile = exclusive scan of ceil(count / unit length), for each of the
-    // four unit lengths the host may pick once it knows the frame's instance capacity (same two-level scan as below)
-    __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
-    for (int level = 0; level < GS_UNIT_LEVELS; ++level) {
-      const uint32_t seg_len = (uint32_t)GS_SEG << level;
-      uint32_t* __restrict__ sf = seg_first + (size_t)level * (T + 1);
-      uint32_t lseg = 0;
-      for (int i = lo; i < hi; ++i) lseg += (count[i] + seg_len - 1) / seg_len;
-      uint32_t iseg = lseg;
+    // Backward units (common.h): the unit length of this frame from its true instance count, then the first unit of every tile
+    // = exclusive scan of ceil(count / unit length) (same two-level scan as below)
+    const uint32_t chunks = 1u << gs_unit_level_for((long long)total, (long long)min_units);
+    const uint32_t seg_len = chunks * GS_SEG;
+    uint32_t lseg = 0;
+    for (int i = lo; i < hi; ++i) lseg += (count[i] + seg_len - 1) / seg_len;
+    uint32_t iseg = lseg;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(iseg, d);
-        if (lane >= d) iseg += o;
-      }
-      __syncthreads();   // seg_wave of the previous level has been read
-      if (lane == 63) seg_wave[wave] = iseg;
-      __syncthreads();
-      uint32_t soff = 0, stot = 0;
-#pragma unroll
-      for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w) {
-        if (w < wave) soff += seg_wave[w];
-        stot += seg_wave[w];
-      }
-      uint32_t srun = soff + iseg - lseg;
-      for (int i = lo; i < hi; ++i) {
-        sf[i] = srun;
-        srun += (count[i] + seg_len - 1) / seg_len;
-      }
-      if (tid == 0) { sf[T] = stot; meta[4 + level] = stot; }
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(iseg, d);
+      if (lane >= d) iseg += o;
     }
+    __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
+    if (lane == 63) seg_wave[wave] = iseg;
+    __syncthreads();
+    uint32_t soff = 0, stot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w) {
+      if (w < wave) soff += seg_wave[w];
+      stot += seg_wave[w];
+    }
+    uint32_t srun = soff + iseg - lseg;
+    for (int i = lo; i < hi; ++i) {
+      seg_first[i] = srun;
+      srun += (count[i] + seg_len - 1) / seg_len;
+    }
+    if (tid == 0) { seg_first[T] = stot; meta[1] = stot; meta[2] = chunks; }
   }
   uint32_t run = wave_off + incl - local;
   for (int i = lo; i < hi; ++i) {
@@ -577,16 +574,13 @@ extern "C" int mi355gs_tune_min_units(int min_units) {
   if (min_units > 0) g_min_units = min_units;
   return old;
 }
-int gs_unit_level(int64_t capacity) {
-  int level = 0;
-  while (level + 1 < GS_UNIT_LEVELS && capacity / ((int64_t)(2 * GS_SEG) << level) >= (int64_t)g_min_units) ++level;
-  return level;
-}
+int gs_min_units() { return g_min_units; }
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
                          GsSched* sched, uint32_t* meta, uint32_t* seg_first) {
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order,
-                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4), meta, seg_first);
+                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4), meta, seg_first,
+                     (uint32_t)g_min_units);
   return 0;
 }
 
@@ -595,7 +589,7 @@ int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
-                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr);  // in place
+                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);  // in place
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
 }

@@ -69,8 +69,15 @@ enum { GS_SCHED_FWD = 0, GS_SCHED_COUNT = 1 };
 constexpr int GS_SORT_SMALL_CAP = 2048;  // keys the tile sort's register network takes in one go (binning.hip)
 
 constexpr int GS_UNIT_LEVELS = 4;
+// The rule, shared by the device (k_scan_tiles, from the frame's true instance count) and the host (from the capacity, to
+// pick the kernel instantiation and to size buffers): lengthen the units while at least `min_units` of them remain.
+__host__ __device__ inline int gs_unit_level_for(long long instances, long long min_units) {
+  int level = 0;
+  while (level + 1 < GS_UNIT_LEVELS && instances / ((long long)(2 * 64) << level) >= min_units) ++level;
+  return level;
+}
+int gs_min_units();               // binning.hip: the mi355gs_tune_min_units knob
 constexpr int GS_MIN_UNITS = 12288;  // lengthen units only while at least this many remain (~2 per resident wave slot)
-int gs_unit_level(int64_t capacity);  // binning.hip (reads the mi355gs_tune_min_units knob)
 
 struct TilesLayout {
   size_t count, start, cursor, final_T, n_contrib, order, seg_first, sched, meta, total;
@@ -84,9 +91,9 @@ struct TilesLayout {
     final_T = o; o += gs_align(npix * 4);
     n_contrib = o; o += gs_align(npix * 4);
     order = o; o += gs_align((size_t)T * 4);
-    seg_first = o; o += gs_align(GS_UNIT_LEVELS * ((size_t)T + 1) * 4);  // per level: prefix over tiles of ceil(count / (GS_SEG << level))
+    seg_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of ceil(count / unit length): first unit of a tile
     sched = o; o += gs_align(GS_SCHED_COUNT * sizeof(GsSched));
-    meta = o; o += gs_align(32);   // [4 + level]: number of backward units of the frame at that unit length
+    meta = o; o += gs_align(16);   // [1]: number of backward units of the frame, [2]: chunks of GS_SEG instances per unit
     total = o;
   }
 };
@@ -96,23 +103,29 @@ struct TilesLayout {
 // segments independently: thousands of equal-sized workgroups that the hardware balances, instead of one workgroup per
 // tile that lasts as long as the tile is deep (composite.hip).
 constexpr int GS_SEG = 64;
-// A unit covers 1, 2, 4 or 8 consecutive 64-instance chunks ("level" 0..3), chosen per frame on the HOST from the instance
-// capacity the caller passes to the render / backward calls (gs_unit_level): boundaries — and with them the 16 B/pixel
-// boundary records and the 32 B/pixel of per-pixel state a unit loads — are only needed every (64 << level) instances.  At C3
-// (0.7 M instances) that is one chunk; at C4 (7.3 M) eight: the boundary buffer shrinks from 700 MB to under 90 MB.
-// k_scan_tiles leaves the per-tile unit prefix for all four levels (it runs before the capacity is known).
+// A unit covers 1, 2, 4 or 8 consecutive 64-instance chunks ("level" 0..3), chosen per frame by k_scan_tiles from the frame's
+// true instance count and left in meta[2]: boundaries — and with them the 16 B/pixel boundary records and the 32 B/pixel of
+// per-pixel state a unit loads — are only needed every (64 << level) instances.  At C3 (0.75 M instances) that is one chunk; at
+// C4 (7.3 M) eight: the boundary state touched per frame falls from 700 MB to under 90 MB.  The host only needs to know whether
+// the looping instantiation of the backward can be required (level of the CAPACITY > 0; count <= capacity) and an upper bound
+// on the number of units for the buffers.
 
 struct BinningLayout {
   size_t keys, list, unit_tile, bstate, total;
-  uint32_t max_units;  // table / boundary slots available: ceil(R / unit length) + T
-  int level;           // unit length of a frame with this capacity: GS_SEG << level instances
+  uint32_t max_units;  // table / boundary slots available: an upper bound on the units of any frame with <= R instances
+  bool may_loop;       // a frame with this capacity can have units longer than one chunk
   __host__ BinningLayout(int64_t R, int T) {
     size_t n = R > 0 ? (size_t)R : 1, o = 0;
     keys = o; o += gs_align(n * 8);
     list = o; o += gs_align(n * 4);
-    level = gs_unit_level(R);
-    const size_t unit_len = (size_t)GS_SEG << level;
-    max_units = (uint32_t)((n + unit_len - 1) / unit_len + (size_t)(T > 0 ? T : 1));
+    // A frame with c <= R instances runs at level L(c) <= L(R) and has at most c / (64 << L(c)) + T units (one partial unit per
+    // tile).  While L(c) is below the top level the rule stopped lengthening, so c / (64 << L(c)) < 2 * min_units; at the top
+    // level it is at most R / (64 << top).  Small capacities never exceed ceil(R / 64).
+    const size_t mu = (size_t)gs_min_units(), top = (size_t)GS_SEG << (GS_UNIT_LEVELS - 1);
+    const size_t by_chunks = (n + GS_SEG - 1) / GS_SEG, by_rule = 2 * mu + 1, by_top = (n + top - 1) / top;
+    const size_t lim = by_chunks < by_rule ? by_chunks : by_rule;
+    may_loop = gs_unit_level_for((long long)n, (long long)mu) > 0;
+    max_units = (uint32_t)((lim > by_top ? lim : by_top) + (size_t)(T > 0 ? T : 1));
     unit_tile = o; o += gs_align((size_t)max_units * 8);  // uint2 per unit: (tile x | tile y << 16, segment)
     bstate = o; o += gs_align((size_t)max_units * 256 * sizeof(float4));  // per boundary: 256 pixels x (T, C0, C1, C2)
     total = o;

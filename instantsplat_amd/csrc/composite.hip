@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
                                                         uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order,
                                                         GsSched* sched, int NB, const uint32_t* __restrict__ seg_first,
                                                         uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units,
-                                                        uint32_t seg_len) {
+                                                        const uint32_t* __restrict__ meta) {
+  const uint32_t seg_len = meta[2] * GS_SEG;  // instances per backward unit of this frame (k_scan_tiles)
   GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
                           composite_fwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T, n_contrib,
                                              seg_first, unit_tile, bstate, max_units, seg_len))
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int
 //    round 1 paid the reduction (and nine atomics) for every one of them.
 constexpr int BW_UNITS = 4;  // units (waves) per workgroup
 
-// CHUNKS: 64-instance chunks per unit (1, or 0 = the run-time value `chunks` for the longer units of big frames; the
+// CHUNKS: 64-instance chunks per unit (1, or 0 = the frame's own value from meta[2] for the longer units of big frames; the
 // one-chunk instantiation keeps 74 VGPRs / six waves per SIMD, the loop over chunks costs 15 more)
 // COUNT: the measurement instantiation (mi355gs_profile_work_counters): the same kernel also adds up, per wave, how many
 // (Gaussian, tile) steps it ran, how many quadrant bodies, and how many lanes of those bodies were valid pixels — the inputs
@@ -291,20 +292,20 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
                                                         const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
                                                         const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
                                                         const uint2* __restrict__ unit_tile, const float4* __restrict__ bstate,
-                                                        const uint32_t* __restrict__ n_units, uint32_t max_units, uint32_t chunks_rt,
+                                                        const uint32_t* __restrict__ meta, uint32_t max_units,
                                                         unsigned long long* __restrict__ counters) {
   __shared__ float4 s_q0[BW_UNITS][GS_SEG];
   __shared__ float4 s_q1[BW_UNITS][GS_SEG];
   __shared__ float4 s_q2[BW_UNITS][GS_SEG];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t unit = blockIdx.x * (uint32_t)BW_UNITS + (uint32_t)wave;
-  if (unit >= min(n_units[0], max_units)) return;  // wave-uniform; no workgroup barrier below
+  if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
   const uint2 entry = unit_tile[unit];
   const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
   const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
   const int tile = ty * gx + tx;
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  const uint32_t chunks = CHUNKS ? (uint32_t)CHUNKS : chunks_rt, seg_len = chunks * GS_SEG;   // instances per unit
+  const uint32_t chunks = CHUNKS ? (uint32_t)CHUNKS : meta[2], seg_len = chunks * GS_SEG;   // instances per unit
   const uint32_t boff = seg * seg_len;  // contributor index (0-based) of this unit's first instance
   if (end <= start + boff) return;
   float4* __restrict__ q0s = s_q0[wave];
@@ -530,12 +531,11 @@ extern "C" int mi355gs_tune_fwd_workgroups_per_cu(int n) {
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
                             uint32_t* n_contrib, const uint32_t* order, GsSched* sched, const uint32_t* seg_first, uint2* unit_tile,
-                            float4* bstate, uint32_t max_units, int level) {
+                            float4* bstate, uint32_t max_units, const uint32_t* meta) {
   const int NB = gs_num_cus();
   const int grid = g_fwd_wg_per_cu > 0 ? (T < g_fwd_wg_per_cu * NB ? T : g_fwd_wg_per_cu * NB) : gs_grid_persistent(T, NB);
   hipLaunchKernelGGL(k_composite_fwd, dim3(grid), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
-                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB, seg_first + (size_t)level * (T + 1), unit_tile, bstate, max_units,
-                     (uint32_t)GS_SEG << level);
+                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB, seg_first, unit_tile, bstate, max_units, meta);
   return 0;
 }
 
@@ -545,14 +545,14 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint32_t* seg_first, const uint2* unit_tile, const float4* bstate, const uint32_t* meta,
-                            uint32_t max_units, int T, int level, unsigned long long* counters) {
+                            uint32_t max_units, bool may_loop, unsigned long long* counters) {
   const dim3 grid((max_units + BW_UNITS - 1) / BW_UNITS);
-  const uint32_t* sf = seg_first + (size_t)level * (T + 1);
+  // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
 #define GS_BWD(CH, CNT)                                                                                                               \
   hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
-                     n_contrib, dL_dpix, grads, out_color, sf, unit_tile, bstate, meta + 4 + level, max_units, 1u << level, counters)
-  if (counters) { if (level == 0) GS_BWD(1, true); else GS_BWD(0, true); }
-  else { if (level == 0) GS_BWD(1, false); else GS_BWD(0, false); }
+                     n_contrib, dL_dpix, grads, out_color, seg_first, unit_tile, bstate, meta, max_units, counters)
+  if (counters) { if (!may_loop) GS_BWD(1, true); else GS_BWD(0, true); }
+  else { if (!may_loop) GS_BWD(1, false); else GS_BWD(0, false); }
 #undef GS_BWD
   return 0;
 }
