@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t unit = blockIdx.x * (uint32_t)BW_UNITS + (uint32_t)wave;
   if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
+  [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
+  [[maybe_unused]] unsigned long long pr_steps = 0, pr_t1 = 0;
   const uint2 entry = unit_tile[unit];
   const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
   const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
@@ -411,6 +413,9 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
       }
     }
     if constexpr (COUNT) { c_steps += 1; c_reduced += any_valid ? 1 : 0; }
+#ifdef GS_PROBE
+    pr_steps += 1;
+#endif
     if (any_valid) {
       // Nine values x 64 lanes -> nine sums, transposed so that every step halves the number of live values:
       // rows first (v_permlane16/32_swap pair steps, two ops per pair), then lane bits 0 and 1 inside the row (DPP
@@ -432,6 +437,9 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
     }
   };
 
+#ifdef GS_PROBE
+  pr_t1 = GS_PROBE_CLOCK();
+#endif
   // ---- the unit's chunks of GS_SEG instances, deepest first
 #pragma unroll 1
   for (int c = (int)chunks - 1; c >= 0; --c) {
@@ -486,6 +494,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
       if (!moreA) break;
     }
   }
+  GS_PROBE_STORE(4096u + unit, pr_t0, GS_PROBE_CLOCK(), pr_steps, pr_t1 - pr_t0, (unsigned long long)tile, (unsigned long long)seg,
+                 (unsigned long long)gs_physical_cu(), (unsigned long long)blockIdx.x);
   if constexpr (COUNT) {
     if (lane == 0 && counters) {
       atomicAdd(counters + 0, c_steps); atomicAdd(counters + 1, c_quads); atomicAdd(counters + 2, c_quads_valid);

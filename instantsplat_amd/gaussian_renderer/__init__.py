@@ -65,23 +65,26 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     projmatrix = viewpoint_camera.projection_matrix  # identity @ projection
     if projmatrix.device != dev:
         projmatrix = projmatrix.to(dev)
-    rasterizer = GaussianRasterizer(raster_settings=GaussianRasterizationSettings(
+    settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
         scale_modifier=scaling_modifier, viewmatrix=view_identity, projmatrix=projmatrix, sh_degree=pc.active_sh_degree,
-        campos=origin, prefiltered=False, debug=pipe.debug))
+        campos=origin, prefiltered=False, debug=pipe.debug)
 
     default_pipeline = override_color is None and not (pipe.compute_cov3D_python or pipe.convert_SHs_python)
     if FUSED_GLUE == "posed" and default_pipeline and pc.max_sh_degree == 3:
         # the whole differentiable body as one autograd node: the projection kernels take the raw parameters + the pose
-        image, radii = render_posed(pc, camera_pose, screenspace_points, rasterizer.raster_settings)
+        # (no GaussianRasterizer module is instantiated on this path: constructing an nn.Module costs ~10 us per call)
+        image, radii = render_posed(pc, camera_pose, screenspace_points, settings)
     elif FUSED_GLUE and default_pipeline:
         # one HIP launch each way for the pose transform + activations (and the pose-gradient reduction)
         means3D, rot_cam, scales_act, opacity = pose_activations(pc._xyz, pc._rotation, pc._scaling, pc._opacity, camera_pose)
         shs_dc, shs_rest = sh_features(pc)
-        image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs_dc, opacities=opacity, scales=scales_act,
-                                  rotations=rot_cam, shs_rest=shs_rest)
+        image, radii = GaussianRasterizer(raster_settings=settings)(
+            means3D=means3D, means2D=screenspace_points, shs=shs_dc, opacities=opacity, scales=scales_act, rotations=rot_cam,
+            shs_rest=shs_rest)
     else:
-        image, radii = rasterizer(means2D=screenspace_points,
-                                  **_operator_inputs(viewpoint_camera, pc, pipe, camera_pose, scaling_modifier, override_color, dev))
+        image, radii = GaussianRasterizer(raster_settings=settings)(
+            means2D=screenspace_points,
+            **_operator_inputs(viewpoint_camera, pc, pipe, camera_pose, scaling_modifier, override_color, dev))
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
