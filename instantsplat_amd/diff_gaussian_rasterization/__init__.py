@@ -144,6 +144,23 @@ def _empty_bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
 
 
+_SIZES = {}
+
+
+def frame_buffers(L, P, W, H, dev):
+    """Per-frame outputs and workspaces of the forward: (radii, color, geom, tiles, num_rendered).  None is pre-filled: the
+    projection kernel writes every radius (0 for a culled Gaussian) and the tile scan writes the instance count, so the two
+    memset launches of `torch.zeros` per frame are not needed; the workspace sizes are asked of the library once per shape."""
+    key = (P, W, H)
+    sizes = _SIZES.get(key)
+    if sizes is None:
+        sizes = _SIZES[key] = (max(int(L.mi355gs_raster_geom_bytes(P)), 1), max(int(L.mi355gs_raster_tiles_bytes(W, H)), 1))
+    i32, u8 = torch.int32, torch.uint8
+    return (torch.empty(P, dtype=i32, device=dev), torch.empty(3, H, W, dtype=torch.float32, device=dev),
+            torch.empty(sizes[0], dtype=u8, device=dev), torch.empty(sizes[1], dtype=u8, device=dev),
+            torch.empty(1, dtype=i32, device=dev))
+
+
 def _cpu_deep_copy_tuple(input_tuple):
     return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
 
@@ -170,11 +187,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         stream = _lib.stream_ptr(dev)
         debug = 1 if s.debug else 0
 
-        radii = torch.zeros(P, dtype=torch.int32, device=dev)
-        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        geom = _empty_bytes(L.mi355gs_raster_geom_bytes(P), dev)
-        tiles = _empty_bytes(L.mi355gs_raster_tiles_bytes(W, H), dev)
-        num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
+        radii, color, geom, tiles, num_rendered = frame_buffers(L, P, W, H, dev)
 
         def run():
             _lib.check(L.mi355gs_raster_forward_preprocess(

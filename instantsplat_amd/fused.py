@@ -11,6 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from . import diff_gaussian_rasterization as dgr
 
 
 class _PoseActivations(torch.autograd.Function):
@@ -81,8 +82,6 @@ class _RenderPosed(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, rot, scaling, opacity_logit, f_dc, f_rest, pose, means2D, settings):
-        from . import diff_gaussian_rasterization as dgr
-        from .diff_gaussian_rasterization import _empty_bytes, size_and_render
         s = settings
         L = _lib.lib()
         xyz, rot, scaling, opl, f_dc, f_rest, pose = map(_lib.f32c, (xyz, rot, scaling, opacity_logit, f_dc, f_rest, pose))
@@ -91,18 +90,14 @@ class _RenderPosed(torch.autograd.Function):
         P, D = xyz.shape[0], int(s.sh_degree)
         H, W = int(s.image_height), int(s.image_width)
         stream, debug = _lib.stream_ptr(dev), (1 if s.debug else 0)
-        radii = torch.zeros(P, dtype=torch.int32, device=dev)
-        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        geom = _empty_bytes(L.mi355gs_raster_geom_bytes(P), dev)
-        tiles = _empty_bytes(L.mi355gs_raster_tiles_bytes(W, H), dev)
-        num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
+        radii, color, geom, tiles, num_rendered = dgr.frame_buffers(L, P, W, H, dev)
         with _lib.on_device(dev):
             _lib.check(L.mi355gs_posed_forward_preprocess(
                 stream, P, D, W, H, _lib.ptr(xyz), _lib.ptr(f_dc), _lib.ptr(f_rest), _lib.ptr(opl), _lib.ptr(scaling),
                 float(s.scale_modifier), _lib.ptr(rot), _lib.ptr(pose), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(origin),
                 float(s.tanfovx), float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(num_rendered), debug),
                 "posed_forward_preprocess")
-            R, binning = size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug)
+            R, binning = dgr.size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug)
         if dgr._KEEP_LAST_FRAME:
             dgr._LAST_FRAME.update(tiles=tiles, W=W, H=H)
         ctx.settings, ctx.capacity, ctx.dims = s, R, (P, D, W, H)
@@ -112,7 +107,6 @@ class _RenderPosed(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, _grad_radii):
-        from .diff_gaussian_rasterization import _empty_bytes
         s, L = ctx.settings, _lib.lib()
         P, D, W, H = ctx.dims
         xyz, rot, scaling, opl, f_dc, f_rest, pose, radii, geom, tiles, binning, bg, view, proj, origin, color = ctx.saved_tensors
@@ -125,7 +119,7 @@ class _RenderPosed(torch.autograd.Function):
         # PerPointAdam's zero-gradient step on it, as in the reference)
         d_frest = torch.zeros_like(f_rest) if D == 0 else new(f_rest)
         d_pose = torch.empty(7, dtype=torch.float32, device=dev)
-        scratch = _empty_bytes(L.mi355gs_raster_grad_scratch_bytes(P), dev)
+        scratch = dgr._empty_bytes(L.mi355gs_raster_grad_scratch_bytes(P), dev)
         pose_scratch = torch.empty(16 * ((P + 255) // 256) + 32, dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             _lib.check(L.mi355gs_posed_backward(

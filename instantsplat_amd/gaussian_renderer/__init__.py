@@ -26,6 +26,19 @@ def _identity_view(dev):
     return _IDENTITY[dev]
 
 
+_ZEROS = {}
+
+
+def _zero_leaf(like):
+    key = (tuple(like.shape), like.device, like.dtype)
+    base = _ZEROS.get(key)
+    if base is None:
+        if len(_ZEROS) > 16:
+            _ZEROS.clear()
+        base = _ZEROS[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    return base.detach().requires_grad_(True)
+
+
 # "posed" (default): one autograd node for the whole render body (fused.render_posed); True: the round-1 fused glue (pose /
 # activation kernel + SH view + operator, three nodes); False: the op-by-op PyTorch glue below.  The latter two are kept
 # for A/B tests: all three must give the same image and gradients.
@@ -55,11 +68,13 @@ def _operator_inputs(viewpoint_camera, pc, pipe, camera_pose, scaling_modifier, 
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, camera_pose=None):
-    dev = pc.get_xyz.device
+    xyz = pc.get_xyz
+    dev = xyz.device
     # zero tensor whose .grad receives the screen-space mean gradients (the reference's `viewspace_points`, :39-48).  The
     # reference makes it a non-leaf (`zeros + 0`) and asks autograd to retain its gradient; a leaf gets the same .grad
-    # without the extra elementwise kernel and the two autograd nodes.
-    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    # without the extra elementwise kernel and the two autograd nodes.  Its VALUE is never read by the operator, so every
+    # call hands out a fresh leaf over one shared all-zero buffer per (shape, device) instead of filling a new one.
+    screenspace_points = _zero_leaf(xyz)
 
     view_identity, origin = _identity_view(dev)      # reference :55-59: identity view matrix, camera at the origin
     projmatrix = viewpoint_camera.projection_matrix  # identity @ projection

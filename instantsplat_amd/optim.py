@@ -15,6 +15,8 @@ import math
 
 import torch
 from torch.optim import Optimizer
+from torch.optim.optimizer import _global_optimizer_post_hooks as _global_post_hooks
+from torch.optim.optimizer import _global_optimizer_pre_hooks as _global_pre_hooks
 
 from . import _lib
 
@@ -59,17 +61,31 @@ class PerPointAdam(Optimizer):
     @staticmethod
     def _group_sig(group):
         pp = group.get("per_point_lr")
-        return (group["betas"], group["eps"], None if pp is None else pp.data_ptr())
+        return (group["betas"], group["eps"], pp, None if pp is None else pp.data_ptr())
+
+    @staticmethod
+    def _same_sig(a, b):
+        return a[0] == b[0] and a[1] == b[1] and a[2] is b[2] and a[3] == b[3]
+
+    def load_state_dict(self, state_dict):
+        self._plans = {}   # the moments are new tensors
+        return super().load_state_dict(state_dict)
 
     def _plan_for(self, live):
         """Everything about a step that does not change from one iteration to the next — which tensors take part, their
         sizes, the addresses of parameters / moments / per-point multipliers, the (betas, eps) batches — as ready-made ctypes
-        arrays, keyed by the identity of the participating parameters and checked against their current addresses."""
-        key = tuple(id(p) for _, p in live)
-        plan = self._plans.get(key) if hasattr(self, "_plans") else None
-        if plan is not None and all(p.data_ptr() == a and self.state[p]["exp_avg"].data_ptr() == b and self._group_sig(g) == sig
-                                    for (p, a, b, g, sig) in plan["check"]):
-            return plan
+        arrays, keyed by the identity of the participating parameters and checked against their current addresses, moment
+        tensors and group settings."""
+        key = tuple([id(p) for _, p in live])
+        plans = self.__dict__.get("_plans")
+        plan = plans.get(key) if plans is not None else None
+        if plan is not None:
+            state_of, same = self.state, self._same_sig
+            for (g, p), (a, m, sig) in zip(live, plan["check"]):
+                if p.data_ptr() != a or state_of[p]["exp_avg"] is not m or not same(self._group_sig(g), sig):
+                    break
+            else:
+                return plan
         if not hasattr(self, "_plans"):
             self._plans = {}
         items = []
@@ -103,16 +119,45 @@ class PerPointAdam(Optimizer):
                 p=PTR(*[it[1].data_ptr() for it in batch]), m=PTR(*[s_["exp_avg"].data_ptr() for s_ in st]),
                 v=PTR(*[s_["exp_avg_sq"].data_ptr() for s_ in st]), pplr=PTR(*[(0 if it[2] is None else it[2].data_ptr()) for it in batch]),
                 keep=[it[2] for it in batch], PTR=PTR, F32=ctypes.c_float * n, I32=I32))
-        plan = dict(batches=batches, check=[(p, p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), g, self._group_sig(g)) for g, p in live])
+        plan = dict(batches=batches, check=[(p.data_ptr(), self.state[p]["exp_avg"], self._group_sig(g)) for g, p in live])
         self._plans[key] = plan
         return plan
 
-    @torch.no_grad()
     def step(self, closure=None):
         """All parameter tensors in two launches (mi355gs_adam_multi_step): per-tensor sum of squared gradients
-        for the whole-tensor gate, then the fused update."""
-        loss = closure() if closure is not None else None
-        L = _lib.lib()
+        for the whole-tensor gate, then the fused update.
+
+        torch.optim.Optimizer would wrap this method in its profiler scope + hook dispatcher (~20 us of host time per call, as
+        much as the rest of the step); the method is marked `hooked` so the base class leaves it alone, and does both itself
+        — only when a profiler is running or a hook is registered."""
+        if _global_pre_hooks or _global_post_hooks or self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks \
+                or torch.autograd._profiler_enabled():
+            return self._step_with_hooks(closure)
+        return self._step(closure)
+
+    step.hooked = True   # see torch.optim.Optimizer._patch_step_function
+
+    def _step_with_hooks(self, closure):
+        args, kwargs = (self, closure), {}
+        with torch.autograd.profiler.record_function(f"Optimizer.step#{self.__class__.__name__}.step"):
+            for hook in (*_global_pre_hooks.values(), *self._optimizer_step_pre_hooks.values()):
+                result = hook(self, args, kwargs)
+                if result is not None:
+                    if not (isinstance(result, tuple) and len(result) == 2):
+                        raise RuntimeError(f"{hook} must return None or a tuple of (new_args, new_kwargs), but got {result}.")
+                    args, kwargs = result
+            out = self._step(*args[1:], **kwargs)
+            self._optimizer_step_code()
+            for hook in (*self._optimizer_step_post_hooks.values(), *_global_post_hooks.values()):
+                hook(self, args, kwargs)
+            return out
+
+    def _step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        state_of = self.state
         live = []
         for group in self.param_groups:
             for p in group["params"]:
@@ -121,33 +166,38 @@ class PerPointAdam(Optimizer):
                     continue
                 if grad.is_sparse:
                     raise RuntimeError("PerPointAdam does not support sparse gradients")
-                state = self.state[p]
+                state = state_of[p]
                 if len(state) == 0:
                     state["step"] = 0
-                    state["exp_avg"] = torch.zeros_like(p)
-                    state["exp_avg_sq"] = torch.zeros_like(p)
+                    with torch.no_grad():
+                        state["exp_avg"] = torch.zeros_like(p)
+                        state["exp_avg_sq"] = torch.zeros_like(p)
                 state["step"] += 1
                 live.append((group, p))
         if not live:
             return loss
+        L = _lib.lib()
         f32 = torch.float32
         for b in self._plan_for(live)["batches"]:
-            grads = []
+            dev = b["dev"]
+            ptrs = []
+            keep = []
             for group, p in zip(b["groups"], b["params"]):
                 g = p.grad
                 if group["weight_decay"] != 0:
-                    g = g.add(p, alpha=group["weight_decay"])
+                    with torch.no_grad():
+                        g = g.add(p, alpha=group["weight_decay"])
                 if g.dtype is not f32 or not g.is_contiguous():
                     g = _lib.f32c(g)
-                if g.device != b["dev"]:
-                    raise RuntimeError(f"tensors on different devices: {b['dev']} vs {g.device}")
-                grads.append(g)
-            dev = b["dev"]
+                if g.device != dev:
+                    raise RuntimeError(f"tensors on different devices: {dev} vs {g.device}")
+                keep.append(g)
+                ptrs.append(g.data_ptr())
             scratch = torch.empty(8, dtype=f32, device=dev)
             b1, b2, eps = b["hyper"]
             with _lib.on_device(dev):
                 _lib.check(L.mi355gs_adam_multi_step(
-                    _lib.stream_ptr(dev), b["n"], b["numel"], b["row"], b["p"], b["PTR"](*[g.data_ptr() for g in grads]), b["m"], b["v"],
-                    b["pplr"], b["F32"](*[float(group["lr"]) for group in b["groups"]]), b1, b2, eps,
-                    b["I32"](*[s_["step"] for s_ in b["states"]]), _lib.ptr(scratch)), "adam_multi_step")
+                    _lib.stream_ptr(dev), b["n"], b["numel"], b["row"], b["p"], b["PTR"](*ptrs), b["m"], b["v"],
+                    b["pplr"], b["F32"](*[group["lr"] for group in b["groups"]]), b1, b2, eps,
+                    b["I32"](*[s_["step"] for s_ in b["states"]]), scratch.data_ptr()), "adam_multi_step")
         return loss

@@ -76,6 +76,43 @@ def test_adam_matches_reference_trajectory(emu):
     ops_util.check_adam_golden(emu)
 
 
+def test_adam_step_keeps_the_optimizer_contract(emu):
+    """PerPointAdam.step opts out of torch.optim.Optimizer's per-call wrapper (profiler scope + hook dispatch); step hooks, the
+    profiler scope, closures and load_state_dict must behave as for any torch optimizer, with the same update either way."""
+    from instantsplat_amd.optim import PerPointAdam
+
+    def fresh():
+        torch.manual_seed(0)
+        p = torch.nn.Parameter(torch.randn(5, 3))
+        p.grad = torch.randn(5, 3)
+        return p, PerPointAdam([{"params": [p], "lr": 1e-2, "name": "x"}], lr=0.0, eps=1e-15)
+
+    p0, o0 = fresh()
+    assert getattr(PerPointAdam.step, "hooked", False) and not hasattr(PerPointAdam.step, "__wrapped__")
+    o0.step()
+    p1, o1 = fresh()
+    calls = []
+    h1 = o1.register_step_pre_hook(lambda opt, args, kwargs: calls.append("pre"))
+    h2 = o1.register_step_post_hook(lambda opt, args, kwargs: calls.append("post"))
+    assert o1.step(lambda: torch.tensor(3.0)) == 3.0 and calls == ["pre", "post"]
+    assert torch.equal(p0.detach(), p1.detach())
+    h1.remove(); h2.remove()
+    with torch.profiler.profile() as prof:
+        o1.step()
+    assert any("Optimizer.step#PerPointAdam.step" in e.key for e in prof.key_averages())
+    o0.step()
+    assert torch.equal(p0.detach(), p1.detach()) and calls == ["pre", "post"]
+    # moments replaced by load_state_dict are the ones the next step uses
+    sd = o1.state_dict()
+    sd["state"][0]["exp_avg"] = torch.ones(5, 3)
+    o1.load_state_dict(sd)
+    before = p1.detach().clone()
+    p1.grad = torch.zeros(5, 3) + 1e-3
+    o1.step()
+    m = o1.state[p1]["exp_avg"]
+    assert torch.allclose(m, torch.full((5, 3), 0.9 + 0.1 * 1e-3)) and not torch.equal(before, p1.detach())
+
+
 def test_two_train_iterations_match_cpu_oracle(emu):
     ops_util.check_train_matches_cpu_oracle(emu, iters=2)
 
