@@ -302,14 +302,24 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
   if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
   [[maybe_unused]] unsigned long long pr_steps = 0, pr_t1 = 0;
+  // Everything the prologue needs is requested in TWO rounds of loads instead of five dependent ones (placement -> tile range
+  // -> pixel state -> wave maxima / branch -> boundary record): a unit's boundary record lives at its own index (the forward
+  // publishes unit_tile[seg_first[tile] + segment]), so it is requested together with the placement, before the unit knows
+  // whether it will need it (the deepest unit of a tile does not: 1 in ~11 at C3); the pixel state — including the frame's
+  // colour, used only with the record — follows as soon as the tile is known, from clamped addresses so that no load sits
+  // in a branch.  GS_PIN4 (an empty asm that "uses" the values) keeps the compiler from sinking the loads below the early
+  // exits; it comes after the last load has been issued, where the first consumer would wait anyway.
+#define GS_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
   const uint2 entry = unit_tile[unit];
+  float4 brec[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) brec[qd] = bstate[(size_t)unit * 256 + qd * 64 + lane];
   const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
   const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
   const int tile = ty * gx + tx;
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t chunks = CHUNKS ? (uint32_t)CHUNKS : meta[2], seg_len = chunks * GS_SEG;   // instances per unit
   const uint32_t boff = seg * seg_len;  // contributor index (0-based) of this unit's first instance
-  if (end <= start + boff) return;
   float4* __restrict__ q0s = s_q0[wave];
   float4* __restrict__ q1s = s_q1[wave];
   float4* __restrict__ q2s = s_q2[wave];
@@ -320,39 +330,40 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uin
   const size_t plane = (size_t)W * H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   float Tr[4], behind[4], g0[4], g1[4], g2[4];
+  float oc0[4], oc1[4], oc2[4];   // the frame's colour at the pixel
   int lastq[4];        // the pixel's last contributor (1-based position in the tile list; 0: none)
   uint32_t wmaxq[4];   // wave-wide max of `last` per quadrant
-  size_t pixq[4];
-  bool insideq[4];
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const int px = px0 + (qd & 1) * 8, py = py0 + (qd >> 1) * 8;
-    insideq[qd] = px < W && py < H;
-    pixq[qd] = (size_t)py * W + px;
-    const float T_final = insideq[qd] ? final_T[pixq[qd]] : 0.f;
-    const uint32_t last = insideq[qd] ? n_contrib[pixq[qd]] : 0u;
-    g0[qd] = g1[qd] = g2[qd] = 0.f;
-    if (insideq[qd]) { g0[qd] = dL_dpix[pixq[qd]]; g1[qd] = dL_dpix[plane + pixq[qd]]; g2[qd] = dL_dpix[2 * plane + pixq[qd]]; }
-    Tr[qd] = T_final;
-    behind[qd] = T_final * (bg0 * g0[qd] + bg1 * g1[qd] + bg2 * g2[qd]);  // dL/dC . (everything behind, background included)
-    lastq[qd] = (int)last;
-    wmaxq[qd] = __builtin_amdgcn_readfirstlane(gs_wave_max_u32(last));   // wave-uniform: keep it in an SGPR
+    const size_t pix = (size_t)min(py, H - 1) * W + min(px, W - 1);
+    Tr[qd] = final_T[pix]; lastq[qd] = (int)n_contrib[pix];
+    g0[qd] = dL_dpix[pix]; g1[qd] = dL_dpix[plane + pix]; g2[qd] = dL_dpix[2 * plane + pix];
+    oc0[qd] = out_color[pix]; oc1[qd] = out_color[plane + pix]; oc2[qd] = out_color[2 * plane + pix];
+  }
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    GS_PIN4(brec[qd].x, brec[qd].y, brec[qd].z, brec[qd].w);
+    GS_PIN4(oc0[qd], oc1[qd], oc2[qd], Tr[qd]);
+    const int px = px0 + (qd & 1) * 8, py = py0 + (qd >> 1) * 8;
+    if (!(px < W && py < H)) { Tr[qd] = 0.f; lastq[qd] = 0; g0[qd] = g1[qd] = g2[qd] = 0.f; }   // outside the image
+  }
+#undef GS_PIN4
+  if (end <= start + boff) return;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    behind[qd] = Tr[qd] * (bg0 * g0[qd] + bg1 * g1[qd] + bg2 * g2[qd]);  // dL/dC . (everything behind, background included)
+    wmaxq[qd] = __builtin_amdgcn_readfirstlane(gs_wave_max_u32((uint32_t)lastq[qd]));   // wave-uniform: keep it in an SGPR
   }
   // the tile only needs instances [0, max over pixels of last)
   const uint32_t tile_max = min(max(max(wmaxq[0], wmaxq[1]), max(wmaxq[2], wmaxq[3])), end - start);
   if (tile_max <= boff) return;  // every pixel's last contributor lies in front of this segment
   if (boff + seg_len < tile_max) {
     // not the deepest active unit of the tile: resume from the forward's record at this unit's far boundary
-    const uint32_t slot = seg_first[tile] + seg;
-    if (slot < max_units) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const float4 b = bstate[(size_t)slot * 256 + qd * 64 + lane];
-        Tr[qd] = b.x;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        if (insideq[qd]) { c0 = out_color[pixq[qd]]; c1 = out_color[plane + pixq[qd]]; c2 = out_color[2 * plane + pixq[qd]]; }
-        behind[qd] = (c0 - b.y) * g0[qd] + (c1 - b.z) * g1[qd] + (c2 - b.w) * g2[qd];
-      }
+    for (int qd = 0; qd < 4; ++qd) {
+      Tr[qd] = brec[qd].x;
+      behind[qd] = (oc0[qd] - brec[qd].y) * g0[qd] + (oc1[qd] - brec[qd].z) * g1[qd] + (oc2[qd] - brec[qd].w) * g2[qd];
     }
   }
 
