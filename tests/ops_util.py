@@ -97,6 +97,19 @@ def check_knn(dev, n, seed=0, duplicates=False):
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-9), float((out - ref).abs().max())  # stated tolerance: rel 1e-5
 
 
+def check_knn_pointmap(dev, V, Wm):
+    """distCUDA2 on the point clouds the BASELINE configs start from (C3: 3 x 256^2 = 196,608 points; C4: 12 x 288^2 = 995,328):
+    back-projected depth maps — locally grid-like, overlapping views, strongly anisotropic density — against the float64 k-d tree."""
+    from instantsplat_amd.simple_knn._C import distCUDA2
+    from instantsplat_amd.synthetic import syn_pointmap
+    pts = syn_pointmap(V, Wm, Wm, 64, 64, seed=0).points.float()
+    assert pts.shape == (V * Wm * Wm, 3)
+    ref = knn_ref.dist2(pts)
+    out = distCUDA2(pts.to(dev)).cpu()
+    assert out.shape == ref.shape
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-9), float(((out - ref).abs() / ref.clamp_min(1e-12)).max())  # rel 1e-5
+
+
 def check_adam_golden(dev):
     from instantsplat_amd.optim import PerPointAdam
     p1, p2 = T("adam_p1_0").clone().to(dev).requires_grad_(True), T("adam_p2_0").clone().to(dev).requires_grad_(True)

@@ -28,6 +28,7 @@ So the assertions are relative to what the fp32 oracle itself achieves against f
 import pytest
 import torch
 
+from tests import ops_util
 from tests.ops_util import bound
 
 pytestmark = pytest.mark.gpu
@@ -173,3 +174,9 @@ def test_c3_196k_512_all_views_match_cpu_oracle(gpu, train_iters):
 @pytest.mark.parametrize("train_iters", [0, 12])
 def test_c4_995k_1080p_matches_cpu_oracle(gpu, train_iters):
     _compare_views_with_cpu_oracle(gpu, "C4", 12, 288, 1920, 1080, (5,), train_iters)
+
+
+@pytest.mark.parametrize("V,Wm", [(3, 256), (12, 288)], ids=["C3_196608", "C4_995328"])
+def test_knn_on_the_baseline_point_clouds(gpu, V, Wm):
+    """a12 (create_from_pcd's distCUDA2) at the sizes the configs use: exact 3-NN mean squared distance vs the float64 k-d tree."""
+    ops_util.check_knn_pointmap(gpu, V, Wm)

@@ -113,6 +113,17 @@ def test_adam_step_keeps_the_optimizer_contract(emu):
     assert torch.allclose(m, torch.full((5, 3), 0.9 + 0.1 * 1e-3)) and not torch.equal(before, p1.detach())
 
 
+def test_device_guard_wraps_calls_for_tensors_off_the_current_device(monkeypatch):
+    """_lib.on_device: no context for the current device (the common case costs one comparison), torch.cuda.device(dev) for
+    any other one — the library launches go to the process's current device."""
+    from instantsplat_amd import _lib
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    assert _lib.on_device(torch.device("cuda", 0)) is _lib._NO_GUARD
+    assert _lib.on_device(torch.device("cpu")) is _lib._NO_GUARD and _lib.on_device(None) is _lib._NO_GUARD
+    guard = _lib.on_device(torch.device("cuda", 1))
+    assert isinstance(guard, torch.cuda.device) and guard.idx == 1
+
+
 def test_two_train_iterations_match_cpu_oracle(emu):
     ops_util.check_train_matches_cpu_oracle(emu, iters=2)
 

@@ -32,3 +32,13 @@ def test_empty(gpu):
 def test_cpu_tensor_is_refused(gpu):
     with pytest.raises(RuntimeError, match="GPU only"):
         run_blob_case("cpu", 10, 32, 32, 0, backward=False)
+
+
+def test_operators_follow_their_tensors_device(gpu):
+    """Tensors on cuda:1 while cuda:0 is the current device: the library launches must go to cuda:1 (_lib.on_device).  Needs a
+    node with two GPUs; on a one-GPU box only the host-side guard is covered (tests/test_ops_emu.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    assert torch.cuda.current_device() == 0
+    assert_raster_parity(run_blob_case("cuda:1", 3000, 128, 96, 1, scale_mean=0.1))
+    assert torch.cuda.current_device() == 0

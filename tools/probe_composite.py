@@ -70,3 +70,11 @@ print("waves per CU: " + pct(w_cu.astype(float)))
 order = np.argsort(-(t1 - k0))[:8]
 for i in order:
     print("  late wave: tile %4d q%d  start %.1f end %.1f us  hits %4d  inst %5d  wait %.1f walk %.1f" % (i // 4, i % 4, (t0[i] - k0) * tick, (t1[i] - k0) * tick, hits[i], inst[i], wait[i] * tick, walk[i] * tick))
+# per-quadrant bias and the per-SIMD picture (wave w of a workgroup runs on SIMD w of its CU)
+print("mean hits per quadrant (q0 top-left, q1 top-right, q2 bottom-left, q3 bottom-right): " + " ".join("%.0f" % h4[:, q].mean() for q in range(4)))
+qi = np.arange(len(hits)) % 4
+simd_hits = np.array([[hits[ok & (cu == c) & (qi == q)].sum() for q in range(4)] for c in cus])
+simd_end = np.array([[((t1 - k0) * tick)[ok & (cu == c) & (qi == q)].max() for q in range(4)] for c in cus])
+print("hits per SIMD: " + pct(simd_hits.ravel()) + "; max/mean %.2f" % (simd_hits.max() / simd_hits.mean()))
+print("SIMD finish [us]: " + pct(simd_end.ravel()) + "; corr(hits, finish) %.2f" % np.corrcoef(simd_hits.ravel(), simd_end.ravel())[0, 1])
+print("within a CU: mean of max(SIMD hits)/mean(SIMD hits) = %.2f" % np.mean(simd_hits.max(1) / simd_hits.mean(1)))
