@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 4
+#define MI355GS_ABI_VERSION 5
 
 /* error codes */
 #define MI355GS_OK 0
@@ -94,7 +94,6 @@ int mi355gs_raster_forward_render(
  *   dL_dshs[P,M,3] (split storage: dL_dshs[P,1,3] + dL_dshs_rest[P,M-1,3]) or dL_dcolors[P,3], dL_dopacities[P],
  *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
  *   geom/tiles/binning/capacity/radii/out_color: exactly what the forward of this frame used and produced
- *   (`tiles` also holds the tile scheduler's counters, which the kernels consume and re-arm: not const)
  *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes */
 size_t mi355gs_raster_grad_scratch_bytes(int P);
 int mi355gs_raster_backward(
@@ -125,10 +124,6 @@ int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, in
  * run the multi-chunk path on small scenes.  It also enters the buffer-size queries: set it before sizing a frame's buffers
  * and keep it until that frame's backward has been enqueued. */
 int mi355gs_tune_min_units(int min_units);
-/* Tuning knob of the persistent forward composite: workgroups launched per CU (0 = the default, enough to hold every tile of a
- * 512^2 frame at once; fewer = tiles are drawn dynamically by fewer resident workgroups).  Returns the previous value; n < 0
- * only queries.  Process-wide, measurement only. */
-int mi355gs_tune_fwd_workgroups_per_cu(int n);
 
 /* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that
  * cannot see the kernels (they are enqueued inside this library) can still attribute time to them.

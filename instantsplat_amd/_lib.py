@@ -34,7 +34,6 @@ _SIGNATURES = {
     "mi355gs_raster_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),
     "mi355gs_tune_min_units": (c_int, [c_int]),
-    "mi355gs_tune_fwd_workgroups_per_cu": (c_int, [c_int]),
     "mi355gs_profile_begin": (c_int, []),
     "mi355gs_profile_work_counters": (c_int, [_P]),
     "mi355gs_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),

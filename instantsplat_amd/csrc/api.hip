@@ -11,11 +11,11 @@ int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const flo
                              const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
                              float*, float*, float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
-int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, GsSched*, uint32_t*, uint32_t*);
+int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t*);
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t,
                       const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            float*, float*, uint32_t*, const uint32_t*, GsSched*, const uint32_t*, uint2*, float4*, uint32_t, const uint32_t*);
+                            float*, float*, uint32_t*, const uint32_t*, const uint32_t*, uint2*, float4*, uint32_t, const uint32_t*);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint32_t*, const uint2*,
                             const float4*, const uint32_t*, uint32_t, bool, unsigned long long*);
@@ -50,18 +50,6 @@ struct ProfScope {
 }  // namespace
 
 thread_local GsFusedStepHooks g_fused;
-
-int gs_num_cus() {
-  static int cached[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (cached[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
-    cached[dev] = n < GS_SCHED_SLOTS ? n : GS_SCHED_SLOTS;
-  }
-  return cached[dev];
-}
 
 void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
 
@@ -129,7 +117,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
   GS_CHECK_LAUNCH("count_tiles");
   gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered,
-                       (uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched), (uint32_t*)(t + tl.meta), (uint32_t*)(t + tl.seg_first));
+                       (uint32_t*)(t + tl.order), (uint32_t*)(t + tl.meta), (uint32_t*)(t + tl.seg_first));
   GS_CHECK_LAUNCH("scan_tiles");
   return MI355GS_OK;
 }
@@ -154,7 +142,7 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
     ProfScope prof(0, stream);
     gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
-                            (const uint32_t*)(t + tl.order), (GsSched*)(t + tl.sched), (const uint32_t*)(t + tl.seg_first),
+                            (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.seg_first),
                             (uint2*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, (const uint32_t*)(t + tl.meta));
   }
   GS_CHECK_LAUNCH("composite_fwd");
@@ -187,7 +175,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   const TilesLayout tl(W, H);
   const BinningLayout bl(capacity, tl.T);
   const char* g = (const char*)geom;
-  char* t = (char*)tiles;  // geometry of the frame is read-only here; the tile scheduler's words are consumed and re-armed
+  const char* t = (const char*)tiles;
   const char* b = (const char*)binning;
   GsGrad* grads = (GsGrad*)grad_scratch;
   if (!g_fused.skip_memsets && hipMemsetAsync(grads, 0, (size_t)P * sizeof(GsGrad), stream) != hipSuccess) return MI355GS_ELAUNCH;

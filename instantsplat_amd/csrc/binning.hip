@@ -22,12 +22,10 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 
 // ---- K2: exclusive scan of per-tile counts (T <= ~10^5 fits one workgroup comfortably)
 // (count and start may alias: every thread reads an element before it overwrites it)
-// With `order` set it also prepares the tile scheduler (common.h, GsSched): order[] = tile indices by descending count
-// (counting sort over 1024 count buckets — exact order inside a bucket is irrelevant for load balance) and the scheduler
-// words are cleared.
+// With `order` set it also writes order[] = tile indices by descending count (counting sort over 1024 count buckets — exact
+// order inside a bucket is irrelevant for load balance): the per-tile kernels launch their heaviest tiles first.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
-                                                               uint32_t* __restrict__ order, uint32_t* __restrict__ sched_words,
-                                                               int n_sched_words, uint32_t* __restrict__ meta,
+                                                               uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
                                                                uint32_t* __restrict__ seg_first, uint32_t min_units) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,11 +49,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     if (w < wave) wave_off += v;
     total += v;
   }
-  // ---- scheduler preparation first: it reads count[], which the scan below may overwrite (count and start can alias)
+  // ---- the tile order first: it reads count[], which the scan below may overwrite (count and start can alias)
   if (order) {
     __shared__ uint32_t hist[SCAN_THREADS];
     __shared__ uint32_t s_max;
-    for (int i = tid; i < n_sched_words; i += SCAN_THREADS) sched_words[i] = 0u;
     uint32_t mx = 0;
     for (int i = lo; i < hi; ++i) mx = max(mx, count[i]);
 #pragma unroll
@@ -558,8 +555,7 @@ __device__ __forceinline__ void sort_one_tile(int tile, const uint32_t* __restri
   }
 }
 
-// One workgroup per tile, heaviest tiles first (order[] from k_scan_tiles).  No persistent scheduling here: a tile's sort is
-// short and latency-bound, so the ~9 us of scheduler round trips cost more than CU balance gains (22 vs 13 us on C3).
+// One workgroup per tile, heaviest tiles first (order[] from k_scan_tiles).
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles(int T, const uint32_t* __restrict__ start, uint64_t* keys,
                                                               uint32_t* __restrict__ list, uint32_t capacity,
                                                               const uint32_t* __restrict__ order) {
@@ -577,9 +573,8 @@ extern "C" int mi355gs_tune_min_units(int min_units) {
 int gs_min_units() { return g_min_units; }
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
-                         GsSched* sched, uint32_t* meta, uint32_t* seg_first) {
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order,
-                     reinterpret_cast<uint32_t*>(sched), (int)(GS_SCHED_COUNT * sizeof(GsSched) / 4), meta, seg_first,
+                         uint32_t* meta, uint32_t* seg_first) {
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order, meta, seg_first,
                      (uint32_t)g_min_units);
   return 0;
 }
@@ -589,7 +584,7 @@ int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
-                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);  // in place
+                     (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);  // in place
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
 }

@@ -46,26 +46,6 @@ struct GeomLayout {
   }
 };
 
-// ---- CU-balanced tile scheduling ---------------------------------------------------------------------------------
-// A 512^2 frame has 1024 tiles = 4096 quadrant waves — exactly the 4 waves/SIMD the chip holds, so the hardware never
-// gets to rebalance: every workgroup is resident from the first cycle and the kernel lasts as long as the CU whose
-// tiles happen to be the heaviest (measured on the C3 workload: busiest CU 1.42x the mean, and where a workgroup lands
-// is not predictable from its index).  The per-tile kernels therefore run as persistent workgroups over per-CU bins:
-// k_scan_tiles orders the tiles by instance count (descending) and bin b owns the entries b, 2NB-1-b, 2NB+b, ... of that
-// order (a serpentine deal, NB = number of CUs, bin loads within ~2 % of each other); the first workgroup to start on a
-// physical CU (s_getreg HW_ID / XCC_ID) claims a bin for that CU, workgroups pop tiles from their CU's bin and, once it is
-// empty, from bins that no CU claimed.  Placement only affects speed: any mapping of workgroups to bins processes every tile
-// exactly once.
-constexpr int GS_SCHED_SLOTS = 512;  // >= physical CU ids (xcc:3 | se:2 | cu:4) and >= NB
-struct GsSched {
-  uint32_t cu_bin[GS_SCHED_SLOTS];  // physical CU -> 2 + bin (0: unclaimed, 1: claim in progress)
-  uint32_t next[GS_SCHED_SLOTS];    // per-bin pop counter
-  // `claimed` is read by finishing workgroups and `done` is incremented by them: on separate 64-byte lines, because a
-  // line that takes loads and device-scope atomics from all eight XCDs at once is very slow
-  uint32_t claimed, pad_a[15];
-  uint32_t done, pad_b[15];
-};
-enum { GS_SCHED_FWD = 0, GS_SCHED_COUNT = 1 };
 constexpr int GS_SORT_SMALL_CAP = 2048;  // keys the tile sort's register network takes in one go (binning.hip)
 
 constexpr int GS_UNIT_LEVELS = 4;
@@ -80,7 +60,7 @@ int gs_min_units();               // binning.hip: the mi355gs_tune_min_units kno
 constexpr int GS_MIN_UNITS = 12288;  // lengthen units only while at least this many remain (~2 per resident wave slot)
 
 struct TilesLayout {
-  size_t count, start, cursor, final_T, n_contrib, order, seg_first, sched, meta, total;
+  size_t count, start, cursor, final_T, n_contrib, order, seg_first, meta, total;
   int gx, gy, T;
   __host__ TilesLayout(int W, int H) {
     gx = (W + GS_TILE - 1) / GS_TILE; gy = (H + GS_TILE - 1) / GS_TILE; T = gx * gy;
@@ -92,7 +72,6 @@ struct TilesLayout {
     n_contrib = o; o += gs_align(npix * 4);
     order = o; o += gs_align((size_t)T * 4);
     seg_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of ceil(count / unit length): first unit of a tile
-    sched = o; o += gs_align(GS_SCHED_COUNT * sizeof(GsSched));
     meta = o; o += gs_align(16);   // [1]: number of backward units of the frame, [2]: chunks of GS_SEG instances per unit
     total = o;
   }
@@ -132,9 +111,6 @@ struct BinningLayout {
   }
 };
 
-int gs_num_cus();  // api.hip: compute units of the current device (cached)
-// persistent per-tile kernels: at most six workgroups per CU (LDS-limited residency of the composite kernels)
-static inline int gs_grid_persistent(int T, int NB) { return T < 6 * NB ? T : 6 * NB; }
 
 // transposed (column-major flat) 4x4 helpers, the storage the reference hands over
 __device__ __forceinline__ float3 gs_tp43(const float* m, float3 p) {
@@ -235,113 +211,12 @@ __device__ __forceinline__ float gs_pair_reduce_rows32(float a, float b) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// ---- device side of the tile scheduler (see GsSched).  Called by wave 0 of a workgroup with all 64 lanes active.
+// physical CU of the calling wave (measurement builds: tools/probe_composite.py)
 __device__ __forceinline__ uint32_t gs_physical_cu() {
   const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [14:13]
   const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));  // HW_REG_XCC_ID [3:0]
   return ((xcc & 7u) << 6) | (((hw >> 13) & 3u) << 4) | ((hw >> 8) & 15u);
 }
-
-__device__ __forceinline__ int gs_sched_claim(GsSched* s, int NB) {
-  uint32_t v = 0;
-  if ((threadIdx.x & 63) == 0) {
-    uint32_t* slot = &s->cu_bin[gs_physical_cu() & (GS_SCHED_SLOTS - 1)];
-    v = atomicCAS(slot, 0u, 1u);
-    if (v == 0u) {  // first workgroup on this CU: take the next unowned bin (NB = "none left", go straight to stealing)
-      const uint32_t b = atomicAdd(&s->claimed, 1u);
-      v = 2u + min(b, (uint32_t)NB);
-      atomicExch(slot, v);
-    } else {
-      while (v == 1u) {  // the claimer publishes within two atomics and waits for nobody
-        __builtin_amdgcn_s_sleep(1);
-        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  return (int)__builtin_amdgcn_readfirstlane(v) - 2;
-}
-
-// Next tile for this workgroup, or -1.  A workgroup drains the bin of its CU; bins nobody claimed (fewer CUs received a
-// workgroup than there are bins) are drained by the first workgroups of the grid once their own bins are empty.  There is
-// deliberately no stealing from claimed bins: the bins are balanced by construction, and a scan of all bin counters by a
-// thousand workgroups finishing together cost 14 us of a 32 us kernel.
-__device__ __forceinline__ int gs_sched_pop(GsSched* s, int bin, int NB, int T, const uint32_t* __restrict__ order) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t per_bin = (uint32_t)((T + NB - 1) / NB);
-  auto take = [&](int b) -> int {  // b wave-uniform; index into `order`, or -1 once bin b is exhausted
-    for (;;) {
-      uint32_t j = 0;
-      if (lane == 0) j = atomicAdd(&s->next[b], 1u);
-      j = __builtin_amdgcn_readfirstlane(j);
-      if (j >= per_bin) return -1;
-      const int idx = (int)j * NB + ((j & 1u) ? NB - 1 - b : b);
-      if (idx < T) return idx;
-    }
-  };
-  if (bin < NB) {
-    const int idx = take(bin);
-    if (idx >= 0) return idx;
-  }
-  // Only the first eight workgroups of the grid (one per XCD) look for unclaimed bins: a thousand workgroups reading this
-  // line when they finish cost more than the kernel they schedule (measured: +28 us on a 21 us kernel).
-  if (blockIdx.x >= 8) return -1;
-  uint32_t c = 0;
-  if (lane == 0) c = atomicAdd(&s->claimed, 0u);  // a stale (smaller) value would only cost failed tickets
-  const int first = (int)__builtin_amdgcn_readfirstlane(c), lim = NB < T ? NB : T;  // bins >= T hold no entries
-  for (int base = first; base < lim; base += 64) {
-    const int b2 = base + lane;
-    bool avail = false;
-    if (b2 < lim) avail = __hip_atomic_load(&s->next[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per_bin;
-    unsigned long long mask = __ballot(avail);
-    while (mask) {
-      const int l = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const int idx = take(base + l);
-      if (idx >= 0) return idx;
-    }
-  }
-  return -1;
-}
-
-// whole workgroup, after its last pop: the last workgroup of the launch re-arms the structure (a second backward over the
-// same forward, or a second render over the same preprocess, finds it as k_scan_tiles left it)
-__device__ __forceinline__ void gs_sched_finish(GsSched* s) {
-  __shared__ int s_last;
-  if (threadIdx.x == 0) s_last = atomicAdd(&s->done, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (s_last)
-    for (int i = threadIdx.x; i < (int)(sizeof(GsSched) / 4); i += blockDim.x) reinterpret_cast<uint32_t*>(s)[i] = 0u;
-}
-
-// Persistent workgroups over the CU-balanced tile bins (common.h, GsSched).
-// Wave priority by the tile's rank inside its bin (rank 0 = the bin's longest list).  The workgroups of a CU run their
-// tiles side by side and share each SIMD's issue slots; the longest list is the CU's critical path, so its waves issue
-// first and the shorter lists fill the slots it leaves.
-__device__ __forceinline__ void gs_rank_priority(int rank) {
-  if (rank == 0) __builtin_amdgcn_s_setprio(3);
-  else if (rank == 1) __builtin_amdgcn_s_setprio(2);
-  else if (rank == 2) __builtin_amdgcn_s_setprio(1);
-  else __builtin_amdgcn_s_setprio(0);
-}
-#define GS_PERSISTENT_TILE_LOOP(sched, NB, T, order, CALL)                     \
-  __shared__ int s_tile;                                                        \
-  const int wave_ = threadIdx.x >> 6;                                           \
-  int bin_ = 0;                                                                 \
-  if (wave_ == 0) bin_ = gs_sched_claim(sched, NB);                             \
-  for (;;) {                                                                    \
-    if (wave_ == 0) {                                                           \
-      const int t_ = gs_sched_pop(sched, bin_, NB, T, order);                   \
-      if ((threadIdx.x & 63) == 0) s_tile = t_;                                 \
-    }                                                                           \
-    __syncthreads();                                                            \
-    const int pos_ = s_tile;                                                    \
-    if (pos_ < 0) break;                                                        \
-    const int tile = (int)order[pos_];                                          \
-    gs_rank_priority(pos_ / NB);                                                \
-    CALL;                                                                       \
-    __syncthreads(); /* s_tile and the tile's LDS staging are reused */         \
-  }                                                                             \
-  gs_sched_finish(sched);
 
 #define GS_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \

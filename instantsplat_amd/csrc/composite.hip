@@ -34,7 +34,6 @@ extern "C" int mi355gs_probe_set(void* buf, unsigned int capacity_rows) {
 
 namespace {
 
-constexpr int BATCH = 512;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_MIN = 0.0001f;
 
@@ -109,24 +108,42 @@ __device__ __forceinline__ float gs_power2(float dx, float dy, float A, float C,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6 forward
+// K6 forward.  Workgroup = one 16x16 tile (heaviest tiles first), wave = one 8x8 pixel quadrant of it — and the four waves
+// never meet: each stages its own 64-record groups in wave-private LDS (lane i <- instance base + i, gathered through the
+// sorted list; the next group's records are requested before the current one is walked), tests the 64 staged records against
+// its quadrant at once (one per lane: box, then the exact maximum of the exponent over the box), collects the hits with a
+// ballot, and walks the set bits of that scalar mask: record addresses are wave-uniform (LDS broadcast reads), loop control is
+// SALU.  The walk takes FWD_GROUP hits per step: their alphas side by side (record reads, exponent, v_exp_f32, threshold tests:
+// independent), then the short transmittance-recurrence steps; a short group is padded with alpha = 0, a no-op for every
+// state variable (a live T >= 1e-4 stays, a finished one stays finished; w == 0 leaves colour and `last` alone).
+//
+// Round 1/2 ran this stage as persistent workgroups over CU-balanced bins with cooperative 512-record batches (two workgroup
+// barriers per batch).  Measured on MI355X, same frames: 84.7 -> 81.8 us at C3 (512^2), 623 -> 595 us at C4 (1080p) for this
+// form, bit-identical images — a wave that finishes early no longer waits for its tile's slowest quadrant, 59 VGPRs keep eight
+// waves per SIMD, and neither the scheduler's atomics nor its bookkeeping in k_scan_tiles exist any more.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int H, uint32_t capacity,
-                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
-                                                   const GsRec* __restrict__ recs, const float* __restrict__ bg,
-                                                   float* __restrict__ out_color, float* __restrict__ final_T,
-                                                   uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_first,
-                                                   uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units,
-                                                   uint32_t seg_len) {
-  __shared__ float4 s_q0[BATCH];
-  __shared__ float4 s_q1[BATCH];
-  __shared__ float4 s_q2[BATCH];
-  __shared__ int s_done[4];
+constexpr int FWD_GROUP = 2;
+
+__global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uint32_t capacity, const uint32_t* __restrict__ tile_start,
+                                                        const uint32_t* __restrict__ list, const GsRec* __restrict__ recs,
+                                                        const float* __restrict__ bg, float* __restrict__ out_color,
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                        const uint32_t* __restrict__ order, const uint32_t* __restrict__ seg_first,
+                                                        uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units,
+                                                        const uint32_t* __restrict__ meta) {
+  __shared__ float4 s_q0[4][GS_SEG];
+  __shared__ float4 s_q1[4][GS_SEG];
+  __shared__ float4 s_q2[4][GS_SEG];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = (int)order[blockIdx.x];      // heaviest tiles first
+  const uint32_t seg_len = meta[2] * GS_SEG;    // instances per backward unit of this frame (k_scan_tiles)
+  float4* __restrict__ q0s = s_q0[wave];
+  float4* __restrict__ q1s = s_q1[wave];
+  float4* __restrict__ q2s = s_q2[wave];
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
-  [[maybe_unused]] unsigned long long pr_hits = 0, pr_wait = 0, pr_groups = 0, pr_walk = 0;
+  [[maybe_unused]] unsigned long long pr_hits = 0, pr_groups = 0, pr_walk = 0;
   // Backward units of this tile (segments of seg_len instances, see common.h): publish them, and leave every pixel's
   // (transmittance after the last blended Gaussian, accumulated colour) at each segment boundary for the backward.
   const uint32_t seg0 = seg_first[tile], nseg = seg_first[tile + 1] - seg0;
@@ -140,94 +157,73 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
   // sign is the "done" flag (outside the image: -1 from the start)
   float Tr = q.inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
-
-  for (uint32_t base = start; base < end; base += BATCH) {
-    const int wave_done = __all(Tr < 0.0f);
-    if (lane == 0) s_done[wave] = wave_done;
-    [[maybe_unused]] const unsigned long long pr_w0 = GS_PROBE_CLOCK();
-    __syncthreads();  // also fences the previous batch's LDS reads against the stores below
-    if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+  if (start + (uint32_t)lane < end) { const GsRec* r = recs + list[start + lane]; r0 = r->q0; r1 = r->q1; r2 = r->q2; }
+  for (uint32_t base = start; base < end; base += GS_SEG) {
+    const int cnt = (int)min((uint32_t)GS_SEG, end - base);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the previous group's LDS reads are done (only this wave reads its staging area)
+    q0s[lane] = r0; q1s[lane] = r1; q2s[lane] = r2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool hit = lane < cnt && quad_hit(r0, r1, q);
+    unsigned long long mask = __ballot(hit);
+    {  // the next group's records travel while this one is walked (list index -> record: two dependent round trips)
+      const uint32_t jn = base + GS_SEG + (uint32_t)lane;
+      if (jn < end) { const GsRec* r = recs + list[jn]; r0 = r->q0; r1 = r->q1; r2 = r->q2; }
+    }
+#ifdef GS_PROBE
+    pr_hits += __popcll(mask); pr_groups += 1;
+    const unsigned long long pr_k0 = GS_PROBE_CLOCK();
+#endif
+    while (mask) {
+      int idx[FWD_GROUP];
+      bool live[FWD_GROUP];
 #pragma unroll
-    for (int sl = tid; sl < BATCH; sl += 256) {
-      const uint32_t j = base + sl;
-      if (j < end) {
-        const GsRec* r = recs + list[j];
-        s_q0[sl] = r->q0; s_q1[sl] = r->q1; s_q2[sl] = r->q2;
+      for (int u = 0; u < FWD_GROUP; ++u) {
+        idx[u] = mask ? __ffsll(mask) - 1 : (u ? idx[u - 1] : 0);
+        live[u] = mask != 0;   // wave-uniform: folds into the lane masks below as scalar logic
+        mask &= mask - 1;      // 0 stays 0
+      }
+      float al[FWD_GROUP];
+      bool valid[FWD_GROUP];
+      float4 col[FWD_GROUP];
+#pragma unroll
+      for (int u = 0; u < FWD_GROUP; ++u) {
+        const float4 a0 = q0s[idx[u]], a1 = q1s[idx[u]];
+        col[u] = q2s[idx[u]];
+        const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
+        const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
+        const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
+        const float alpha = fminf(0.99f, a1.w * __builtin_amdgcn_exp2f(power2));
+        // a skipped Gaussian is a transparent one (and so is the padding of a short group)
+        valid[u] = live[u] && power2 <= 0.0f && alpha >= ALPHA_MIN;
+        al[u] = valid[u] ? alpha : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < FWD_GROUP; ++u) {
+        // A finished pixel carries its final transmittance NEGATED (outside the image: -1): w0 and test_T are then
+        // negative, so `stop` (and nothing else) also covers "already done", and one select updates the state.
+        const float w0 = al[u] * Tr;
+        const float test_T = Tr - w0;  // T (1 - alpha)
+        const bool stop = test_T < T_MIN;
+        const float w = stop ? 0.0f : w0;
+        C0 += col[u].x * w; C1 += col[u].y * w; C2 += col[u].z * w;
+        // blended <=> alpha passed the tests and this is not the stopping Gaussian (w > 0 exactly then): mask logic
+        // on the two compare results instead of a third compare
+        last = (valid[u] && !stop) ? (base - start) + (uint32_t)idx[u] + 1u : last;
+        Tr = stop ? -fabsf(Tr) : test_T;
       }
     }
-    __syncthreads();
 #ifdef GS_PROBE
-    pr_wait += GS_PROBE_CLOCK() - pr_w0;
+    pr_walk += GS_PROBE_CLOCK() - pr_k0;
 #endif
-    if (wave_done) continue;
-    const int cnt = (int)min((uint32_t)BATCH, end - base);
-    for (int k = 0; k < cnt; k += 64) {
-      const int i = k + lane;
-      bool hit = false;
-      if (i < cnt) hit = quad_hit(s_q0[i], s_q1[i], q);
-      unsigned long long mask = __ballot(hit);
-#ifdef GS_PROBE
-      pr_hits += __popcll(mask); pr_groups += 1;
-      const unsigned long long pr_k0 = GS_PROBE_CLOCK();
-#endif
-      // Walk over the hit mask, FOUR hits per step.  A hit has two parts: its alpha at this lane's pixel (record reads,
-      // exponent, v_exp_f32, threshold tests: ~50 issue cycles, independent of every other hit) and the transmittance
-      // recurrence (w = alpha T, T' = T - w, stop test, selects: a dependent chain through Tr).  Done hit by hit, the
-      // alpha of hit k+1 waited for the recurrence of hit k and the wave issued one instruction per dependency latency
-      // — with at most four waves per SIMD, and fewer once the light quadrants of a tile have finished, the kernel ran at
-      // ~45 % of its VALU issue bound (84 cycles/hit x 1.0 M hits = 37 us of an 84 us kernel; tools/isa_cost.py).  With the
-      // four alphas computed side by side the wave has four independent chains in flight, then four short recurrence steps.
-      // A group with fewer than four hits left is padded with alpha = 0, which is a no-op for every state variable
-      // (a live T >= 1e-4 stays, a finished one stays finished; w == 0 leaves colour and `last` alone).
-      while (mask) {
-        int idx[4];
-        bool live[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          idx[u] = mask ? k + __ffsll(mask) - 1 : (u ? idx[u - 1] : k);
-          live[u] = mask != 0;   // wave-uniform: folds into the lane masks below as scalar logic
-          mask &= mask - 1;      // 0 stays 0
-        }
-        float al[4];
-        bool valid[4];
-        float4 col[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float4 a0 = s_q0[idx[u]], a1 = s_q1[idx[u]];
-          col[u] = s_q2[idx[u]];
-          const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
-          const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
-          const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
-          const float alpha = fminf(0.99f, a1.w * __builtin_amdgcn_exp2f(power2));
-          // a skipped Gaussian is a transparent one (and so is the padding of a short group)
-          valid[u] = live[u] && power2 <= 0.0f && alpha >= ALPHA_MIN;
-          al[u] = valid[u] ? alpha : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          // A finished pixel carries its final transmittance NEGATED (outside the image: -1): w0 and test_T are then
-          // negative, so `stop` (and nothing else) also covers "already done", and one select updates the state.
-          const float w0 = al[u] * Tr;
-          const float test_T = Tr - w0;  // T (1 - alpha)
-          const bool stop = test_T < T_MIN;
-          const float w = stop ? 0.0f : w0;
-          C0 += col[u].x * w; C1 += col[u].y * w; C2 += col[u].z * w;
-          // blended <=> alpha passed the tests and this is not the stopping Gaussian (w > 0 exactly then): mask logic
-          // on the two compare results instead of a third compare
-          last = (valid[u] && !stop) ? (base - start) + (uint32_t)idx[u] + 1u : last;
-          Tr = stop ? -fabsf(Tr) : test_T;
-        }
-      }
-#ifdef GS_PROBE
-      pr_walk += GS_PROBE_CLOCK() - pr_k0;
-#endif
-      const uint32_t pos = (base - start) + (uint32_t)k + 64u;  // instances of the tile blended so far
-      if (pos % seg_len == 0u) {
-        next_boundary = pos / seg_len;
-        if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
-      }
-      if (__all(Tr < 0.0f)) break;
+    const uint32_t pos = (base - start) + GS_SEG;  // instances of the tile blended so far
+    if (pos % seg_len == 0u) {
+      next_boundary = pos / seg_len;
+      if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
     }
+    if (__all(Tr < 0.0f)) break;
   }
   // boundaries this wave never reached (all its pixels were finished, or the tile ended): the state no longer changes
   const float Tfin = fabsf(Tr);
@@ -241,22 +237,8 @@ __device__ __forceinline__ void composite_fwd_tile(int tile, int gx, int W, int 
     out_color[plane + pix] = C1 + Tfin * bg[1];
     out_color[2 * plane + pix] = C2 + Tfin * bg[2];
   }
-  GS_PROBE_STORE((uint32_t)tile * 4u + (uint32_t)wave, pr_t0, GS_PROBE_CLOCK(), pr_hits, pr_wait, pr_groups, (unsigned long long)(end - start),
+  GS_PROBE_STORE((uint32_t)tile * 4u + (uint32_t)wave, pr_t0, GS_PROBE_CLOCK(), pr_hits, 0ull, pr_groups, (unsigned long long)(end - start),
                  (unsigned long long)gs_physical_cu(), pr_walk);
-}
-
-__global__ __launch_bounds__(256) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity,
-                                                        const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
-                                                        const GsRec* __restrict__ recs, const float* __restrict__ bg,
-                                                        float* __restrict__ out_color, float* __restrict__ final_T,
-                                                        uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order,
-                                                        GsSched* sched, int NB, const uint32_t* __restrict__ seg_first,
-                                                        uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units,
-                                                        const uint32_t* __restrict__ meta) {
-  const uint32_t seg_len = meta[2] * GS_SEG;  // instances per backward unit of this frame (k_scan_tiles)
-  GS_PERSISTENT_TILE_LOOP(sched, NB, T, order,
-                          composite_fwd_tile(tile, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T, n_contrib,
-                                             seg_first, unit_tile, bstate, max_units, seg_len))
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -542,21 +524,12 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
   return 0;
 }
 
-static int g_fwd_wg_per_cu = 0;   // 0: default residency (gs_grid_persistent)
-extern "C" int mi355gs_tune_fwd_workgroups_per_cu(int n) {
-  const int old = g_fwd_wg_per_cu;
-  if (n >= 0) g_fwd_wg_per_cu = n;
-  return old;
-}
-
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
-                            uint32_t* n_contrib, const uint32_t* order, GsSched* sched, const uint32_t* seg_first, uint2* unit_tile,
-                            float4* bstate, uint32_t max_units, const uint32_t* meta) {
-  const int NB = gs_num_cus();
-  const int grid = g_fwd_wg_per_cu > 0 ? (T < g_fwd_wg_per_cu * NB ? T : g_fwd_wg_per_cu * NB) : gs_grid_persistent(T, NB);
-  hipLaunchKernelGGL(k_composite_fwd, dim3(grid), dim3(256), 0, stream, T, gx, W, H, capacity, tile_start, list,
-                     recs, bg, out_color, final_T, n_contrib, order, sched + GS_SCHED_FWD, NB, seg_first, unit_tile, bstate, max_units, meta);
+                            uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, uint2* unit_tile, float4* bstate,
+                            uint32_t max_units, const uint32_t* meta) {
+  hipLaunchKernelGGL(k_composite_fwd, dim3(T), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T,
+                     n_contrib, order, seg_first, unit_tile, bstate, max_units, meta);
   return 0;
 }
 

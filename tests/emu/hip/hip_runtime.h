@@ -64,8 +64,6 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-// twenty "compute units" while the made-up placement below only ever uses fourteen: some bins are never claimed and must
-// be drained by the first workgroups of the grid
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 20; return hipSuccess; }
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
@@ -382,13 +380,14 @@ static inline emu_uint2v __builtin_amdgcn_permlane32_swap(unsigned old, unsigned
   r.v[1] = l >= 32 ? S(l) : D(l + 32);
   return r;
 }
-// hardware-id registers: a made-up, scattered placement (7 "CUs" x 2 "XCCs") so the tile scheduler's claim / steal paths run
+// hardware-id registers (read by the measurement build's probes only): a made-up placement of 7 "CUs" x 2 "XCCs"
 static inline unsigned __builtin_amdgcn_s_getreg(int simm16) {
   const unsigned b = blockIdx.x;
   return (simm16 & 63) == 20 ? (b & 1u) : (((b * 5u + 3u) % 7u) << 8);
 }
 #define __HIP_MEMORY_SCOPE_AGENT 4
 template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
