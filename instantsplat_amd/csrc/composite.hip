@@ -157,20 +157,41 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
   // sign is the "done" flag (outside the image: -1 from the start)
   float Tr = q.inside ? 1.0f : -1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-  if (start + (uint32_t)lane < end) { const GsRec* r = recs + list[start + lane]; r0 = r->q0; r1 = r->q1; r2 = r->q2; }
+  // The staged record of this lane as three native 16-byte vectors (a float4 local that is assigned under a condition ends up
+  // in scratch memory, and the store that puts it there waits for the load it was meant to overlap).  Gathering a record is
+  // two dependent round trips (sorted list -> record); both are taken off the critical path: while group g is walked, the
+  // records of group g + 1 and the list entries of group g + 2 are in flight.  Addresses are clamped, so no load sits in a branch.
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  auto list_at = [&](uint32_t j) { return list[min(j, end - 1u)]; };
+  auto fetch = [&](uint32_t id, v4f& a, v4f& b, v4f& c) {
+    const v4f* r = reinterpret_cast<const v4f*>(recs + id);
+    a = r[0]; b = r[1]; c = r[2];
+  };
+  v4f r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
+  uint32_t id_next = 0;
+  if (start < end) {
+    fetch(list_at(start + (uint32_t)lane), r0, r1, r2);
+    id_next = list_at(start + GS_SEG + (uint32_t)lane);
+  }
   for (uint32_t base = start; base < end; base += GS_SEG) {
     const int cnt = (int)min((uint32_t)GS_SEG, end - base);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the previous group's LDS reads are done (only this wave reads its staging area)
-    q0s[lane] = r0; q1s[lane] = r1; q2s[lane] = r2;
+    reinterpret_cast<v4f*>(q0s)[lane] = r0; reinterpret_cast<v4f*>(q1s)[lane] = r1; reinterpret_cast<v4f*>(q2s)[lane] = r2;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const bool hit = lane < cnt && quad_hit(r0, r1, q);
+    const bool hit = lane < cnt && quad_hit(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w), q);
     unsigned long long mask = __ballot(hit);
-    {  // the next group's records travel while this one is walked (list index -> record: two dependent round trips)
-      const uint32_t jn = base + GS_SEG + (uint32_t)lane;
-      if (jn < end) { const GsRec* r = recs + list[jn]; r0 = r->q0; r1 = r->q1; r2 = r->q2; }
+    if (base + GS_SEG < end) {
+      fetch(id_next, r0, r1, r2);
+      id_next = list_at(base + 2 * GS_SEG + (uint32_t)lane);
+    }
+    // the boundary in front of this group (the state after `base - start` instances) is stored here, not behind the walk
+    // that produced it: the wait for the next group's records at the top of the loop also covers every older memory
+    // operation, and a store issued just before it would be waited for at its full latency
+    if (base != start && (base - start) % seg_len == 0u) {
+      next_boundary = (base - start) / seg_len;
+      if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
     }
 #ifdef GS_PROBE
     pr_hits += __popcll(mask); pr_groups += 1;
@@ -218,11 +239,6 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
 #ifdef GS_PROBE
     pr_walk += GS_PROBE_CLOCK() - pr_k0;
 #endif
-    const uint32_t pos = (base - start) + GS_SEG;  // instances of the tile blended so far
-    if (pos % seg_len == 0u) {
-      next_boundary = pos / seg_len;
-      if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
-    }
     if (__all(Tr < 0.0f)) break;
   }
   // boundaries this wave never reached (all its pixels were finished, or the tile ended): the state no longer changes
