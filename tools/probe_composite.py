@@ -78,3 +78,14 @@ simd_end = np.array([[((t1 - k0) * tick)[ok & (cu == c) & (qi == q)].max() for q
 print("hits per SIMD: " + pct(simd_hits.ravel()) + "; max/mean %.2f" % (simd_hits.max() / simd_hits.mean()))
 print("SIMD finish [us]: " + pct(simd_end.ravel()) + "; corr(hits, finish) %.2f" % np.corrcoef(simd_hits.ravel(), simd_end.ravel())[0, 1])
 print("within a CU: mean of max(SIMD hits)/mean(SIMD hits) = %.2f" % np.mean(simd_hits.max(1) / simd_hits.mean(1)))
+# where does the dispatcher put consecutive workgroups?  (workgroup index = rank of the tile by instance count, descending)
+tile_inst = inst[::4]
+tile_cu = cu[::4].astype(int)
+rank_of = np.argsort(-tile_inst, kind="stable")       # rank -> tile (ties may differ from the device's counting sort)
+cu_by_rank = tile_cu[rank_of]
+print("CU of the first 24 workgroups: " + " ".join(str(c) for c in cu_by_rank[:24]))
+for period in (8, 32, 64, 128, 256):
+    same = np.mean(cu_by_rank[:-period] == cu_by_rank[period:]) if len(cu_by_rank) > period else float("nan")
+    print("  fraction of workgroups on the same CU as workgroup index - %d: %.2f" % (period, same))
+xcc = cu_by_rank >> 6
+print("XCC of the first 24 workgroups: " + " ".join(str(c) for c in xcc[:24]))
