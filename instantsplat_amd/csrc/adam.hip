@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, int row, float* __restr
 namespace {
 
 constexpr int MT_MAX = 8;
-constexpr int MT_CHUNK = 4096;  // elements per workgroup
+constexpr int MT_CHUNK = 2048;  // elements per workgroup (measured on C3: 4096 -> 17.3 us, 2048 -> 15.8, 1024 -> 18.9)
 
 struct MultiAdamArgs {
   int n;
