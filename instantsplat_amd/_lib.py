@@ -97,7 +97,30 @@ def check(code: int, what: str):
 
 
 def ptr(t: torch.Tensor | None):
-    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+    """A tensor's address as ctypes takes it for a void* argument (a plain int; None = NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+_F32 = torch.float32
+
+
+def f32c_on_one_device(*tensors):
+    """f32c + require_device in one pass over the arguments: -> ([contiguous float32 tensors], their common device)."""
+    out, dev = [], None
+    for t in tensors:
+        if t.dtype is not _F32:
+            raise RuntimeError(f"expected float32, got {t.dtype}")
+        if not t.is_contiguous():
+            t = t.contiguous()
+        d = t.device
+        if dev is None:
+            if d.type != "cuda" and not _TEST_MODE:
+                raise RuntimeError("instantsplat_amd operators run on the GPU only (got a CPU tensor; there is no CPU fallback)")
+            dev = d
+        elif d != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {d}")
+        out.append(t)
+    return out, dev
 
 
 def require_device(*tensors: torch.Tensor | None):
@@ -137,10 +160,10 @@ def on_device(device):
     return _NO_GUARD
 
 
-def stream_ptr(device) -> c_void_p:
+def stream_ptr(device):
     if device is not None and device.type == "cuda":
-        return c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    return c_void_p(0)
+        return torch.cuda.current_stream(device).cuda_stream
+    return None
 
 
 def f32c(t: torch.Tensor | None):

@@ -145,6 +145,16 @@ def _empty_bytes(n: int, device) -> torch.Tensor:
 
 
 _SIZES = {}
+_GRAD_SCRATCH = {}
+
+
+def grad_scratch_bytes(L, P):
+    n = _GRAD_SCRATCH.get(P)
+    if n is None:
+        if len(_GRAD_SCRATCH) > 64:
+            _GRAD_SCRATCH.clear()
+        n = _GRAD_SCRATCH[P] = int(L.mi355gs_raster_grad_scratch_bytes(P))
+    return n
 
 
 def frame_buffers(L, P, W, H, dev):
@@ -154,6 +164,8 @@ def frame_buffers(L, P, W, H, dev):
     key = (P, W, H)
     sizes = _SIZES.get(key)
     if sizes is None:
+        if len(_SIZES) > 64:
+            _SIZES.clear()
         sizes = _SIZES[key] = (max(int(L.mi355gs_raster_geom_bytes(P)), 1), max(int(L.mi355gs_raster_tiles_bytes(W, H)), 1))
     i32, u8 = torch.int32, torch.uint8
     return (torch.empty(P, dtype=i32, device=dev), torch.empty(3, H, W, dtype=torch.float32, device=dev),
@@ -242,7 +254,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dL_dscales = new(P, 3) if cov_ is None else None
         dL_drot = new(P, 4) if cov_ is None else None
         dL_dcov = new(P, 6) if cov_ is not None else None
-        scratch = _empty_bytes(L.mi355gs_raster_grad_scratch_bytes(P), dev)
+        scratch = _empty_bytes(grad_scratch_bytes(L, P), dev)
         stream = _lib.stream_ptr(dev)
 
         def run():

@@ -84,9 +84,8 @@ class _RenderPosed(torch.autograd.Function):
     def forward(ctx, xyz, rot, scaling, opacity_logit, f_dc, f_rest, pose, means2D, settings):
         s = settings
         L = _lib.lib()
-        xyz, rot, scaling, opl, f_dc, f_rest, pose = map(_lib.f32c, (xyz, rot, scaling, opacity_logit, f_dc, f_rest, pose))
-        bg, view, proj, origin = _lib.f32c(s.bg), _lib.f32c(s.viewmatrix), _lib.f32c(s.projmatrix), _lib.f32c(s.campos)
-        dev = _lib.require_device(xyz, rot, scaling, opl, f_dc, f_rest, pose, bg, view, proj, origin)
+        (xyz, rot, scaling, opl, f_dc, f_rest, pose, bg, view, proj, origin), dev = _lib.f32c_on_one_device(
+            xyz, rot, scaling, opacity_logit, f_dc, f_rest, pose, s.bg, s.viewmatrix, s.projmatrix, s.campos)
         P, D = xyz.shape[0], int(s.sh_degree)
         H, W = int(s.image_height), int(s.image_width)
         stream, debug = _lib.stream_ptr(dev), (1 if s.debug else 0)
@@ -119,7 +118,7 @@ class _RenderPosed(torch.autograd.Function):
         # PerPointAdam's zero-gradient step on it, as in the reference)
         d_frest = torch.zeros_like(f_rest) if D == 0 else new(f_rest)
         d_pose = torch.empty(7, dtype=torch.float32, device=dev)
-        scratch = dgr._empty_bytes(L.mi355gs_raster_grad_scratch_bytes(P), dev)
+        scratch = dgr._empty_bytes(dgr.grad_scratch_bytes(L, P), dev)
         pose_scratch = torch.empty(16 * ((P + 255) // 256) + 32, dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             _lib.check(L.mi355gs_posed_backward(

@@ -70,6 +70,19 @@ def fused_ssim(img1, img2, padding="same", train=True):
     return _FusedSSIM.apply(img1, img2, train, padding == "valid")
 
 
+_SCRATCH_BYTES = {}
+
+
+def _scratch_bytes(L, B, C, H, W):
+    key = (B, C, H, W)
+    n = _SCRATCH_BYTES.get(key)
+    if n is None:
+        if len(_SCRATCH_BYTES) > 64:
+            _SCRATCH_BYTES.clear()
+        n = _SCRATCH_BYTES[key] = int(L.mi355gs_ssim_scratch_bytes(B, C, H, W))
+    return n
+
+
 class _FusedL1SSIM(torch.autograd.Function):
     """(1-lambda)*L1 + lambda*(1-SSIM): loss AND its gradient w.r.t. img1 come out of one pass over the images
     (mi355gs_l1_ssim_loss_fused); backward only scales the kept gradient by the incoming dL/dloss."""
@@ -77,12 +90,11 @@ class _FusedL1SSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img1, img2, lambda_dssim):
         L = _lib.lib()
-        a, b = _lib.f32c(img1), _lib.f32c(img2)
+        (a, b), dev = _lib.f32c_on_one_device(img1, img2)
         if a.dim() != 4 or a.shape != b.shape:
             raise RuntimeError("fused_ssim expects two [B,C,H,W] tensors of equal shape")
-        dev = _lib.require_device(a, b)
         B, C, H, W = a.shape
-        scratch = torch.empty(int(L.mi355gs_ssim_scratch_bytes(B, C, H, W)), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(_scratch_bytes(L, B, C, H, W), dtype=torch.uint8, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)   # [ssim_mean, l1_mean]
         loss = torch.empty((), dtype=torch.float32, device=dev)
         grad = torch.empty_like(a)
