@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
 // them per pixel).  Gaussians whose box misses the wave's quadrant, or that lie behind every
 // pixel's last contributor, are skipped wave-wide.
 // ------------------------------------------------------------------------------------------------
-// One WAVE = one UNIT: segment `seg` (GS_SEG instances) of one tile's list; a workgroup carries four independent units.
+// One WAVE = one UNIT: segment `seg` (GS_SEG instances) of one tile's list; a workgroup is BW_UNITS independent waves (one, below).
 // The state a back-to-front replay would carry into the segment comes from the forward's boundary record instead: T is the
 // forward's own product, and the colour behind is dL/dC . (final colour - colour accumulated in front of the boundary).
 //
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
 //    ~125 issue cycles (8 v_permlane*_swap at 8 cycles, 9 DPP / select ops at 4; tools/ubench/valu_rate.hip) against
 //    ~100 for one quadrant's pixel math, and a Gaussian touches 1.5-2 quadrants of a tile on the benchmark scenes —
 //    round 1 paid the reduction (and nine atomics) for every one of them.
-constexpr int BW_UNITS = 4;  // units (waves) per workgroup
+constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgroups give the dispatcher the finest grain (129.4 -> 128.2 us at C3 against 4)
 
 // CHUNKS: 64-instance chunks per unit (1, or 0 = the frame's own value from meta[2] for the longer units of big frames; the
 // one-chunk instantiation keeps 74 VGPRs / six waves per SIMD, the loop over chunks costs 15 more)
@@ -283,7 +283,7 @@ constexpr int BW_UNITS = 4;  // units (waves) per workgroup
 // (Gaussian, tile) steps it ran, how many quadrant bodies, and how many lanes of those bodies were valid pixels — the inputs
 // of the VALU-issue model bench.py reports next to the HBM roofline.  The shipped launches use COUNT = false: no counters exist.
 template <int CHUNKS, bool COUNT = false>
-__global__ __launch_bounds__(256) void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
+__global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
                                                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -559,7 +559,7 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
   const dim3 grid((max_units + BW_UNITS - 1) / BW_UNITS);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
 #define GS_BWD(CH, CNT)                                                                                                               \
-  hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
+  hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
                      n_contrib, dL_dpix, grads, out_color, seg_first, unit_tile, bstate, meta, max_units, counters)
   if (counters) { if (!may_loop) GS_BWD(1, true); else GS_BWD(0, true); }
   else { if (!may_loop) GS_BWD(1, false); else GS_BWD(0, false); }

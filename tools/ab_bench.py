@@ -11,6 +11,8 @@ for name in list(_lib._SIGNATURES):   # an older build may lack newer optional e
     if not hasattr(_probe, name):
         del _lib._SIGNATURES[name]
 _lib._use_library_for_testing(lib)
+if os.environ.get("GS_MIN_UNITS"):   # A/B of the backward's unit length (mi355gs_tune_min_units)
+    _lib.lib().mi355gs_tune_min_units(int(os.environ["GS_MIN_UNITS"]))
 sys.argv = ["bench.py"] + sys.argv[2:]
 import bench
 bench.main()
