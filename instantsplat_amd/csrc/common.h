@@ -57,7 +57,8 @@ __host__ __device__ inline int gs_unit_level_for(long long instances, long long 
   return level;
 }
 int gs_min_units();               // binning.hip: the mi355gs_tune_min_units knob
-constexpr int GS_MIN_UNITS = 12288;  // lengthen units only while at least this many remain (~2 per resident wave slot)
+constexpr int GS_MIN_UNITS = 40960;  // lengthen units only while at least this many remain (6-7 rounds of the 6144 resident waves:
+                                     // measured at C4, 7.3 M instances: 512-instance units 2.34 ms/view, 256: 2.28, 128: 2.21, 64: 2.24)
 
 struct TilesLayout {
   size_t count, start, cursor, final_T, n_contrib, order, seg_first, meta, total;

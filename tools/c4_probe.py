@@ -5,6 +5,9 @@ from instantsplat_amd.synthetic import syn_pointmap
 from instantsplat_amd.train import setup_training
 from instantsplat_amd.gaussian_renderer import render
 from instantsplat_amd.fused_ssim import fused_l1_ssim_loss
+from instantsplat_amd import _lib
+if os.environ.get("GS_MIN_UNITS"):   # A/B of the backward's unit length (mi355gs_tune_min_units)
+    _lib.lib().mi355gs_tune_min_units(int(os.environ["GS_MIN_UNITS"]))
 dev = torch.device('cuda:0')
 st = setup_training(syn_pointmap(12, 288, 288, 1920, 1080, seed=0), dev)
 g = st.gaussians
