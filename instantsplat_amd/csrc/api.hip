@@ -11,13 +11,14 @@ int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const flo
                              const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
                              float*, float*, float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
-int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t*);
+int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t,
                       const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            float*, float*, uint32_t*, const uint32_t*, const uint32_t*, uint2*, float4*, uint32_t, const uint32_t*);
+                            float*, float*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint4*, float4*, uint32_t,
+                            const uint32_t*);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint32_t*, const uint2*,
+                            const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint32_t*, const uint4*,
                             const float4*, const uint32_t*, uint32_t, bool, unsigned long long*);
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
@@ -117,7 +118,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
   GS_CHECK_LAUNCH("count_tiles");
   gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered,
-                       (uint32_t*)(t + tl.order), (uint32_t*)(t + tl.meta), (uint32_t*)(t + tl.seg_first));
+                       (uint32_t*)(t + tl.order), (uint32_t*)(t + tl.meta), (uint32_t*)(t + tl.seg_first), (uint32_t*)(t + tl.part_first));
   GS_CHECK_LAUNCH("scan_tiles");
   return MI355GS_OK;
 }
@@ -142,8 +143,8 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
     ProfScope prof(0, stream);
     gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
-                            (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.seg_first),
-                            (uint2*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, (const uint32_t*)(t + tl.meta));
+                            (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.seg_first), (const uint32_t*)(t + tl.part_first),
+                            (uint4*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, (const uint32_t*)(t + tl.meta));
   }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;
@@ -184,7 +185,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
       ProfScope prof(1, stream);
       gs_launch_composite_bwd(stream, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                               (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
-                              dL_dpix, grads, out_color, (const uint32_t*)(t + tl.seg_first), (const uint2*)(b + bl.unit_tile),
+                              dL_dpix, grads, out_color, (const uint32_t*)(t + tl.seg_first), (const uint4*)(b + bl.unit_tile),
                               (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, bl.may_loop,
                               g_prof.work_counters);
     }

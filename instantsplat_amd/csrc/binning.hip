@@ -26,7 +26,8 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 // order inside a bucket is irrelevant for load balance): the per-tile kernels launch their heaviest tiles first.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
-                                                               uint32_t* __restrict__ seg_first, uint32_t min_units) {
+                                                               uint32_t* __restrict__ seg_first, uint32_t* __restrict__ part_first,
+                                                               uint32_t min_units) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -91,28 +92,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     // = exclusive scan of ceil(count / unit length) (same two-level scan as below)
     const uint32_t chunks = 1u << gs_unit_level_for((long long)total, (long long)min_units);
     const uint32_t seg_len = chunks * GS_SEG;
-    uint32_t lseg = 0;
-    for (int i = lo; i < hi; ++i) lseg += (count[i] + seg_len - 1) / seg_len;
-    uint32_t iseg = lseg;
+    // ... and, in the same pass, the prefix of "this tile's last unit is a short one" (part_first): the backward launches
+    // the full-length units first and the short ones last, where they shorten the tail of the kernel (composite.hip)
+    uint32_t lseg = 0, lpart = 0;
+    for (int i = lo; i < hi; ++i) { lseg += (count[i] + seg_len - 1) / seg_len; lpart += (count[i] % seg_len) != 0u; }
+    uint32_t iseg = lseg, ipart = lpart;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      uint32_t o = __shfl_up(iseg, d);
-      if (lane >= d) iseg += o;
+      uint32_t o = __shfl_up(iseg, d), op = __shfl_up(ipart, d);
+      if (lane >= d) { iseg += o; ipart += op; }
     }
     __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
-    if (lane == 63) seg_wave[wave] = iseg;
+    __shared__ uint32_t part_wave[SCAN_THREADS / GS_WAVE];
+    if (lane == 63) { seg_wave[wave] = iseg; part_wave[wave] = ipart; }
     __syncthreads();
-    uint32_t soff = 0, stot = 0;
+    uint32_t soff = 0, stot = 0, poff = 0, ptot = 0;
 #pragma unroll
     for (int w = 0; w < SCAN_THREADS / GS_WAVE; ++w) {
-      if (w < wave) soff += seg_wave[w];
-      stot += seg_wave[w];
+      if (w < wave) { soff += seg_wave[w]; poff += part_wave[w]; }
+      stot += seg_wave[w]; ptot += part_wave[w];
     }
-    uint32_t srun = soff + iseg - lseg;
+    uint32_t srun = soff + iseg - lseg, prun = poff + ipart - lpart;
     for (int i = lo; i < hi; ++i) {
-      seg_first[i] = srun;
+      seg_first[i] = srun; part_first[i] = prun;
       srun += (count[i] + seg_len - 1) / seg_len;
+      prun += (count[i] % seg_len) != 0u;
     }
+    if (tid == 0) { part_first[T] = ptot; meta[3] = ptot; }
     if (tid == 0) { seg_first[T] = stot; meta[1] = stot; meta[2] = chunks; }
   }
   uint32_t run = wave_off + incl - local;
@@ -573,9 +579,9 @@ extern "C" int mi355gs_tune_min_units(int min_units) {
 int gs_min_units() { return g_min_units; }
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
-                         uint32_t* meta, uint32_t* seg_first) {
+                         uint32_t* meta, uint32_t* seg_first, uint32_t* part_first) {
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order, meta, seg_first,
-                     (uint32_t)g_min_units);
+                     part_first, (uint32_t)g_min_units);
   return 0;
 }
 
@@ -584,7 +590,7 @@ int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
-                     (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);  // in place
+                     (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);  // in place
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
 }

@@ -61,7 +61,7 @@ constexpr int GS_MIN_UNITS = 40960;  // lengthen units only while at least this 
                                      // measured at C4, 7.3 M instances: 512-instance units 2.34 ms/view, 256: 2.28, 128: 2.21, 64: 2.24)
 
 struct TilesLayout {
-  size_t count, start, cursor, final_T, n_contrib, order, seg_first, meta, total;
+  size_t count, start, cursor, final_T, n_contrib, order, seg_first, part_first, meta, total;
   int gx, gy, T;
   __host__ TilesLayout(int W, int H) {
     gx = (W + GS_TILE - 1) / GS_TILE; gy = (H + GS_TILE - 1) / GS_TILE; T = gx * gy;
@@ -73,7 +73,8 @@ struct TilesLayout {
     n_contrib = o; o += gs_align(npix * 4);
     order = o; o += gs_align((size_t)T * 4);
     seg_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of ceil(count / unit length): first unit of a tile
-    meta = o; o += gs_align(16);   // [1]: number of backward units of the frame, [2]: chunks of GS_SEG instances per unit
+    part_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of "the tile's last unit is shorter than the unit length"
+    meta = o; o += gs_align(16);   // [1]: backward units of the frame, [2]: chunks of GS_SEG instances per unit, [3]: short units
     total = o;
   }
 };
@@ -106,7 +107,7 @@ struct BinningLayout {
     const size_t lim = by_chunks < by_rule ? by_chunks : by_rule;
     may_loop = gs_unit_level_for((long long)n, (long long)mu) > 0;
     max_units = (uint32_t)((lim > by_top ? lim : by_top) + (size_t)(T > 0 ? T : 1));
-    unit_tile = o; o += gs_align((size_t)max_units * 8);  // uint2 per unit: (tile x | tile y << 16, segment)
+    unit_tile = o; o += gs_align((size_t)max_units * 16);  // uint4 per unit, in launch order: (tile x | tile y << 16, segment, slot, 0)
     bstate = o; o += gs_align((size_t)max_units * 256 * sizeof(float4));  // per boundary: 256 pixels x (T, C0, C1, C2)
     total = o;
   }

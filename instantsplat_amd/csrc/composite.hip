@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ seg_first,
-                                                        uint2* __restrict__ unit_tile, float4* __restrict__ bstate, uint32_t max_units,
+                                                        const uint32_t* __restrict__ part_first, uint4* __restrict__ unit_tile,
+                                                        float4* __restrict__ bstate, uint32_t max_units,
                                                         const uint32_t* __restrict__ meta) {
   __shared__ float4 s_q0[4][GS_SEG];
   __shared__ float4 s_q1[4][GS_SEG];
@@ -147,9 +148,19 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
   // Backward units of this tile (segments of seg_len instances, see common.h): publish them, and leave every pixel's
   // (transmittance after the last blended Gaussian, accumulated colour) at each segment boundary for the backward.
   const uint32_t seg0 = seg_first[tile], nseg = seg_first[tile + 1] - seg0;
-  for (uint32_t sg = tid; sg < nseg; sg += 256)
-    if (seg0 + sg < max_units)  // (tile x | tile y << 16, segment): the backward needs no division to place itself
-      unit_tile[seg0 + sg] = make_uint2((uint32_t)(tile % gx) | ((uint32_t)(tile / gx) << 16), sg);
+  // The table is written in the backward's LAUNCH order: every full-length unit of the frame first (tile by tile), then the
+  // tiles' short last units.  The hardware hands out workgroups in index order, so the units that start last are the short ones
+  // and the kernel's tail — the stretch where the SIMDs run out of waves — is made of half-length work.  A unit's boundary
+  // record stays at its slot seg_first[tile] + segment; the entry carries it.
+  {
+    const uint32_t p0 = part_first[tile], n_full = nseg - (part_first[tile + 1] - p0);
+    const uint32_t full0 = seg0 - p0, all_full = meta[1] - meta[3];
+    for (uint32_t sg = tid; sg < nseg; sg += 256) {
+      const uint32_t pos = sg < n_full ? full0 + sg : all_full + p0;
+      if (pos < max_units)  // (tile x | tile y << 16, segment, slot): the backward needs no division to place itself
+        unit_tile[pos] = make_uint4((uint32_t)(tile % gx) | ((uint32_t)(tile / gx) << 16), sg, seg0 + sg, 0u);
+    }
+  }
   uint32_t next_boundary = 0;  // boundaries [0, next_boundary) of this tile have been stored by this wave
 
   // Tr: live transmittance while the pixel is still blending; once it is finished (T < 1e-4 would be reached) it holds MINUS
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
   // in scratch memory, and the store that puts it there waits for the load it was meant to overlap).  Gathering a record is
   // two dependent round trips (sorted list -> record); both are taken off the critical path: while group g is walked, the
   // records of group g + 1 and the list entries of group g + 2 are in flight.  Addresses are clamped, so no load sits in a branch.
-  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v4f __attribute__((vector_size(16)));   // (vector_size, not ext_vector_type: g++ builds these sources for the emulator)
   auto list_at = [&](uint32_t j) { return list[min(j, end - 1u)]; };
   auto fetch = [&](uint32_t id, v4f& a, v4f& b, v4f& c) {
     const v4f* r = reinterpret_cast<const v4f*>(recs + id);
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
     reinterpret_cast<v4f*>(q0s)[lane] = r0; reinterpret_cast<v4f*>(q1s)[lane] = r1; reinterpret_cast<v4f*>(q2s)[lane] = r2;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const bool hit = lane < cnt && quad_hit(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w), q);
+    const bool hit = lane < cnt && quad_hit(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r1[0], r1[1], r1[2], r1[3]), q);
     unsigned long long mask = __ballot(hit);
     if (base + GS_SEG < end) {
       fetch(id_next, r0, r1, r2);
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
                                                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
                                                         const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
-                                                        const uint2* __restrict__ unit_tile, const float4* __restrict__ bstate,
+                                                        const uint4* __restrict__ unit_tile, const float4* __restrict__ bstate,
                                                         const uint32_t* __restrict__ meta, uint32_t max_units,
                                                         unsigned long long* __restrict__ counters) {
   __shared__ float4 s_q0[BW_UNITS][GS_SEG];
@@ -301,18 +312,20 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
   [[maybe_unused]] unsigned long long pr_steps = 0, pr_t1 = 0;
   // Everything the prologue needs is requested in TWO rounds of loads instead of five dependent ones (placement -> tile range
-  // -> pixel state -> wave maxima / branch -> boundary record): a unit's boundary record lives at its own index (the forward
-  // publishes unit_tile[seg_first[tile] + segment]), so it is requested together with the placement, before the unit knows
-  // whether it will need it (the deepest unit of a tile does not: 1 in ~11 at C3); the pixel state — including the frame's
+  // -> pixel state -> wave maxima / branch -> boundary record): the table entry names the unit's tile, segment and the slot of
+  // its boundary record, which is requested before the unit knows whether it will need it (the deepest unit of a tile does
+  // not: 1 in ~11 at C3), together with the pixel state — including the frame's
   // colour, used only with the record — follows as soon as the tile is known, from clamped addresses so that no load sits
   // in a branch.  GS_PIN4 (an empty asm that "uses" the values) keeps the compiler from sinking the loads below the early
   // exits; it comes after the last load has been issued, where the first consumer would wait anyway.
 #define GS_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-  const uint2 entry = unit_tile[unit];
+  const uint4 entry = unit_tile[unit];   // `unit` is the position in launch order (full-length units first, short ones last)
+  const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
+  const uint32_t slot = __builtin_amdgcn_readfirstlane(entry.z);
+  if (slot >= max_units) return;   // (a frame that overflowed its buffers)
   float4 brec[4];
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) brec[qd] = bstate[(size_t)unit * 256 + qd * 64 + lane];
-  const uint32_t where = __builtin_amdgcn_readfirstlane(entry.x), seg = __builtin_amdgcn_readfirstlane(entry.y);  // uniform: scalar
+  for (int qd = 0; qd < 4; ++qd) brec[qd] = bstate[(size_t)slot * 256 + qd * 64 + lane];
   const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
   const int tile = ty * gx + tx;
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
@@ -542,10 +555,10 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
 
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
-                            uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, uint2* unit_tile, float4* bstate,
-                            uint32_t max_units, const uint32_t* meta) {
+                            uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, const uint32_t* part_first,
+                            uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta) {
   hipLaunchKernelGGL(k_composite_fwd, dim3(T), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T,
-                     n_contrib, order, seg_first, unit_tile, bstate, max_units, meta);
+                     n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta);
   return 0;
 }
 
@@ -554,7 +567,7 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
 int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
-                            const uint32_t* seg_first, const uint2* unit_tile, const float4* bstate, const uint32_t* meta,
+                            const uint32_t* seg_first, const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units, bool may_loop, unsigned long long* counters) {
   const dim3 grid((max_units + BW_UNITS - 1) / BW_UNITS);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
