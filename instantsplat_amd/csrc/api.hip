@@ -18,7 +18,7 @@ int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uin
                             float*, float*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint4*, float4*, uint32_t,
                             const uint32_t*);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
-                            const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint32_t*, const uint4*,
+                            const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint4*,
                             const float4*, const uint32_t*, uint32_t, bool, unsigned long long*);
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
@@ -185,7 +185,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
       ProfScope prof(1, stream);
       gs_launch_composite_bwd(stream, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                               (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
-                              dL_dpix, grads, out_color, (const uint32_t*)(t + tl.seg_first), (const uint4*)(b + bl.unit_tile),
+                              dL_dpix, grads, out_color, (const uint4*)(b + bl.unit_tile),
                               (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, bl.may_loop,
                               g_prof.work_counters);
     }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
                                                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix, GsGrad* __restrict__ grads,
-                                                        const float* __restrict__ out_color, const uint32_t* __restrict__ seg_first,
+                                                        const float* __restrict__ out_color,
                                                         const uint4* __restrict__ unit_tile, const float4* __restrict__ bstate,
                                                         const uint32_t* __restrict__ meta, uint32_t max_units,
                                                         unsigned long long* __restrict__ counters) {
@@ -567,13 +567,13 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
 int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
-                            const uint32_t* seg_first, const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
+                            const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units, bool may_loop, unsigned long long* counters) {
   const dim3 grid((max_units + BW_UNITS - 1) / BW_UNITS);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
 #define GS_BWD(CH, CNT)                                                                                                               \
   hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
-                     n_contrib, dL_dpix, grads, out_color, seg_first, unit_tile, bstate, meta, max_units, counters)
+                     n_contrib, dL_dpix, grads, out_color, unit_tile, bstate, meta, max_units, counters)
   if (counters) { if (!may_loop) GS_BWD(1, true); else GS_BWD(0, true); }
   else { if (!may_loop) GS_BWD(1, false); else GS_BWD(0, false); }
 #undef GS_BWD
