@@ -89,3 +89,22 @@ for period in (8, 32, 64, 128, 256):
     print("  fraction of workgroups on the same CU as workgroup index - %d: %.2f" % (period, same))
 xcc = cu_by_rank >> 6
 print("XCC of the first 24 workgroups: " + " ".join(str(c) for c in xcc[:24]))
+# is the placement the same from launch to launch?  (same frame rendered again, also during a training run)
+def placement():
+    with torch.no_grad():
+        buf.zero_()
+        assert raw.mi355gs_probe_set(ctypes.c_void_p(buf.data_ptr()), T * 4) == 0
+        render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
+        torch.cuda.synchronize()
+        raw.mi355gs_probe_set(ctypes.c_void_p(0), 0)
+    return buf.cpu().numpy()[::4, 6].astype(int)
+runs = [placement() for _ in range(4)]
+ra2 = RunAhead(st, window=10)
+for _ in range(20):
+    ra2.step()
+ra2.flush(); BinningPolicy.reset("exact"); torch.cuda.synchronize()
+runs.append(placement())
+base = runs[0][rank_of]
+for i, r in enumerate(runs[1:], 1):
+    print("placement of run %d vs run 0 (by workgroup index): %.3f of the workgroups on the same CU" % (i, np.mean(r[rank_of] == base)))
+print("workgroups per CU in run 0: " + pct(np.bincount(runs[0], minlength=512)[np.bincount(runs[0], minlength=512) > 0].astype(float)))
