@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
 //    ~125 issue cycles (8 v_permlane*_swap at 8 cycles, 9 DPP / select ops at 4; tools/ubench/valu_rate.hip) against
 //    ~100 for one quadrant's pixel math, and a Gaussian touches 1.5-2 quadrants of a tile on the benchmark scenes —
 //    round 1 paid the reduction (and nine atomics) for every one of them.
+constexpr uint32_t BW_XCD_RUN = 64;   // consecutive units sent to the same XCD (C3, FETCH_SIZE per launch: none 90 MB, 16: 56, 32: 50, 64: 47; time 124.6 / 122.1 / 122.0 / 122.7 us)
 constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgroups give the dispatcher the finest grain (129.4 -> 128.2 us at C3 against 4)
 
 // CHUNKS: 64-instance chunks per unit (1, or 0 = the frame's own value from meta[2] for the longer units of big frames; the
@@ -307,7 +308,12 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
   __shared__ float4 s_q1[BW_UNITS][GS_SEG];
   __shared__ float4 s_q2[BW_UNITS][GS_SEG];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const uint32_t unit = blockIdx.x * (uint32_t)BW_UNITS + (uint32_t)wave;
+  // Workgroup p runs on XCD p mod 8 (round-robin dispatch), each XCD behind its own L2.  Consecutive units are mostly units of
+  // one tile and re-read the same 8 KiB of per-pixel state, so they should share an L2: inside every block of 8 * BW_XCD_RUN
+  // launch positions the index is transposed, and units RUN b .. RUN b + RUN - 1 of the block all land on XCD b.
+  static_assert(BW_UNITS == 1, "the XCD transposition below is written for one unit per workgroup");
+  const uint32_t pos = blockIdx.x, in_block = pos % (8u * BW_XCD_RUN);
+  const uint32_t unit = pos - in_block + (in_block & 7u) * BW_XCD_RUN + (in_block >> 3);
   if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
   [[maybe_unused]] unsigned long long pr_steps = 0, pr_t1 = 0;
@@ -569,7 +575,8 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units, bool may_loop, unsigned long long* counters) {
-  const dim3 grid((max_units + BW_UNITS - 1) / BW_UNITS);
+  const uint32_t blk = 8u * BW_XCD_RUN;   // whole blocks of launch positions (see the index transposition in the kernel)
+  const dim3 grid((max_units + blk - 1u) / blk * blk);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
 #define GS_BWD(CH, CNT)                                                                                                               \
   hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \

@@ -131,7 +131,8 @@ def check_multi_chunk_units(dev, n=6000, min_units=4):
     (csrc/common.h, GS_MIN_UNITS; C4 runs at 8).  Lowering the knob makes small scenes take that path: the forward then
     leaves boundary records only every chunks * 64 instances and a backward wave replays several chunks in a row — image and
     every gradient must be what the one-chunk path gives (bit for bit in the forward; the backward's float atomics land in a
-    different order on the GPU)."""
+    different order: on the GPU always, under the emulator because the two unit lengths number — and since the XCD transposition of
+    the launch index also order — their units differently; measured there: 1.05e-6 of the largest gradient, relative L2 9e-7)."""
     from instantsplat_amd import _lib
     L = _lib.lib()
     cuda = torch.device(dev).type == "cuda"
@@ -148,7 +149,7 @@ def check_multi_chunk_units(dev, n=6000, min_units=4):
     assert torch.equal(a["color"], b["color"]) and torch.equal(a["radii"], b["radii"])
     for k in a["grads"]:
         d = float((a["grads"][k] - b["grads"][k]).abs().max())
-        assert d <= (1e-5 if cuda else 1e-6) * max(1.0, float(a["grads"][k].abs().max())), (k, d)
+        assert d <= 1e-5 * max(1.0, float(a["grads"][k].abs().max())), (k, d)
 
 
 def check_tile_lists_sorted(dev, n):
