@@ -244,6 +244,11 @@ class FusedTrainer:
         if not self.handle:
             raise RuntimeError("mi355gs_trainer_create failed")
         self.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
+        # Asynchronous verification: the step's instance count is stored by the tile-scan kernel STRAIGHT into a slot of this
+        # ring of pinned host memory (device-mapped), so no device-to-host copy — a 4-5 us blit kernel on the training stream,
+        # once per iteration — is enqueued for it.  A slot is reused after COUNT_RING steps; RunAhead verifies every `window` steps.
+        self._count_ring = torch.zeros(self.COUNT_RING, dtype=torch.int32, pin_memory=(dev.type == "cuda"))
+        self._count_next = 0
 
     def close(self):
         handle, self.handle = getattr(self, "handle", None), None
@@ -266,6 +271,8 @@ class FusedTrainer:
 
     __del__ = close
 
+    COUNT_RING = 256
+
     def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True):
         """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1]).
         defer_optimizer: stop after backward; `apply_optimizer()` then commits the update (or the caller discards it)."""
@@ -287,25 +294,32 @@ class FusedTrainer:
             steps.append(max(s["step"], 1))
         b1, b2 = grp[0]["betas"]
         F7, I7 = ctypes.c_float * 7, ctypes.c_int32 * 7
+        if verify_async:
+            if len(BinningPolicy.pending) >= self.COUNT_RING:
+                raise RuntimeError("more unverified frames than count slots: call BinningPolicy.poll() at least every "
+                                   f"{self.COUNT_RING} steps")
+            k = self._count_next
+            self._count_next = (k + 1) % self.COUNT_RING
+            count_out = self._count_ring[k:k + 1]
+        else:
+            count_out = self.num_rendered
         with _lib.on_device(self.dev):
             _lib.check(_lib.lib().mi355gs_trainer_step(
                 ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), int(g.active_sh_degree),
                 _lib.ptr(st.gt_images[cam.uid]),
                 _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(bg),
                 F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"]), float(opt.lambda_dssim),
-                1 if (do_opt and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(self.num_rendered)), "trainer_step")
+                1 if (do_opt and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(count_out)), "trainer_step")
         self._pending_opt = (F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"])) if do_opt else None
         if not verify_async:
             return cam
-        # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy)
+        # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy): the count is in its
+        # pinned slot once the event recorded behind the step has completed
+        ev = None
         if self.dev.type == "cuda":
-            pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            pinned.copy_(self.num_rendered, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
-        else:
-            pinned, ev = self.num_rendered.clone(), None
-        BinningPolicy.pending.append((ev, pinned, self.capacity, ("train", cam.uid), it))
+        BinningPolicy.pending.append((ev, count_out, self.capacity, ("train", cam.uid), it))
         return cam
 
     def apply_optimizer(self):
