@@ -273,9 +273,11 @@ class FusedTrainer:
 
     COUNT_RING = 256
 
-    def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True):
+    def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True, record_event: bool = True):
         """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1]).
-        defer_optimizer: stop after backward; `apply_optimizer()` then commits the update (or the caller discards it)."""
+        defer_optimizer: stop after backward; `apply_optimizer()` then commits the update (or the caller discards it).
+        record_event=False: the caller synchronises with the stream itself before it polls the counts (RunAhead's read-back of
+        the loss ring does), so no event is recorded behind the step."""
         st = self.st
         st.iteration += 1
         it, g, opt = st.iteration, st.gaussians, st.opt
@@ -316,7 +318,7 @@ class FusedTrainer:
         # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy): the count is in its
         # pinned slot once the event recorded behind the step has completed
         ev = None
-        if self.dev.type == "cuda":
+        if self.dev.type == "cuda" and record_event:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
         BinningPolicy.pending.append((ev, count_out, self.capacity, ("train", cam.uid), it))
@@ -407,7 +409,8 @@ class RunAhead:
     def step(self):
         """One training iteration; returns the EMA loss at window boundaries (like the reference's progress bar), else None."""
         if self.trainer is not None and FusedTrainer.supported(self.st):
-            self.trainer.step(self.ring[self.n_in_window:self.n_in_window + 1])
+            # (flush() reads the loss ring back — a blocking copy on this stream — before it polls the counts: no events needed)
+            self.trainer.step(self.ring[self.n_in_window:self.n_in_window + 1], record_event=False)
         else:
             loss = _forward_backward_step(self.st, self.fused)
             self.ring[self.n_in_window] = loss
