@@ -120,18 +120,20 @@ def size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, colo
     BinningPolicy — the reference operator's own blocking 4-byte read-back, or a verified bound with no host sync — allocate
     them and enqueue binning + composite.  Returns (capacity handed to the library, binning scratch)."""
     key = BinningPolicy.current_key
+    on_gpu = dev.type == "cuda"   # then `num_rendered` is a slot of pinned host memory the tile-scan kernel stores into (count_slot)
     if BinningPolicy.mode == "bounded" and key is not None and key in BinningPolicy.known:
         R = int(BinningPolicy.slack * BinningPolicy.known[key]) + BinningPolicy.pad  # capacity, no host sync
-        if dev.type == "cuda":
-            pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            pinned.copy_(num_rendered, non_blocking=True)
+        ev = None
+        if on_gpu:   # the count is in its slot once this event has completed
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-        else:  # emulated kernels on CPU tensors (tests): the count is already there
-            pinned, ev = num_rendered, None
-        BinningPolicy.pending.append((ev, pinned, R, key, BinningPolicy.current_tag))
+        BinningPolicy.pending.append((ev, num_rendered, R, key, BinningPolicy.current_tag))
     else:
-        R = int(num_rendered.item())  # the reference operator's own blocking read-back
+        # the reference operator's own blocking read-back of the count — without its device-to-host copy: the kernel has
+        # stored the value in host memory, the host only waits for the stream
+        if on_gpu:
+            torch.cuda.current_stream(dev).synchronize()
+        R = int(num_rendered[0])
         if key is not None:
             BinningPolicy.known[key] = R
     binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R, W, H), dev)
@@ -160,7 +162,8 @@ def grad_scratch_bytes(L, P):
 def frame_buffers(L, P, W, H, dev):
     """Per-frame outputs and workspaces of the forward: (radii, color, geom, tiles, num_rendered).  None is pre-filled: the
     projection kernel writes every radius (0 for a culled Gaussian) and the tile scan writes the instance count, so the two
-    memset launches of `torch.zeros` per frame are not needed; the workspace sizes are asked of the library once per shape."""
+    memset launches of `torch.zeros` per frame are not needed; the workspace sizes are asked of the library once per shape.
+    The count lives in host memory (count_slot)."""
     key = (P, W, H)
     sizes = _SIZES.get(key)
     if sizes is None:
@@ -169,8 +172,27 @@ def frame_buffers(L, P, W, H, dev):
         sizes = _SIZES[key] = (max(int(L.mi355gs_raster_geom_bytes(P)), 1), max(int(L.mi355gs_raster_tiles_bytes(W, H)), 1))
     i32, u8 = torch.int32, torch.uint8
     return (torch.empty(P, dtype=i32, device=dev), torch.empty(3, H, W, dtype=torch.float32, device=dev),
-            torch.empty(sizes[0], dtype=u8, device=dev), torch.empty(sizes[1], dtype=u8, device=dev),
-            torch.empty(1, dtype=i32, device=dev))
+            torch.empty(sizes[0], dtype=u8, device=dev), torch.empty(sizes[1], dtype=u8, device=dev), count_slot(dev))
+
+
+_COUNT_RINGS = {}
+COUNT_RING = 256
+
+
+def count_slot(dev):
+    """Where the forward leaves the frame's instance count: on the GPU a slot of a ring of pinned (device-mapped) host memory —
+    the tile-scan kernel's 4-byte store goes straight to the host, no device-to-host copy is enqueued to read it — handed out
+    round-robin (a slot is reused after COUNT_RING forwards; BinningPolicy.pending may not grow beyond that)."""
+    if dev.type != "cuda":
+        return torch.zeros(1, dtype=torch.int32, device=dev)
+    ring = _COUNT_RINGS.get(dev)
+    if ring is None:
+        ring = _COUNT_RINGS[dev] = [torch.zeros(COUNT_RING, dtype=torch.int32, pin_memory=True), 0]
+    if len(BinningPolicy.pending) >= COUNT_RING:
+        raise RuntimeError(f"more unverified frames than count slots: call BinningPolicy.poll() at least every {COUNT_RING} forwards")
+    k = ring[1]
+    ring[1] = (k + 1) % COUNT_RING
+    return ring[0][k:k + 1]
 
 
 def _cpu_deep_copy_tuple(input_tuple):
