@@ -23,6 +23,8 @@ import time
 import torch
 import torch.distributed as dist
 
+PROF_EVERY = 8   # HIP events around every 8th launch of the timed kernels (see the timed region)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -132,6 +134,10 @@ def main():
         ra.step()
     ra.flush()
     sync()
+    # live kernel timing: HIP events around every PROF_EVERY-th launch of the two composite kernels on the launch stream (an event
+    # pair costs ~3.5 us of stream time: around every launch it would add 14 us to a 311 us iteration)
+    prof_every = PROF_EVERY if args.steps >= 10 * PROF_EVERY else max(1, args.steps // 10)   # at least ~10 timed launches
+    L.mi355gs_profile_set_period(prof_every)
     L.mi355gs_profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -145,6 +151,7 @@ def main():
         _lib.check(L.mi355gs_profile_read(kind, ctypes.byref(tot_ms), ctypes.byref(n)), "profile_read")
         kern[name] = (tot_ms.value / max(n.value, 1), n.value)
     L.mi355gs_profile_end()
+    L.mi355gs_profile_set_period(1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -334,7 +341,7 @@ def main():
             "iters_per_sec_1k": long_runs, "fps_reference_method": fps,
             "roofline": {"kernel": "k_composite_bwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": bwd_ms,
-                         "launches": bwd_n, "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs),
+                         "launches": bwd_n, "timed_every": prof_every, "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs),
                          "pmc_sq": valu, "compute": compute,
                          "note": "the kernel is VALU-issue-bound, not HBM-bound (roofline.compute: counters of this run x measured issue "
                                  "costs): the HBM fraction is reported as the contract asks.  traffic > algorithmic bytes: the backward runs in "

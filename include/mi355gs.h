@@ -130,6 +130,9 @@ int mi355gs_tune_min_units(int min_units);
  * kind: 0 = composite forward, 1 = composite backward.  profile_read synchronises the recorded events
  * and returns the summed milliseconds and launch count since profile_begin. */
 int mi355gs_profile_begin(void);
+/* Time only every `every`-th launch of a kind (default 1: all).  An event pair costs ~3.5 us of stream time, which matters when
+ * the timed kernels are part of a measured loop.  Returns the previous period; every <= 0 only queries. */
+int mi355gs_profile_set_period(int every);
 /* While `counters` (device uint64[8], zeroed by the caller) is non-null, every composite-backward launch runs its counting
  * instantiation and ADDS: [0] (Gaussian, tile) steps, [1] quadrant bodies evaluated, [2] of those with at least one valid
  * pixel, [3] valid (pixel, Gaussian) pairs, [4] steps that ended in a reduction + atomics, [5] waves that did work.

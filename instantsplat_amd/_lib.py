@@ -35,6 +35,7 @@ _SIGNATURES = {
     "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),
     "mi355gs_tune_min_units": (c_int, [c_int]),
     "mi355gs_profile_begin": (c_int, []),
+    "mi355gs_profile_set_period": (c_int, [c_int]),
     "mi355gs_profile_work_counters": (c_int, [_P]),
     "mi355gs_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "mi355gs_profile_end": (c_int, []),

@@ -31,11 +31,14 @@ struct ProfState {
   hipEvent_t ev[PROF_KINDS][PROF_MAX][2];
   int created[PROF_KINDS] = {0, 0};
   int used[PROF_KINDS] = {0, 0};
+  int period = 1;                   // events go around every period-th launch of a kind (mi355gs_profile_set_period)
+  int seen[PROF_KINDS] = {0, 0};   // launches of the kind since profile_begin
 } g_prof;
 struct ProfScope {
   hipStream_t s; hipEvent_t stop; bool active = false;
   ProfScope(int kind, hipStream_t stream) : s(stream) {
     if (!g_prof.on || g_prof.used[kind] >= PROF_MAX) return;
+    if (g_prof.seen[kind]++ % g_prof.period != 0) return;
     const int i = g_prof.used[kind];
     if (i >= g_prof.created[kind]) {
       if (hipEventCreate(&g_prof.ev[kind][i][0]) != hipSuccess || hipEventCreate(&g_prof.ev[kind][i][1]) != hipSuccess) return;
@@ -216,7 +219,14 @@ int mi355gs_raster_frame_stats(void* stream_, int W, int H, const void* tiles, i
 int mi355gs_profile_begin(void) {
   g_prof.on = true;
   g_prof.used[0] = g_prof.used[1] = 0;
+  g_prof.seen[0] = g_prof.seen[1] = 0;
   return MI355GS_OK;
+}
+
+int mi355gs_profile_set_period(int every) {
+  const int old = g_prof.period;
+  if (every > 0) g_prof.period = every;
+  return old;
 }
 
 int mi355gs_profile_work_counters(void* counters) {
