@@ -73,7 +73,8 @@ size_t mi355gs_raster_binning_bytes(int64_t num_instances, int W, int H);
  *   cov3D_precomp[P,6] replaces scales/rotations when non-null
  *   viewmatrix[16], projmatrix[16]: row-vector convention, i.e. the transposed matrices the
  *     reference stores (scene/cameras.py:54-55) in flat memory; campos[3]
- *   radii[P] (int32, output); num_rendered: device int32, receives the instance count R */
+ *   radii[P] (int32, output); num_rendered: one int32 the device can write — device memory, or pinned host memory mapped into
+ *   the device's address space, in which case the count reaches the host without a copy — receives the instance count R */
 int mi355gs_raster_forward_preprocess(
     void* stream, int P, int D, int M, int W, int H,
     const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
@@ -255,7 +256,7 @@ int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float
  *   workspace: mi355gs_trainer_workspace_bytes() bytes, owned by the caller, must outlive the handle.
  *   The handle is the only writer of the parameter and moment tensors while it is alive (it remembers across steps that
  *   a tensor without gradients has an all-zero first moment and then skips it; create a new handle after changing them).
- *   capacity: instance capacity of the binning buffers; *num_rendered (device) receives the true count of every
+ *   capacity: instance capacity of the binning buffers; *num_rendered (device-writable, see above) receives the true count of every
  *   step — a step with num_rendered > capacity dropped instances and must be discarded by the caller.
  *   lr[7], step[7] (1-based Adam step of each group): host arrays.  loss_out: device float[1].
  * ---------------------------------------------------------------------------------------------- */
