@@ -10,7 +10,6 @@ from __future__ import annotations
 import ctypes
 import math
 import random
-import struct
 import time
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -145,14 +144,17 @@ def _fused_synced_iteration(st: TrainState):
                     render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
         need = max(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
         tr = st._trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
-        st._loss_slot = torch.zeros(1, dtype=torch.float32, device=tr.dev)
+        # loss and instance count are stored by the kernels that produce them straight into two words of pinned, device-mapped
+        # host memory (count as int32: a float32 detour would round counts above 2^24, reachable at 1 M Gaussians / 1080p, and
+        # could hide an overflow of a few instances): the iteration's read-back is a wait for the stream, not a copy
+        st._host_words = torch.zeros(2, dtype=torch.int32, pin_memory=(tr.dev.type == "cuda"))
+        st._loss_slot = st._host_words[0:1].view(torch.float32)
     saved = (st.iteration, list(st.viewpoint_stack), st.rng.getstate(), st.gaussians.active_sh_degree,
              [st.gaussians.optimizer.state[p]["step"] for p in tr.params], [g["lr"] for g in st.gaussians.optimizer.param_groups])
-    cam = tr.step(st._loss_slot, defer_optimizer=True, verify_async=False)
-    # the iteration's one host read-back: loss bits and instance count travel together as int32 (a float32 detour would
-    # round counts above 2^24, reachable at 1 M Gaussians / 1080p, and could hide an overflow of a few instances)
-    bits, r = torch.cat([st._loss_slot.view(torch.int32), tr.num_rendered]).tolist()
-    loss = struct.unpack("<f", struct.pack("<i", bits))[0]
+    cam = tr.step(st._loss_slot, defer_optimizer=True, verify_async=False, count_out=st._host_words[1:2])
+    if tr.dev.type == "cuda":
+        torch.cuda.current_stream(tr.dev).synchronize()
+    loss, r = float(st._loss_slot[0]), int(st._host_words[1])
     BinningPolicy.known[("train", cam.uid)] = int(r)
     if r > tr.capacity:   # dropped instances: discard, redo exactly, and grow the buffers for the next iterations
         st.iteration, st.viewpoint_stack, st.gaussians.active_sh_degree = saved[0], saved[1], saved[3]
@@ -273,11 +275,13 @@ class FusedTrainer:
 
     COUNT_RING = 256
 
-    def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True, record_event: bool = True):
+    def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True, record_event: bool = True,
+             count_out: torch.Tensor | None = None):
         """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1]).
         defer_optimizer: stop after backward; `apply_optimizer()` then commits the update (or the caller discards it).
         record_event=False: the caller synchronises with the stream itself before it polls the counts (RunAhead's read-back of
-        the loss ring does), so no event is recorded behind the step."""
+        the loss ring does), so no event is recorded behind the step.
+        count_out (with verify_async=False): where the step's instance count goes instead of the handle's device word."""
         st = self.st
         st.iteration += 1
         it, g, opt = st.iteration, st.gaussians, st.opt
@@ -303,7 +307,7 @@ class FusedTrainer:
             k = self._count_next
             self._count_next = (k + 1) % self.COUNT_RING
             count_out = self._count_ring[k:k + 1]
-        else:
+        elif count_out is None:
             count_out = self.num_rendered
         with _lib.on_device(self.dev):
             _lib.check(_lib.lib().mi355gs_trainer_step(
