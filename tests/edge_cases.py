@@ -135,7 +135,6 @@ def check_multi_chunk_units(dev, n=6000, min_units=4):
     the launch index also order — their units differently; measured there: 1.05e-6 of the largest gradient, relative L2 9e-7)."""
     from instantsplat_amd import _lib
     L = _lib.lib()
-    cuda = torch.device(dev).type == "cuda"
     res = {}
     old = L.mi355gs_tune_min_units(0)
     try:
