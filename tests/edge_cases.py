@@ -204,6 +204,72 @@ def check_tile_lists_sorted(dev, n):
 
 
 
+def check_backward_launch_order(dev, n=3000, min_units=None):
+    """The unit table the forward leaves for the backward (csrc/composite.hip, common.h), read raw through the C ABI: it is a
+    permutation of every (tile, segment) of the frame; every full-length unit comes before every short one (the tiles' last
+    units, which are launched last to shorten the kernel's tail); an entry's slot is seg_first[tile] + segment."""
+    from instantsplat_amd import _lib
+    from instantsplat_amd.camera import Camera
+    import numpy as np
+    dev = torch.device(dev)
+    L = _lib.lib()
+    old = L.mi355gs_tune_min_units(0)
+    if min_units is not None:
+        L.mi355gs_tune_min_units(min_units)
+    try:
+        g = torch.Generator().manual_seed(3)
+        z = 2.0 + 4.0 * torch.rand(n, generator=g)
+        means = torch.stack([0.5 * (2 * torch.rand(n, generator=g) - 1) * z, 0.35 * (2 * torch.rand(n, generator=g) - 1) * z, z], dim=1)
+        q = torch.randn(n, 4, generator=g)
+        q = q / q.norm(dim=1, keepdim=True)
+        scales = 0.02 + 0.05 * torch.rand(n, 3, generator=g)
+        opac = torch.full((n,), 0.05) + 0.1 * torch.rand(n, generator=g)
+        col = torch.rand(n, 3, generator=g)
+        W, H = 80, 48
+        tanx = math.tan(math.radians(60) / 2)
+        tany = tanx * H / W
+        cam = Camera(0, torch.eye(4), math.radians(60), 2 * math.atan(tany), W, H)
+        t = lambda x: x.float().contiguous().to(dev)
+        means, q, scales, opac, col = map(t, (means, q, scales, opac, col))
+        view, proj, campos = t(torch.eye(4).reshape(-1)), t(cam.projection_matrix.reshape(-1)), t(torch.zeros(3))
+        geom = torch.zeros(L.mi355gs_raster_geom_bytes(n), dtype=torch.uint8, device=dev)
+        tiles = torch.zeros(L.mi355gs_raster_tiles_bytes(W, H), dtype=torch.uint8, device=dev)
+        radii = torch.zeros(n, dtype=torch.int32, device=dev)
+        nr = torch.zeros(1, dtype=torch.int32, device=dev)
+        p, stream = _lib.ptr, _lib.stream_ptr(dev)
+        _lib.check(L.mi355gs_raster_forward_preprocess(stream, n, 0, 0, W, H, p(means), None, None, p(col), p(opac), p(scales), 1.0, p(q), None,
+                                                       p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles), p(nr), 0), "preprocess")
+        R = int(nr.item())
+        binning = torch.zeros(L.mi355gs_raster_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+        img, bg = torch.zeros(3, H, W, device=dev), torch.zeros(3, device=dev)
+        _lib.check(L.mi355gs_raster_forward_render(stream, n, W, H, R, p(bg), p(geom), p(tiles), p(binning), p(img), 0), "render")
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        T, al = gx * gy, (lambda x: (x + 255) & ~255)
+        # scratch layouts (csrc/common.h).  tiles = count | cursor | start[T+1] | final_T | n_contrib | order | seg_first[T+1] |
+        # part_first[T+1] | meta; binning = keys[R] (8 B) | list[R] (4 B) | unit table (16 B per entry) | boundary records
+        tb = tiles.cpu().numpy()
+        o = 2 * al(T * 4)
+        start = tb[o: o + (T + 1) * 4].view(np.int32); o += al((T + 1) * 4) + 2 * al(W * H * 4) + al(T * 4)
+        seg_first = tb[o: o + (T + 1) * 4].view(np.int32); o += al((T + 1) * 4)
+        part_first = tb[o: o + (T + 1) * 4].view(np.int32); o += al((T + 1) * 4)
+        meta = tb[o: o + 16].view(np.int32)
+        n_units, chunks, n_short = int(meta[1]), int(meta[2]), int(meta[3])
+        seg_len = 64 * chunks
+        count = np.diff(start)
+        assert n_units == int(np.sum((count + seg_len - 1) // seg_len)) == int(seg_first[T]) and n_short == int(np.sum(count % seg_len != 0))
+        table = binning.cpu().numpy()[al(R * 8) + al(R * 4):][: n_units * 16].view(np.uint32).reshape(n_units, 4)
+        where, seg, slot = table[:, 0], table[:, 1], table[:, 2]
+        tile = (where >> 16) * gx + (where & 0xFFFF)
+        assert bool((tile < T).all()) and bool((slot == seg_first[tile] + seg).all())
+        assert len(np.unique(slot)) == n_units and int(slot.max()) == n_units - 1          # every unit exactly once
+        last_seg = (count[tile] + seg_len - 1) // seg_len - 1
+        short = (seg == last_seg) & (count[tile] % seg_len != 0)
+        assert int(short.sum()) == n_short and not short[: n_units - n_short].any() and short[n_units - n_short:].all()
+        return n_units, n_short, chunks
+    finally:
+        L.mi355gs_tune_min_units(old)
+
+
 def check_operator_error_behaviour(dev, tmp_path):
     """Error contract of the rasterizer module (operator __init__ as called at reference
     gaussian_renderer/__init__.py:126-135): exactly one colour source and one covariance source or an `Exception`, the

@@ -38,6 +38,12 @@ def test_multi_chunk_backward_units(gpu):
     edge_cases.check_multi_chunk_units(gpu)
 
 
+@pytest.mark.parametrize("min_units", [None, 12])
+def test_backward_launch_order(gpu, min_units):
+    n_units, n_short, chunks = edge_cases.check_backward_launch_order(gpu, min_units=min_units)
+    assert n_units > n_short > 0 and (chunks == 1 if min_units is None else chunks > 1), (n_units, n_short, chunks)
+
+
 @pytest.mark.parametrize("n,longer_than", [(600, 0), (3000, 2048), (12000, 8192), (40000, 8192)])
 def test_tile_lists_sorted(gpu, n, longer_than):
     assert edge_cases.check_tile_lists_sorted(gpu, n) > longer_than
