@@ -287,6 +287,10 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
 //    ~100 for one quadrant's pixel math, and a Gaussian touches 1.5-2 quadrants of a tile on the benchmark scenes —
 //    round 1 paid the reduction (and nine atomics) for every one of them.
 constexpr uint32_t BW_XCD_RUN = 64;   // consecutive units sent to the same XCD (C3, FETCH_SIZE per launch: none 90 MB, 16: 56, 32: 50, 64: 47; time 124.6 / 122.1 / 122.0 / 122.7 us)
+#ifndef GS_BW_MFMA
+#define GS_BW_MFMA 0
+#endif
+constexpr bool BW_REDUCE_MFMA = GS_BW_MFMA != 0;   // A/B build switch of the experiment in replay_one (tools/variants.sh)
 constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgroups give the dispatcher the finest grain (129.4 -> 128.2 us at C3 against 4)
 
 // CHUNKS: 64-instance chunks per unit (1, or 0 = the frame's own value from meta[2] for the longer units of big frames; the
@@ -384,6 +388,12 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
     }
   }
 
+  typedef float v4f __attribute__((vector_size(16)));
+  [[maybe_unused]] float sel[9];   // BW_REDUCE_MFMA: the B operands "column c"
+  if constexpr (BW_REDUCE_MFMA) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) sel[c] = (lane & 15) == c ? 1.f : 0.f;
+  }
   const bool bit0 = (lane & 1) != 0, bit1 = (lane & 2) != 0;
   const bool out_lane = (lane & 14) == 0 || lane == 2;                 // the nine lanes that hold a finished sum
   const int out_comp = lane == 2 ? 8 : (lane >> 4) + 4 * (lane & 1);   // ... and which of the nine it is
@@ -444,7 +454,27 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
 #ifdef GS_PROBE
     pr_steps += 1;
 #endif
-    if (any_valid) {
+    if constexpr (BW_REDUCE_MFMA) {
+      if (any_valid) {
+        // EXPERIMENT: the cross-row half of the reduction on the matrix pipe.  v_mfma_f32_16x16x4_f32 computes
+        // D[i][j] += sum_k A[i][k] B[k][j] with A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[4 R + t][j] in register t of
+        // lane 16 R + j: with A = a moment and B = "column c" (1 in lanes with lane % 16 == c) the four rows of 16 lanes are summed
+        // and moment c lands in column c; nine accumulating MFMAs put the nine moments side by side.  Exact fp32.
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m0, sel[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m1, sel[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m2, sel[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m3, sel[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m4, sel[4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m5, sel[5], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m6, sel[6], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m7, sel[7], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m8, sel[8], acc, 0, 0, 0);
+        // lane (R, c): register t holds the sum over the four rows of lanes 4 R + t (mod 16) -> add the registers, then the rows
+        const float mine = gs_sum_rows((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        if (lane < 9) atomicAdd(reinterpret_cast<float*>(grads + id) + lane, mine);
+      }
+    } else if (any_valid) {
       // Nine values x 64 lanes -> nine sums, transposed so that every step halves the number of live values:
       // rows first (v_permlane16/32_swap pair steps, two ops per pair), then lane bits 0 and 1 inside the row (DPP
       // quad_perm pair steps), then the four quads of the row (row_ror:4, row_ror:8) on the single survivor.

@@ -380,6 +380,20 @@ static inline emu_uint2v __builtin_amdgcn_permlane32_swap(unsigned old, unsigned
   r.v[1] = l >= 32 ? S(l) : D(l + 32);
   return r;
 }
+// v_mfma_f32_16x16x4_f32: D[i][j] = C[i][j] + sum_k A[i][k] B[k][j]; A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j,
+// D[4 R + t][j] in element t of lane 16 R + j (CDNA3/4 ISA guide, matrix layouts).  All 64 lanes must be active.
+typedef float emu_v4f __attribute__((vector_size(16)));
+static inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_v4f c, int, int, int) {
+  int buf = emu::wave_exchange(((uint64_t)emu::from_bits<unsigned>(emu::to_bits(b)) << 32) | emu::from_bits<unsigned>(emu::to_bits(a)), true);
+  auto& ws = emu::ctx().waves[emu::wave_id()];
+  auto A = [&](unsigned lane) { return emu::from_bits<float>(ws.val[buf][lane] & 0xffffffffu); };
+  auto B = [&](unsigned lane) { return emu::from_bits<float>(ws.val[buf][lane] >> 32); };
+  const unsigned l = emu::lane_id(), R = l >> 4, j = l & 15;
+  emu_v4f d = c;
+  for (unsigned t = 0; t < 4; ++t)
+    for (unsigned k = 0; k < 4; ++k) d[t] += A(16 * k + 4 * R + t) * B(16 * k + j);
+  return d;
+}
 // hardware-id registers (read by the measurement build's probes only): a made-up placement of 7 "CUs" x 2 "XCCs"
 static inline unsigned __builtin_amdgcn_s_getreg(int simm16) {
   const unsigned b = blockIdx.x;
