@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 5
+#define MI355GS_ABI_VERSION 6
 
 /* error codes */
 #define MI355GS_OK 0
@@ -95,8 +95,10 @@ int mi355gs_raster_forward_render(
  *   dL_dshs[P,M,3] (split storage: dL_dshs[P,1,3] + dL_dshs_rest[P,M-1,3]) or dL_dcolors[P,3], dL_dopacities[P],
  *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
  *   geom/tiles/binning/capacity/radii/out_color: exactly what the forward of this frame used and produced
- *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes */
+ *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes (per-Gaussian accumulators; the last 256 bytes, from
+ *   mi355gs_raster_grad_gate_offset(P) on, are the eight gate flags mi355gs_posed_backward leaves for the optimizer) */
 size_t mi355gs_raster_grad_scratch_bytes(int P);
+size_t mi355gs_raster_grad_gate_offset(int P);
 int mi355gs_raster_backward(
     void* stream, int P, int D, int M, int W, int H, const float* bg,
     const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
@@ -192,11 +194,16 @@ int mi355gs_adam_step(void* stream, int64_t n, int row, float* param, const floa
 /* All parameter tensors of one optimizer step in two launches (<= 8 tensors per call).  The arrays are
  * HOST arrays of length ntensors holding device pointers / per-tensor scalars; per_point_lr[t] may be null;
  * step[t] is the 1-based step count of tensor t; scratch: device float[8].  The whole-tensor gradient gate
- * of the reference (per_point_adam.py:62-69) is evaluated on the device from the summed squares. */
+ * of the reference (per_point_adam.py:62-69) is evaluated on the device from the summed squares — or, when `gate` is
+ * non-null, taken from flags the gradients' producer has already left on the device: tensor t updates its moments iff
+ * gate[gate_index[t]] > 0 (device float[8] / host int32[ntensors], entries 0..7; `scratch` may then be null) and the
+ * pass over all gradients is not launched.  mi355gs_posed_backward leaves such flags behind its gradient records
+ * (group order xyz, f_dc, f_rest, opacity, scaling, rotation, pose); the caller vouches that grads[t] is exactly the
+ * tensor that call wrote. */
 int mi355gs_adam_multi_step(void* stream, int ntensors, const int64_t* numel, const int32_t* row, float* const* params,
                             const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                             const float* const* per_point_lr, const float* lr, float beta1, float beta2, float eps,
-                            const int32_t* step, float* scratch);
+                            const int32_t* step, float* scratch, const float* gate, const int32_t* gate_index);
 
 /* ------------------------------------------------------------------------------------------------
  * InstantSplat camera-frame transform fused with the Gaussian activations
@@ -230,6 +237,9 @@ int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* ro
  *   Stage 2 of the forward is mi355gs_raster_forward_render, unchanged.
  *   backward: pose_scratch = device float[16 * ((P + 255) / 256) + 32]; d_f_rest may be null while D == 0 (the reference's
  *   gradient for it is all zero then); d_* receive dL/d(raw parameter), d_pose[7] dL/dpose.
+ *   Also written: PerPointAdam's whole-tensor gate flags for these gradients, float[8] at grad_scratch +
+ *   mi355gs_raster_grad_gate_offset(P): flag k > 0 <=> the gradient of group k (xyz, f_dc, f_rest, opacity, scaling,
+ *   rotation, pose) has a non-zero element — what mi355gs_adam_multi_step(gate=...) consumes instead of re-reading them.
  * ---------------------------------------------------------------------------------------------- */
 int mi355gs_posed_forward_preprocess(void* stream, int P, int D, int W, int H, const float* xyz, const float* f_dc,
                                      const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,

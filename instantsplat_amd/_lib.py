@@ -25,6 +25,7 @@ _SIGNATURES = {
     "mi355gs_raster_tiles_bytes": (c_size_t, [c_int, c_int]),
     "mi355gs_raster_binning_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mi355gs_raster_grad_scratch_bytes": (c_size_t, [c_int]),
+    "mi355gs_raster_grad_gate_offset": (c_size_t, [c_int]),
     "mi355gs_raster_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P,
                                                   _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_forward_render": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int]),
@@ -46,7 +47,7 @@ _SIGNATURES = {
     "mi355gs_knn_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_knn_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "mi355gs_adam_step": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int]),
-    "mi355gs_adam_multi_step": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P]),
+    "mi355gs_adam_multi_step": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P]),
     "mi355gs_pose_forward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_pose_backward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_posed_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
@@ -64,11 +65,18 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+ABI_VERSION = 6   # include/mi355gs.h MI355GS_ABI_VERSION the signatures above were written for
+
+
 def _bind(path: str):
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = the .so does not match include/mi355gs.h
         fn.restype, fn.argtypes = res, args
+    got = lib.mi355gs_abi_version()
+    if got != ABI_VERSION:   # a stale build that happens to export every name would be called with the wrong argument lists
+        raise RuntimeError(f"{path} implements ABI v{got}, this package binds v{ABI_VERSION}: rebuild it with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'`")
     return lib
 
 
@@ -85,11 +93,49 @@ def lib():
 
 def _use_library_for_testing(path: str | None):
     """tests/ only: run the emulated (g++-compiled) build of the kernel sources on CPU tensors."""
-    global _LIB, _TEST_MODE
+    global _LIB, _TEST_MODE, _EXT_BOUND_TO
     if path is None:
         _LIB, _TEST_MODE = None, False
     else:
         _LIB, _TEST_MODE = _bind(path), True
+    _EXT_BOUND_TO = None   # the compiled binding is re-bound to the new library's entry points on its next use
+
+
+# ---- compiled PyTorch binding (csrc_torch/binding.cpp): the same C-ABI calls made from C++ autograd nodes.
+# BINDING = "compiled": use it wherever it covers the call (render_posed, fused_l1_ssim_loss, PerPointAdam.step);
+# "ctypes": the Python autograd.Function binding everywhere (kept for A/B and as the reference for the compiled one's tests).
+BINDING = os.environ.get("MI355GS_BINDING", "compiled")
+EXT_PATH = os.path.join(_HERE, "lib", "_mi355gs_torch.so")
+_EXT = None
+_EXT_BOUND_TO = None
+_EXT_SYMBOLS = ("mi355gs_raster_geom_bytes", "mi355gs_raster_tiles_bytes", "mi355gs_raster_binning_bytes",
+                "mi355gs_raster_grad_scratch_bytes", "mi355gs_raster_grad_gate_offset", "mi355gs_posed_forward_preprocess",
+                "mi355gs_raster_forward_render", "mi355gs_posed_backward", "mi355gs_ssim_scratch_bytes", "mi355gs_l1_ssim_loss_fused",
+                "mi355gs_adam_multi_step", "mi355gs_error_string")
+
+
+def compiled():
+    """The compiled binding bound to the library `lib()` currently returns, or None when BINDING == "ctypes".
+    A missing build is an error, not a silent fallback: both bindings run the same kernels, but the drop-in loop is
+    ~30 % slower through ctypes and nothing else would say so."""
+    global _EXT, _EXT_BOUND_TO
+    if BINDING != "compiled":
+        return None
+    L = lib()
+    if _EXT_BOUND_TO is L:
+        return _EXT
+    if _EXT is None:
+        if not os.path.exists(EXT_PATH):
+            raise RuntimeError(f"{EXT_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(or set MI355GS_BINDING=ctypes to use the Python binding)")
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_mi355gs_torch", EXT_PATH)
+        _EXT = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_EXT)
+    _EXT.forget_gates()
+    _EXT.bind({name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value for name in _EXT_SYMBOLS})
+    _EXT_BOUND_TO = L
+    return _EXT
 
 
 def check(code: int, what: str):

@@ -54,6 +54,9 @@ struct MultiAdamArgs {
   float* v[MT_MAX];
   const float* pplr[MT_MAX];
   float step_size[MT_MAX];
+  const float* gate;  // caller-provided gate flags (or null)
+  int gidx[MT_MAX];   // >= 0: tensor t's moment update is decided by gate[gidx[t]]; < 0: by its own sum of squares, sumsq[t]
+  int sq_out[MT_MAX]; // k_adam_sumsq: where tensor t's sum goes (its own index unless the launch covers a subset of a step's tensors)
   int vec4[MT_MAX];  // numel % 4 == 0 and all four arrays 16-byte aligned: 128-bit loads/stores
   // Optional memory of gated-off tensors across launches (fused trainer only).  live[2t] = sequence number of the last
   // launch that scanned tensor t's first moment while gated off (0: none since the last update), live[2t+1] = 1 if any
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void k_adam_sumsq(MultiAdamArgs a, float* __re
   __syncthreads();
   if (threadIdx.x == 0) {
     const float tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    if (tot > 0.f) atomicAdd(&sumsq[t], tot);
+    if (tot > 0.f) atomicAdd(&sumsq[a.sq_out[t]], tot);
   }
 }
 
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
   const int t = mt_find(a, blockIdx.x);
   const long long lo = (long long)(blockIdx.x - a.first_block[t]) * MT_CHUNK;
   const long long hi = min(a.numel[t], lo + MT_CHUNK);
-  const bool update = sumsq[t] > 0.f;
+  const bool update = (a.gidx[t] >= 0 ? a.gate[a.gidx[t]] : sumsq[t]) > 0.f;
   if (a.live) {
     const bool first = blockIdx.x == (unsigned)a.first_block[t] && threadIdx.x == 0;
     if (update) {
@@ -168,21 +171,24 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
 extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_t* numel, const int32_t* row, float* const* params,
                                        const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                                        const float* const* per_point_lr, const float* lr, float beta1, float beta2, float eps,
-                                       const int32_t* step, float* scratch) {
+                                       const int32_t* step, float* scratch, const float* gate, const int32_t* gate_index) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
-  if (ntensors < 0 || ntensors > MT_MAX || !scratch) return MI355GS_EINVAL;
+  if (ntensors < 0 || ntensors > MT_MAX || (gate && !gate_index)) return MI355GS_EINVAL;
   if (ntensors == 0) return MI355GS_OK;
   if (!numel || !row || !params || !grads || !exp_avg || !exp_avg_sq || !per_point_lr || !lr || !step) return MI355GS_EINVAL;
   MultiAdamArgs a;
-  a.n = ntensors;
+  a.n = ntensors; a.gate = gate;
   int blocks = 0;
+  bool need_sumsq = false;   // some tensor's gate has to be computed from its gradient
   for (int t = 0; t < MT_MAX; ++t) {
     a.first_block[t] = blocks;
     if (t < ntensors) {
       if (numel[t] < 0 || row[t] <= 0 || step[t] <= 0 || (numel[t] > 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t])))
         return MI355GS_EINVAL;
-      a.numel[t] = numel[t]; a.row[t] = row[t];
+      if (gate && gate_index[t] >= MT_MAX) return MI355GS_EINVAL;
+      a.numel[t] = numel[t]; a.row[t] = row[t]; a.gidx[t] = gate ? gate_index[t] : -1; a.sq_out[t] = t;
+      if (a.gidx[t] < 0) need_sumsq = true;
       a.param[t] = params[t]; a.grad[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.pplr[t] = per_point_lr[t];
       const double bc1 = 1.0 - pow((double)beta1, (double)step[t]), bc2 = 1.0 - pow((double)beta2, (double)step[t]);
       a.step_size[t] = (float)((double)lr[t] * (sqrt(bc2) / bc1));
@@ -190,15 +196,40 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
       blocks += (int)((numel[t] + MT_CHUNK - 1) / MT_CHUNK);
     } else {
       a.numel[t] = 0; a.row[t] = 1; a.param[t] = nullptr; a.grad[t] = nullptr; a.m[t] = nullptr; a.v[t] = nullptr; a.pplr[t] = nullptr;
-      a.step_size[t] = 0.f; a.vec4[t] = 0;
+      a.step_size[t] = 0.f; a.vec4[t] = 0; a.gidx[t] = -1; a.sq_out[t] = t;
     }
   }
   a.first_block[MT_MAX] = blocks;
   a.live = nullptr; a.seq = 0;
   if (blocks == 0) return MI355GS_OK;
-  if (g_fused.gate == scratch) { a.live = g_fused.adam_live; a.seq = g_fused.adam_seq; }
-  if (g_fused.gate == scratch) {
+  if (!gate && g_fused.gate == scratch) { a.live = g_fused.adam_live; a.seq = g_fused.adam_seq; }
+  if (need_sumsq && !scratch) return MI355GS_EINVAL;
+  if (gate) {
+    // the caller vouches that gate[gate_index[t]] > 0 <=> grads[t] has a non-zero element (the flags
+    // mi355gs_posed_backward leaves behind the gradient records): no pass over those gradients.  Tensors without a flag
+    // (gate_index[t] < 0: e.g. the pose table, whose gradient autograd scatters from the one row the backward wrote) are
+    // summed by a launch that covers only them.
+    if (need_sumsq) {
+      MultiAdamArgs s = a;
+      int k = 0, sblocks = 0;
+      for (int t = 0; t < ntensors; ++t) {
+        if (a.gidx[t] >= 0) continue;
+        s.first_block[k] = sblocks; s.numel[k] = a.numel[t]; s.grad[k] = a.grad[t]; s.vec4[k] = a.vec4[t]; s.sq_out[k] = t;
+        sblocks += (int)((a.numel[t] + MT_CHUNK - 1) / MT_CHUNK);
+        ++k;
+      }
+      for (int j = k; j <= MT_MAX; ++j) s.first_block[j] = sblocks;
+      s.n = k;
+      if (hipMemsetAsync(scratch, 0, MT_MAX * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+      if (sblocks > 0) {
+        hipLaunchKernelGGL(k_adam_sumsq, dim3(sblocks), dim3(256), 0, stream, s, scratch);
+        GS_CHECK_LAUNCH("adam_sumsq");
+      }
+    }
+  } else if (g_fused.gate == scratch) {
     // fused train step: the gate flags were written by the kernels that produced the gradients
+    a.gate = scratch;
+    for (int t = 0; t < ntensors; ++t) a.gidx[t] = t;
   } else {
     if (hipMemsetAsync(scratch, 0, MT_MAX * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
     hipLaunchKernelGGL(k_adam_sumsq, dim3(blocks), dim3(256), 0, stream, a, scratch);

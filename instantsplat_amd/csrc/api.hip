@@ -91,7 +91,8 @@ size_t mi355gs_raster_binning_bytes(int64_t n, int W, int H) {
   if (W <= 0 || H <= 0) return 0;
   return BinningLayout(n, TilesLayout(W, H).T).total;
 }
-size_t mi355gs_raster_grad_scratch_bytes(int P) { return gs_align((size_t)(P > 0 ? P : 1) * sizeof(GsGrad)); }
+size_t mi355gs_raster_grad_gate_offset(int P) { return gs_align((size_t)(P > 0 ? P : 1) * sizeof(GsGrad)); }
+size_t mi355gs_raster_grad_scratch_bytes(int P) { return mi355gs_raster_grad_gate_offset(P) + 256; }
 
 int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                                       const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
@@ -182,7 +183,9 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   const char* t = (const char*)tiles;
   const char* b = (const char*)binning;
   GsGrad* grads = (GsGrad*)grad_scratch;
-  if (!g_fused.skip_memsets && hipMemsetAsync(grads, 0, (size_t)P * sizeof(GsGrad), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  // (with gate_tail the eight gate flags behind the records are cleared by the same memset)
+  const size_t clear_bytes = g_fused.gate_tail ? mi355gs_raster_grad_gate_offset(P) + 8 * sizeof(float) : (size_t)P * sizeof(GsGrad);
+  if (!g_fused.skip_memsets && hipMemsetAsync(grads, 0, clear_bytes, stream) != hipSuccess) return MI355GS_ELAUNCH;
   if (cap > 0) {
     {
       ProfScope prof(1, stream);

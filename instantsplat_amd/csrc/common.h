@@ -258,6 +258,7 @@ struct GsFusedStepHooks {
   GsPrologue prologue;
   GsPosed posed;
   float* gate = nullptr;   // device float[8] or null
+  bool gate_tail = false;  // the flags live right behind the GsGrad records (mi355gs_raster_grad_gate_offset) and are cleared with them
   uint32_t* adam_live = nullptr;  // device uint32[16] persisting across steps (see k_adam_multi) or null
   uint32_t adam_seq = 0;          // launch sequence number (never 0) for adam_live
   int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_sh_rest = -1, gate_pose = -1;

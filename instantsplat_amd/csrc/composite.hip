@@ -319,6 +319,10 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
   const uint32_t pos = blockIdx.x, in_block = pos % (8u * BW_XCD_RUN);
   const uint32_t unit = pos - in_block + (in_block & 7u) * BW_XCD_RUN + (in_block >> 3);
   if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
+  // The one-chunk instantiation is launched when the CAPACITY cannot need longer units; a frame that overflowed its capacity
+  // may still have been laid out in longer ones (k_scan_tiles decides from the true count).  Such a frame is discarded by its
+  // caller anyway: leave its gradients zero instead of replaying it with the wrong unit length.
+  if (CHUNKS != 0 && meta[2] != (uint32_t)CHUNKS) return;
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
   [[maybe_unused]] unsigned long long pr_steps = 0, pr_t1 = 0;
   // Everything the prologue needs is requested in TWO rounds of loads instead of five dependent ones (placement -> tile range

@@ -78,7 +78,7 @@ int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t*
   const float* pplr[7] = {t->pplr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (++t->adam_seq == 0u) t->adam_seq = 1u;
   g_fused.adam_live = t->adam_live; g_fused.adam_seq = t->adam_seq;
-  return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch);
+  return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch, nullptr, nullptr);
 }
 
 __global__ void k_trainer_consts(float* consts) {
@@ -117,19 +117,23 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
   if (!pose || !pose_scratch || !d_pose || D < 0 || D > 3 || (D > 0 && (!f_rest || !d_f_rest))) return MI355GS_EINVAL;
   if (P <= 0) return hipMemsetAsync(d_pose, 0, 7 * sizeof(float), stream) == hipSuccess ? MI355GS_OK : MI355GS_ELAUNCH;
   const int rows = (P + 255) / 256;
+  float* gate = (float*)((char*)grad_scratch + mi355gs_raster_grad_gate_offset(P));
   int rc;
   {
     struct Scope { ~Scope() { g_fused = GsFusedStepHooks(); } } scope;
     g_fused.posed.pose = pose;
     g_fused.posed.acc = pose_scratch + (size_t)16 * rows;   // unused with `partial` set; kept valid
     g_fused.posed.partial = pose_scratch;                   // one row of 16 pose sums per projection workgroup
+    // PerPointAdam's whole-tensor gate flags, in the optimizer's group order, from the kernels that write the gradients
+    g_fused.gate = gate; g_fused.gate_tail = true;
+    g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_sh_rest = 2; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5;
     rc = mi355gs_raster_backward(stream, P, D, D == 0 ? 1 : 16, W, H, bg, xyz, f_dc, D == 0 ? nullptr : f_rest, nullptr, opacity_logit,
                                  log_scales, scale_modifier, rotation, nullptr, view_identity, projmatrix, origin, tanfovx, tanfovy,
                                  geom, tiles, binning, capacity, radii, out_color, dL_dpix, grad_scratch, d_xyz, d_means2D, d_f_dc,
                                  D == 0 ? nullptr : d_f_rest, nullptr, d_opacity_logit, d_log_scales, d_rotation, nullptr, debug);
   }
   if (rc) return rc;
-  gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, nullptr, nullptr, 0, 0.0, 0.f, nullptr);
+  gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, gate + 6, nullptr, 0, 0.0, 0.f, nullptr);
   GS_CHECK_LAUNCH("pose_finish");
   return MI355GS_OK;
 }

@@ -1,0 +1,341 @@
+// Compiled PyTorch binding of the drop-in path: render()'s differentiable body, the training loss and the
+// PerPointAdam step as C++ autograd nodes / functions over the C ABI of libmi355gs.so (include/mi355gs.h).
+//
+// Why it exists: the reference binds its operators through compiled torch extensions
+// (reference gaussian_renderer/__init__.py:14-17: `from diff_gaussian_rasterization import ...` is a pybind module,
+// train.py:39-43 `fused_ssim`).  The ctypes + Python `autograd.Function` binding of the same entry points
+// (instantsplat_amd/fused.py, fused_ssim/__init__.py, optim.py) costs 100-190 us of host time per iteration — the
+// autograd engine re-entering Python from its device thread, ~40-argument ctypes calls, ~25 tensor allocations made one
+// Python call at a time — which the reference-shaped loop (two blocking read-backs per iteration) cannot hide.
+// This module makes the same calls from C++.  It holds NO compute: every kernel is behind the C ABI, whose entry points
+// it receives as addresses from instantsplat_amd/_lib.py (so the CPU test tier can hand it the emulated build).
+//
+// Built by __graft_entry__.build() -> instantsplat_amd/lib/_mi355gs_torch.so (instantsplat_amd/csrc_torch/build.py).
+#include <torch/extension.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <mutex>
+
+#include "../../include/mi355gs.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+// ---- C ABI entry points (addresses handed over by _lib.py: whichever build of the library the package has loaded)
+struct Abi {
+  decltype(&mi355gs_raster_geom_bytes) geom_bytes = nullptr;
+  decltype(&mi355gs_raster_tiles_bytes) tiles_bytes = nullptr;
+  decltype(&mi355gs_raster_binning_bytes) binning_bytes = nullptr;
+  decltype(&mi355gs_raster_grad_scratch_bytes) grad_scratch_bytes = nullptr;
+  decltype(&mi355gs_raster_grad_gate_offset) grad_gate_offset = nullptr;
+  decltype(&mi355gs_posed_forward_preprocess) posed_forward_preprocess = nullptr;
+  decltype(&mi355gs_raster_forward_render) forward_render = nullptr;
+  decltype(&mi355gs_posed_backward) posed_backward = nullptr;
+  decltype(&mi355gs_ssim_scratch_bytes) ssim_scratch_bytes = nullptr;
+  decltype(&mi355gs_l1_ssim_loss_fused) l1_ssim_loss_fused = nullptr;
+  decltype(&mi355gs_adam_multi_step) adam_multi_step = nullptr;
+  decltype(&mi355gs_error_string) error_string = nullptr;
+  bool bound = false;
+} g_abi;
+
+void bind_abi(const std::map<std::string, uintptr_t>& sym) {
+  auto get = [&](const char* name) {
+    auto it = sym.find(name);
+    TORCH_CHECK(it != sym.end() && it->second, "mi355gs torch binding: entry point ", name, " was not provided");
+    return it->second;
+  };
+#define GS_BIND(field, name) g_abi.field = reinterpret_cast<decltype(g_abi.field)>(get(#name))
+  GS_BIND(geom_bytes, mi355gs_raster_geom_bytes);
+  GS_BIND(tiles_bytes, mi355gs_raster_tiles_bytes);
+  GS_BIND(binning_bytes, mi355gs_raster_binning_bytes);
+  GS_BIND(grad_scratch_bytes, mi355gs_raster_grad_scratch_bytes);
+  GS_BIND(grad_gate_offset, mi355gs_raster_grad_gate_offset);
+  GS_BIND(posed_forward_preprocess, mi355gs_posed_forward_preprocess);
+  GS_BIND(forward_render, mi355gs_raster_forward_render);
+  GS_BIND(posed_backward, mi355gs_posed_backward);
+  GS_BIND(ssim_scratch_bytes, mi355gs_ssim_scratch_bytes);
+  GS_BIND(l1_ssim_loss_fused, mi355gs_l1_ssim_loss_fused);
+  GS_BIND(adam_multi_step, mi355gs_adam_multi_step);
+  GS_BIND(error_string, mi355gs_error_string);
+#undef GS_BIND
+  g_abi.bound = true;
+}
+
+void check(int code, const char* what) {
+  TORCH_CHECK(code == 0, "mi355gs: ", what, " failed: ", g_abi.error_string ? g_abi.error_string(code) : "?", " (", code, ")");
+}
+
+// The launches inside the library go to the process's current device: make it the tensors' device for the call, and hand
+// over torch's current stream on it (CPU tensors: the emulated build of the CPU test tier, no stream).
+struct DeviceScope {
+  c10::hip::OptionalHIPGuard guard;
+  void* stream = nullptr;
+  explicit DeviceScope(const Tensor& t) {
+    if (t.is_cuda()) {
+      guard.set_device(t.device());
+      stream = (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+    }
+  }
+  void synchronize(const Tensor& t) const {
+    if (t.is_cuda()) c10::hip::getCurrentHIPStream(t.device().index()).synchronize();
+  }
+};
+
+Tensor f32c(const Tensor& t, const char* name, const Tensor& like) {
+  TORCH_CHECK(t.scalar_type() == at::kFloat, "expected float32, got ", t.scalar_type(), " (", name, ")");
+  TORCH_CHECK(t.device() == like.device(), "tensors on different devices: ", like.device(), " vs ", t.device(), " (", name, ")");
+  return t.is_contiguous() ? t : t.contiguous();
+}
+float* fp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
+
+Tensor empty_bytes(size_t n, const Tensor& like) {
+  return at::empty({(int64_t)(n > 0 ? n : 1)}, like.options().dtype(at::kByte));
+}
+
+// ---- the gate flags of the most recent posed backward, for the optimizer (see adam_step).
+// mi355gs_posed_backward leaves "gradient of group k has a non-zero element" flags behind its gradient records.  The
+// optimizer may use them instead of re-reading all gradients only for tensors that are PROVABLY the ones that call wrote:
+// same storage object (kept alive only weakly here), offset 0, never modified since (the version counter autograd's
+// .grad shares with the tensor this node returned is where the node left it; an accumulation into an existing .grad bumps
+// it, a clone has another storage).
+struct GateRecord {
+  Tensor scratch;  // keeps the flags alive (they live in the backward's gradient scratch)
+  const float* gate = nullptr;
+  std::vector<c10::weak_intrusive_ptr<c10::StorageImpl>> storage;   // the seven gradient tensors' storages, group order
+  int64_t numel[7] = {0, 0, 0, 0, 0, 0, 0};
+  int64_t version[7] = {0, 0, 0, 0, 0, 0, 0};   // as handed to autograd (zeros_like leaves 1, empty_like 0)
+  bool valid = false;
+};
+std::mutex g_gate_mutex;
+GateRecord g_gates;
+
+// ------------------------------------------------------------------------------------------------
+// render()'s differentiable body: raw GaussianModel tensors + the 7-vector camera pose in, image out
+// (reference gaussian_renderer/__init__.py:81-135; the Python twin is instantsplat_amd/fused.py::_RenderPosed)
+// ------------------------------------------------------------------------------------------------
+struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
+  static variable_list forward(AutogradContext* ctx, Tensor xyz_, Tensor rot_, Tensor scaling_, Tensor opl_, Tensor f_dc_,
+                               Tensor f_rest_, Tensor pose_, Tensor means2D, Tensor bg_, Tensor view_, Tensor proj_, Tensor origin_,
+                               int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t D,
+                               int64_t capacity, Tensor count_slot) {
+    TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    (void)means2D;  // its VALUE is never read (the reference's viewspace_points dummy); it only receives a gradient
+    const Tensor xyz = f32c(xyz_, "xyz", xyz_), rot = f32c(rot_, "rotation", xyz), scaling = f32c(scaling_, "scaling", xyz),
+                 opl = f32c(opl_, "opacity", xyz), f_dc = f32c(f_dc_, "features_dc", xyz), f_rest = f32c(f_rest_, "features_rest", xyz),
+                 pose = f32c(pose_, "camera_pose", xyz), bg = f32c(bg_, "bg", xyz), view = f32c(view_, "viewmatrix", xyz),
+                 proj = f32c(proj_, "projmatrix", xyz), origin = f32c(origin_, "campos", xyz);
+    TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "means3D must have dimensions (num_points, 3)");
+    TORCH_CHECK(count_slot.scalar_type() == at::kInt && count_slot.numel() == 1, "count_slot must be one int32");
+    const int P = (int)xyz.size(0);
+    const DeviceScope dev(xyz);
+    Tensor radii = at::empty({P}, xyz.options().dtype(at::kInt));
+    Tensor color = at::empty({3, H, W}, xyz.options());
+    Tensor geom = empty_bytes(g_abi.geom_bytes(P), xyz), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), xyz);
+    int32_t* count = count_slot.data_ptr<int32_t>();  // pinned host memory the tile-scan kernel stores into (a CPU word under emulation)
+    check(g_abi.posed_forward_preprocess(dev.stream, P, (int)D, (int)W, (int)H, fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling),
+                                         (float)scale_modifier, fp(rot), fp(pose), fp(view), fp(proj), fp(origin), (float)tanfovx,
+                                         (float)tanfovy, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count, 0),
+          "posed_forward_preprocess");
+    int64_t R = capacity;
+    if (R < 0) {
+      // the reference operator's own blocking read-back of the instance count — without its device-to-host copy: the kernel
+      // has stored the value in host memory, the host only waits for the stream
+      dev.synchronize(xyz);
+      R = *reinterpret_cast<volatile int32_t*>(count);
+    }
+    Tensor binning = empty_bytes(g_abi.binning_bytes(R, (int)W, (int)H), xyz);
+    check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, R, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(),
+                               fp(color), 0),
+          "raster_forward_render");
+    ctx->saved_data["dims"] = std::vector<int64_t>{P, D, W, H, R};
+    ctx->saved_data["scalars"] = std::vector<double>{tanfovx, tanfovy, scale_modifier};
+    ctx->save_for_backward({xyz, rot, scaling, opl, f_dc, f_rest, pose, radii, geom, tiles, binning, bg, view, proj, origin, color});
+    ctx->mark_non_differentiable({radii});
+    return {color, radii};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &xyz = saved[0], &rot = saved[1], &scaling = saved[2], &opl = saved[3], &f_dc = saved[4], &f_rest = saved[5],
+                 &pose = saved[6], &radii = saved[7], &geom = saved[8], &tiles = saved[9], &binning = saved[10], &bg = saved[11],
+                 &view = saved[12], &proj = saved[13], &origin = saved[14], &color = saved[15];
+    const auto dims = ctx->saved_data["dims"].toIntVector();
+    const auto sc = ctx->saved_data["scalars"].toDoubleVector();
+    const int P = (int)dims[0], D = (int)dims[1], W = (int)dims[2], H = (int)dims[3];
+    const int64_t R = dims[4];
+    const Tensor g = f32c(grad_out[0], "grad_color", xyz);
+    const DeviceScope dev(xyz);
+    Tensor d_xyz = at::empty_like(xyz), d_rot = at::empty_like(rot), d_scaling = at::empty_like(scaling), d_opl = at::empty_like(opl),
+           d_fdc = at::empty_like(f_dc), d_m2d = at::empty_like(xyz);
+    // below its SH degree f_rest gets the all-zero gradient cat(f_dc, f_rest) would give it (the optimizer then takes
+    // PerPointAdam's zero-gradient step on it, as in the reference)
+    Tensor d_frest = D == 0 ? at::zeros_like(f_rest) : at::empty_like(f_rest);
+    Tensor d_pose = at::empty({7}, xyz.options());
+    Tensor scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
+    Tensor pose_scratch = at::empty({16 * (((int64_t)P + 255) / 256) + 32}, xyz.options());
+    check(g_abi.posed_backward(dev.stream, P, D, W, H, fp(bg), fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling), (float)sc[2], fp(rot),
+                               fp(pose), fp(view), fp(proj), fp(origin), (float)sc[0], (float)sc[1], geom.data_ptr(), tiles.data_ptr(),
+                               binning.data_ptr(), R, radii.data_ptr<int32_t>(), fp(color), fp(g), scratch.data_ptr(), fp(pose_scratch),
+                               fp(d_xyz), fp(d_m2d), fp(d_fdc), D ? fp(d_frest) : nullptr, fp(d_opl), fp(d_scaling), fp(d_rot), fp(d_pose),
+                               0),
+          "posed_backward");
+    {
+      std::lock_guard<std::mutex> lock(g_gate_mutex);
+      const Tensor* outs[7] = {&d_xyz, &d_fdc, &d_frest, &d_opl, &d_scaling, &d_rot, &d_pose};   // the optimizer's group order
+      g_gates.storage.clear();
+      for (int k = 0; k < 7; ++k) {
+        g_gates.storage.push_back(outs[k]->storage().getWeakStorageImpl());
+        g_gates.numel[k] = outs[k]->numel();
+        g_gates.version[k] = (int64_t)outs[k]->_version();
+      }
+      g_gates.scratch = scratch;
+      g_gates.gate = reinterpret_cast<const float*>(static_cast<const char*>(scratch.data_ptr()) + g_abi.grad_gate_offset(P));
+      g_gates.valid = true;
+    }
+    Tensor none;
+    return {d_xyz, d_rot, d_scaling, d_opl, d_fdc, d_frest, d_pose, d_m2d, none, none, none, none,
+            none, none, none, none, none, none, none, none};
+  }
+};
+
+std::vector<Tensor> render_posed(Tensor xyz, Tensor rot, Tensor scaling, Tensor opl, Tensor f_dc, Tensor f_rest, Tensor pose,
+                                 Tensor means2D, Tensor bg, Tensor view, Tensor proj, Tensor origin, int64_t H, int64_t W,
+                                 double tanfovx, double tanfovy, double scale_modifier, int64_t D, int64_t capacity, Tensor count_slot) {
+  return RenderPosedFn::apply(xyz, rot, scaling, opl, f_dc, f_rest, pose, means2D, bg, view, proj, origin, H, W, tanfovx, tanfovy,
+                              scale_modifier, D, capacity, count_slot);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1 - lambda) * L1 + lambda * (1 - SSIM) and its gradient from one pass over the images
+// (reference train.py:171-176; the Python twin is fused_ssim/__init__.py::_FusedL1SSIM)
+// ------------------------------------------------------------------------------------------------
+struct L1SsimLossFn : public torch::autograd::Function<L1SsimLossFn> {
+  static variable_list forward(AutogradContext* ctx, Tensor img1, Tensor img2, double lambda_dssim) {
+    TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    const Tensor a = f32c(img1, "img1", img1), b = f32c(img2, "img2", a);
+    TORCH_CHECK(a.dim() == 4 && a.sizes() == b.sizes(), "fused_ssim expects two [B,C,H,W] tensors of equal shape");
+    const int B = (int)a.size(0), C = (int)a.size(1), H = (int)a.size(2), W = (int)a.size(3);
+    const DeviceScope dev(a);
+    Tensor scratch = empty_bytes(g_abi.ssim_scratch_bytes(B, C, H, W), a);
+    Tensor out = at::empty({2}, a.options());   // [ssim_mean, l1_mean]
+    Tensor loss = at::empty({}, a.options());
+    Tensor grad = at::empty_like(a);
+    check(g_abi.l1_ssim_loss_fused(dev.stream, B, C, H, W, fp(a), fp(b), scratch.data_ptr(), (float)lambda_dssim, fp(out), fp(out) + 1,
+                                   fp(loss), fp(grad)),
+          "l1_ssim_loss_fused");
+    ctx->save_for_backward({grad});
+    ctx->mark_non_differentiable({out});
+    return {loss, out};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const auto saved = ctx->get_saved_variables();
+    Tensor none;
+    return {saved[0] * grad_out[0], none, none};
+  }
+};
+
+std::vector<Tensor> l1_ssim_loss(Tensor img1, Tensor img2, double lambda_dssim) { return L1SsimLossFn::apply(img1, img2, lambda_dssim); }
+
+// ------------------------------------------------------------------------------------------------
+// PerPointAdam.step over a fixed set of tensors (reference scene/per_point_adam.py:34-100; Python twin: optim.py)
+// ------------------------------------------------------------------------------------------------
+struct AdamPlan {
+  std::vector<Tensor> params, exp_avg, exp_avg_sq, pplr;  // pplr[t] undefined: no per-point multiplier
+  std::vector<int64_t> numel;
+  std::vector<int32_t> row;
+  double beta1, beta2, eps;
+  int64_t last_used_gates = 0;   // diagnostics: tensors of the last step that took a gate flag of the posed backward
+  std::string last_gate_note;    // diagnostics: why a tensor of the last step did not qualify
+
+  AdamPlan(std::vector<Tensor> p, std::vector<Tensor> m, std::vector<Tensor> v, std::vector<c10::optional<Tensor>> pp, double b1, double b2,
+           double e)
+      : params(std::move(p)), exp_avg(std::move(m)), exp_avg_sq(std::move(v)), beta1(b1), beta2(b2), eps(e) {
+    const size_t n = params.size();
+    TORCH_CHECK(n >= 1 && n <= 8 && exp_avg.size() == n && exp_avg_sq.size() == n && pp.size() == n, "AdamPlan: 1..8 tensors, equal-length lists");
+    for (size_t t = 0; t < n; ++t) {
+      const Tensor& q = params[t];
+      TORCH_CHECK(q.scalar_type() == at::kFloat && q.is_contiguous(), "AdamPlan: parameters must be contiguous float32");
+      for (const Tensor* s : {&exp_avg[t], &exp_avg_sq[t]})
+        TORCH_CHECK(s->scalar_type() == at::kFloat && s->is_contiguous() && s->device() == q.device() && s->numel() == q.numel(),
+                    "AdamPlan: moments must match their parameter");
+      numel.push_back(q.numel());
+      if (pp[t].has_value() && pp[t]->defined()) {
+        const Tensor& l = *pp[t];
+        TORCH_CHECK(l.scalar_type() == at::kFloat && l.is_contiguous() && l.device() == q.device() && q.dim() >= 1 && q.size(0) > 0 &&
+                        l.numel() == q.size(0),
+                    "AdamPlan: per_point_lr must hold one contiguous float32 per point");
+        pplr.push_back(l);
+        row.push_back((int32_t)(q.numel() / q.size(0)));
+      } else {
+        pplr.emplace_back();
+        row.push_back(1);
+      }
+    }
+  }
+
+  // grads[t]: the tensor's .grad; lr[t], step[t] (1-based, already incremented by the caller)
+  void step(const std::vector<Tensor>& grads, const std::vector<double>& lr, const std::vector<int64_t>& step) {
+    const size_t n = params.size();
+    TORCH_CHECK(grads.size() == n && lr.size() == n && step.size() == n, "AdamPlan.step: list lengths");
+    const DeviceScope dev(params[0]);
+    int64_t nm[8]; int32_t rw[8], st[8], gidx[8];
+    float* pp[8]; const float* gg[8]; float* mm[8]; float* vv[8]; const float* ll[8]; float lrs[8];
+    std::vector<Tensor> keep;
+    int64_t n_flagged = 0;
+    GateRecord rec;
+    {
+      std::lock_guard<std::mutex> lock(g_gate_mutex);
+      rec = g_gates;
+    }
+    for (size_t t = 0; t < n; ++t) {
+      Tensor g = grads[t];
+      TORCH_CHECK(g.defined() && g.numel() == numel[t] && g.device() == params[t].device(), "AdamPlan.step: gradient ", t, " does not match its parameter");
+      bool mine = false;
+      if (rec.valid && g.scalar_type() == at::kFloat && g.is_contiguous() && g.storage_offset() == 0) {
+        const c10::StorageImpl* impl = g.storage().unsafeGetStorageImpl();
+        for (int k = 0; k < (int)rec.storage.size() && !mine; ++k) {
+          auto strong = rec.storage[k].lock();
+          if (strong && strong.get() == impl && rec.numel[k] == g.numel() && rec.version[k] == (int64_t)g._version()) { gidx[t] = k; mine = true; }
+        }
+      }
+      if (!mine) {
+        std::ostringstream why;
+        why << "tensor " << t << ": record " << (rec.valid ? "valid" : "absent") << ", offset " << g.storage_offset() << ", version " << g._version()
+            << ", storage " << (const void*)g.storage().unsafeGetStorageImpl() << ", numel " << g.numel();
+        last_gate_note = why.str();
+      }
+      if (!mine) gidx[t] = -1;   // the library sums this tensor's squared gradient itself
+      n_flagged += mine ? 1 : 0;
+      if (g.scalar_type() != at::kFloat || !g.is_contiguous()) { g = g.to(at::kFloat).contiguous(); keep.push_back(g); }
+      nm[t] = numel[t]; rw[t] = row[t]; st[t] = (int32_t)step[t]; lrs[t] = (float)lr[t];
+      pp[t] = params[t].data_ptr<float>(); gg[t] = g.data_ptr<float>(); mm[t] = exp_avg[t].data_ptr<float>();
+      vv[t] = exp_avg_sq[t].data_ptr<float>(); ll[t] = pplr[t].defined() ? pplr[t].data_ptr<float>() : nullptr;
+    }
+    const bool gated = n_flagged > 0;
+    Tensor scratch;
+    if (n_flagged < (int64_t)n) scratch = at::empty({8}, params[0].options());
+    last_used_gates = n_flagged;
+    check(g_abi.adam_multi_step(dev.stream, (int)n, nm, rw, pp, gg, mm, vv, ll, lrs, (float)beta1, (float)beta2, (float)eps, st,
+                                scratch.defined() ? scratch.data_ptr<float>() : nullptr, gated ? rec.gate : nullptr, gated ? gidx : nullptr),
+          "adam_multi_step");
+  }
+};
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "compiled PyTorch binding of libmi355gs.so's drop-in operators (no compute of its own)";
+  m.def("bind", &bind_abi, "hand over the C-ABI entry points (name -> address) of the loaded libmi355gs build");
+  m.def("render_posed", &render_posed);
+  m.def("l1_ssim_loss", &l1_ssim_loss);
+  m.def("forget_gates", []() { std::lock_guard<std::mutex> lock(g_gate_mutex); g_gates = GateRecord(); });
+  py::class_<AdamPlan>(m, "AdamPlan")
+      .def(py::init<std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, std::vector<c10::optional<Tensor>>, double, double, double>())
+      .def("step", &AdamPlan::step)
+      .def_readonly("last_used_gates", &AdamPlan::last_used_gates)
+      .def_readonly("last_gate_note", &AdamPlan::last_gate_note);
+}

@@ -56,6 +56,17 @@ def last_frame_stats():
     return int(r), int(reff)
 
 
+class _Pending:
+    """One frame rendered without reading its instance count back (BinningPolicy mode "bounded")."""
+    __slots__ = ("ev", "slot", "capacity", "key", "tag", "hold", "dev")
+
+    def __init__(self, ev, slot, capacity, key, tag, hold=None, dev=None):
+        # ev: a torch.cuda.Event recorded behind the frame's tile scan; None: already complete (CPU / emulated kernels);
+        # "stream": no event was recorded — the caller orders the count by synchronising `dev`'s current stream itself
+        # (RunAhead's window read-back), so only a BLOCKING poll may look at the slot.
+        self.ev, self.slot, self.capacity, self.key, self.tag, self.hold, self.dev = ev, slot, capacity, key, tag, hold, dev
+
+
 class BinningPolicy:
     """How a frame's instance buffer is sized.
 
@@ -67,35 +78,73 @@ class BinningPolicy:
         exceeded its capacity (those frames dropped instances and everything computed from them is invalid —
         instantsplat_amd.train rolls back to its last verified snapshot and replays them in exact mode).
         Frames without a hint, or with an unknown key, use the exact path.
+
+    Process-wide state (one policy, one `known` table, one pending list): right for the deployment this package is
+    built for — one process per GPU, one scene per process — and a trap for two scenes in one process, which must use
+    distinct hint keys and poll together.
     """
     mode = "exact"
     slack = 1.5
     pad = 16384
     known = {}       # key -> last verified R
-    pending = []     # (event, pinned int32[1], capacity, key, tag)
+    pending = []     # _Pending
     current_key = None
     current_tag = None
 
     @classmethod
     def reset(cls, mode="exact"):
+        for e in cls.pending:
+            _release_slot(e)
         cls.mode, cls.known, cls.pending, cls.current_key, cls.current_tag = mode, {}, [], None, None
+
+    @classmethod
+    def deferred_capacity(cls):
+        """Capacity for the frame about to be rendered if its count will NOT be read back (bounded mode, hinted key with a
+        known count); None: the exact path."""
+        key = cls.current_key
+        if cls.mode == "bounded" and key is not None and key in cls.known:
+            return int(cls.slack * cls.known[key]) + cls.pad
+        return None
+
+    @classmethod
+    def defer(cls, slot, capacity, dev, event=True):
+        """Queue the frame whose tile scan was just enqueued on `dev`'s current stream for later verification."""
+        ev = None
+        if dev is not None and dev.type == "cuda":
+            if event:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+            else:
+                ev = "stream"
+        ring = _COUNT_RINGS.get(dev)
+        k = ring.reserved.pop(slot.data_ptr(), None) if ring is not None else None
+        cls.pending.append(_Pending(ev, slot, capacity, cls.current_key, cls.current_tag, None if k is None else (ring, k), dev))
 
     @classmethod
     def poll(cls, block: bool = False):
         """Process finished read-backs; returns the tags of frames that overflowed their capacity."""
-        bad, keep = [], []
-        for ev, pinned, cap, key, tag in cls.pending:
+        bad, keep, synced = [], [], set()
+        for e in cls.pending:
+            ev = e.ev
             if ev is None:
                 pass
+            elif ev == "stream":
+                if not block:   # nothing orders this count yet: its slot may still hold an older frame's value
+                    keep.append(e)
+                    continue
+                if e.dev not in synced:
+                    torch.cuda.current_stream(e.dev).synchronize()
+                    synced.add(e.dev)
             elif block:
                 ev.synchronize()
             elif not ev.query():
-                keep.append((ev, pinned, cap, key, tag))
+                keep.append(e)
                 continue
-            r = int(pinned[0])
-            cls.known[key] = r
-            if r > cap:
-                bad.append(tag)
+            r = int(e.slot[0])
+            cls.known[e.key] = r
+            if r > e.capacity:
+                bad.append(e.tag)
+            _release_slot(e)
         cls.pending = keep
         return bad
 
@@ -121,13 +170,9 @@ def size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, colo
     them and enqueue binning + composite.  Returns (capacity handed to the library, binning scratch)."""
     key = BinningPolicy.current_key
     on_gpu = dev.type == "cuda"   # then `num_rendered` is a slot of pinned host memory the tile-scan kernel stores into (count_slot)
-    if BinningPolicy.mode == "bounded" and key is not None and key in BinningPolicy.known:
-        R = int(BinningPolicy.slack * BinningPolicy.known[key]) + BinningPolicy.pad  # capacity, no host sync
-        ev = None
-        if on_gpu:   # the count is in its slot once this event has completed
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-        BinningPolicy.pending.append((ev, num_rendered, R, key, BinningPolicy.current_tag))
+    R = BinningPolicy.deferred_capacity()
+    if R is not None:
+        BinningPolicy.defer(num_rendered, R, dev)   # capacity from the last verified count, no host sync
     else:
         # the reference operator's own blocking read-back of the count — without its device-to-host copy: the kernel has
         # stored the value in host memory, the host only waits for the stream
@@ -179,20 +224,46 @@ _COUNT_RINGS = {}
 COUNT_RING = 256
 
 
+class _CountRing:
+    """Pinned (device-mapped) host words the tile-scan kernel stores a frame's instance count into — no device-to-host copy
+    is enqueued to read it.  Two halves with different lifetimes:
+      * words [0, COUNT_RING): frames whose count is read back at once (exact mode, inference) — handed out round-robin; the
+        value is consumed before the forward returns, so reuse after COUNT_RING forwards is harmless;
+      * words [COUNT_RING, 2 * COUNT_RING): frames queued in BinningPolicy.pending — a word stays reserved until poll() has
+        read it, however many other forwards run in between."""
+
+    def __init__(self):
+        self.words = torch.zeros(2 * COUNT_RING, dtype=torch.int32, pin_memory=True)
+        self.next = 0
+        self.free = list(range(2 * COUNT_RING - 1, COUNT_RING - 1, -1))
+        self.reserved = {}   # address of a handed-out reserved word -> its index, until BinningPolicy.defer() takes it over
+
+
+def _release_slot(entry):
+    hold = entry.hold
+    if hold is not None:
+        ring, k = hold
+        ring.free.append(k)
+        entry.hold = None
+
+
 def count_slot(dev):
-    """Where the forward leaves the frame's instance count: on the GPU a slot of a ring of pinned (device-mapped) host memory —
-    the tile-scan kernel's 4-byte store goes straight to the host, no device-to-host copy is enqueued to read it — handed out
-    round-robin (a slot is reused after COUNT_RING forwards; BinningPolicy.pending may not grow beyond that)."""
+    """Where the forward leaves the frame's instance count (see _CountRing); on the CPU (emulated kernels) a plain word."""
     if dev.type != "cuda":
         return torch.zeros(1, dtype=torch.int32, device=dev)
     ring = _COUNT_RINGS.get(dev)
     if ring is None:
-        ring = _COUNT_RINGS[dev] = [torch.zeros(COUNT_RING, dtype=torch.int32, pin_memory=True), 0]
-    if len(BinningPolicy.pending) >= COUNT_RING:
+        ring = _COUNT_RINGS[dev] = _CountRing()
+    if BinningPolicy.deferred_capacity() is None:
+        k = ring.next
+        ring.next = (k + 1) % COUNT_RING
+        return ring.words[k:k + 1]
+    if not ring.free:
         raise RuntimeError(f"more unverified frames than count slots: call BinningPolicy.poll() at least every {COUNT_RING} forwards")
-    k = ring[1]
-    ring[1] = (k + 1) % COUNT_RING
-    return ring[0][k:k + 1]
+    k = ring.free.pop()
+    slot = ring.words[k:k + 1]
+    ring.reserved[slot.data_ptr()] = k
+    return slot
 
 
 def _cpu_deep_copy_tuple(input_tuple):

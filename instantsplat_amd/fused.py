@@ -132,9 +132,29 @@ class _RenderPosed(torch.autograd.Function):
 
 
 def render_posed(pc, pose, means2D, settings):
-    """-> (image[3,H,W], radii[P]) for the default pipeline (SH colours of the active degree, scale/rotation covariance)."""
-    return _RenderPosed.apply(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
-                              settings)
+    """-> (image[3,H,W], radii[P]) for the default pipeline (SH colours of the active degree, scale/rotation covariance).
+
+    The node is the compiled one (csrc_torch/binding.cpp: same two C-ABI calls each way, issued from C++) unless the
+    binding is switched to ctypes, the operator's debug mode is on (snapshot dumps are written by the Python node) or
+    bench.py's frame-statistics hook wants the frame's scratch kept."""
+    s = settings
+    ext = None if (s.debug or dgr._KEEP_LAST_FRAME) else _lib.compiled()
+    if ext is None:
+        return _RenderPosed.apply(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
+                                  settings)
+    policy = dgr.BinningPolicy
+    dev = pc._xyz.device
+    slot = dgr.count_slot(dev)
+    cap = policy.deferred_capacity()
+    color, radii = ext.render_posed(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
+                                    s.bg, s.viewmatrix, s.projmatrix, s.campos, int(s.image_height), int(s.image_width),
+                                    float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), int(s.sh_degree),
+                                    -1 if cap is None else cap, slot)
+    if cap is not None:
+        policy.defer(slot, cap, dev)
+    elif policy.current_key is not None:
+        policy.known[policy.current_key] = int(slot[0])
+    return color, radii
 
 
 def sh_features(pc):

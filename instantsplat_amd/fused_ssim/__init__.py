@@ -115,4 +115,7 @@ class _FusedL1SSIM(torch.autograd.Function):
 
 def fused_l1_ssim_loss(img1, img2, lambda_dssim=0.2):
     """Returns (loss, [ssim_mean, l1_mean]); loss = (1-lambda)*L1 + lambda*(1-SSIM) as reference train.py:176."""
+    ext = _lib.compiled()
+    if ext is not None:
+        return ext.l1_ssim_loss(img1, img2, float(lambda_dssim))
     return _FusedL1SSIM.apply(img1, img2, lambda_dssim)

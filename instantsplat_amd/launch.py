@@ -19,6 +19,55 @@ import torch
 import torch.distributed as dist
 
 
+def pin_rank_to_cpu_slice(local_rank: int, local_world: int) -> list:
+    """One process per GPU means N Python hosts on one socket: give each rank its own slice of the CPUs this job may use
+    (sched_setaffinity) and cap its thread pools to it, so that eight eager launch loops do not migrate over and preempt
+    each other — the scaling risk SURVEY.md 8e names is host contention, not the fabric.  Returns the CPUs kept."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:   # not Linux
+        return []
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    per = len(cpus) // local_world
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    n_threads = max(1, min(per, 8))
+    os.environ["OMP_NUM_THREADS"] = str(n_threads)
+    torch.set_num_threads(n_threads)
+    return mine
+
+
+def gather_rank_reports(report: dict) -> list:
+    """all_gather of one small dict per rank (rank 0 prints them); a list of one without a process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, report)
+        return out
+    return [report]
+
+
+def device_identity(dev) -> dict:
+    """What distinguishes this rank's GPU from its neighbours' (index, PCI address / uuid when the runtime exposes them)."""
+    if torch.device(dev).type != "cuda":
+        return {"device": str(dev)}
+    props = torch.cuda.get_device_properties(dev)
+    ident = {"device": str(dev), "name": props.name}
+    for attr in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(props, attr, None)
+        if v is not None:
+            ident[attr] = str(v)
+    return ident
+
+
+def assert_one_rank_per_device(reports: list, device_count: int):
+    """With at least as many GPUs as ranks, two ranks on one device is a launcher bug that would silently halve the
+    measured scaling: refuse it."""
+    seen = [r["gpu"].get("uuid") or r["gpu"].get("pci_bus_id") or r["gpu"]["device"] for r in reports]
+    if device_count >= len(reports) and len(set(seen)) != len(seen):
+        raise RuntimeError(f"ranks share a GPU although {device_count} are visible: {seen}")
+
+
 def reduce_scene_metrics(psnr: float, n_images: int, iterations: int, seconds: float, device) -> dict:
     """SUM-reduce [psnr*n_images, n_images, iterations, 1] and MAX-reduce [seconds] over all ranks."""
     s = torch.tensor([psnr * n_images, float(n_images), float(iterations), 1.0], dtype=torch.float64, device=device)
@@ -40,9 +89,12 @@ def main():
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cpus = pin_rank_to_cpu_slice(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    reports = gather_rank_reports({"rank": rank, "gpu": device_identity(dev), "cpus": len(cpus)})
+    assert_one_rank_per_device(reports, torch.cuda.device_count())
     from .synthetic import syn_pointmap
     from .train import training
     scene = syn_pointmap(3, args.pointmap, args.pointmap, args.res, args.res, seed=rank)  # scene i -> rank i

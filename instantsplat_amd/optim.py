@@ -178,8 +178,21 @@ class PerPointAdam(Optimizer):
             return loss
         L = _lib.lib()
         f32 = torch.float32
+        ext = _lib.compiled()
         for b in self._plan_for(live)["batches"]:
             dev = b["dev"]
+            if ext is not None and not any(group["weight_decay"] != 0 for group in b["groups"]):
+                # compiled binding: the same library call from C++ (csrc_torch/binding.cpp AdamPlan), which also recognises
+                # gradients that are exactly the tensors the last render backward wrote and then takes that call's gate flags
+                # instead of launching the pass over all gradients
+                plan = b.get("compiled")
+                if plan is None or b.get("compiled_ext") is not ext:
+                    b1, b2, eps = b["hyper"]
+                    plan = b["compiled"] = ext.AdamPlan([p.data for p in b["params"]], [s_["exp_avg"] for s_ in b["states"]],
+                                                        [s_["exp_avg_sq"] for s_ in b["states"]], b["keep"], b1, b2, eps)
+                    b["compiled_ext"] = ext
+                plan.step([p.grad for p in b["params"]], [group["lr"] for group in b["groups"]], [s_["step"] for s_ in b["states"]])
+                continue
             ptrs = []
             keep = []
             for group, p in zip(b["groups"], b["params"]):
@@ -199,5 +212,5 @@ class PerPointAdam(Optimizer):
                 _lib.check(L.mi355gs_adam_multi_step(
                     _lib.stream_ptr(dev), b["n"], b["numel"], b["row"], b["p"], b["PTR"](*ptrs), b["m"], b["v"],
                     b["pplr"], b["F32"](*[group["lr"] for group in b["groups"]]), b1, b2, eps,
-                    b["I32"](*[s_["step"] for s_ in b["states"]]), scratch.data_ptr()), "adam_multi_step")
+                    b["I32"](*[s_["step"] for s_ in b["states"]]), scratch.data_ptr(), None, None), "adam_multi_step")
         return loss

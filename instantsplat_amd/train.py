@@ -321,11 +321,8 @@ class FusedTrainer:
             return cam
         # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy): the count is in its
         # pinned slot once the event recorded behind the step has completed
-        ev = None
-        if self.dev.type == "cuda" and record_event:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.dev))
-        BinningPolicy.pending.append((ev, count_out, self.capacity, ("train", cam.uid), it))
+        with binning_hint(("train", cam.uid), tag=it):
+            BinningPolicy.defer(count_out, self.capacity, self.dev, event=record_event)
         return cam
 
     def apply_optimizer(self):

@@ -317,3 +317,88 @@ def check_operator_error_behaviour(dev, tmp_path):
     # and the valid call still works afterwards
     color, radii = r(means3D=means, means2D=m2d, opacities=op, shs=shs, scales=scales, rotations=rots)
     assert color.shape == (3, 32, 48) and radii.shape == (64,) and bool(torch.isfinite(color).all())
+
+
+def check_tile_lists_against_oracle(dev, n, W=80, H=48, seed=5):
+    """The binning stage against the ORACLE's lists (SURVEY.md 8d asked for num_rendered within 0.01 %; the device bins to
+    a tighter rectangle on purpose, preprocess.hip "tight tile rects", so the property is stated exactly instead):
+      * every per-tile list of the device is a SUBSET of the oracle's list of that tile (the reference's 3-sigma rectangle),
+        in the same relative order (depth, then index);
+      * every instance the device dropped has alpha < 1/255 at every pixel of that tile — it could not have been blended,
+        so image, n_contrib-as-a-set and all gradients are unaffected by dropping it;
+      * no instance is dropped that reaches alpha >= 1/255 anywhere (the same statement, from the other side)."""
+    from instantsplat_amd import _lib
+    from instantsplat_amd.camera import Camera
+    from oracle import gs_ref
+    from oracle.raster_torch import RasterSettings
+    import numpy as np
+    dev = torch.device(dev)
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(seed)
+    z = 2.0 + 4.0 * torch.rand(n, generator=g)
+    means = torch.stack([0.6 * (2 * torch.rand(n, generator=g) - 1) * z, 0.4 * (2 * torch.rand(n, generator=g) - 1) * z, z], dim=1)
+    q = torch.randn(n, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    # a mix of sizes and opacities: faint large Gaussians are the ones whose 3-sigma rectangle is much larger than their
+    # alpha >= 1/255 footprint
+    scales = 0.01 + 0.08 * torch.rand(n, 3, generator=g) ** 2
+    opac = 0.005 + 0.9 * torch.rand(n, generator=g) ** 3
+    col = torch.rand(n, 3, generator=g)
+    tanx = math.tan(math.radians(60) / 2)
+    tany = tanx * H / W
+    cam = Camera(0, torch.eye(4), math.radians(60), 2 * math.atan(tany), W, H)
+    t = lambda x: x.float().contiguous().to(dev)
+    d_means, d_q, d_scales, d_opac, d_col = map(t, (means, q, scales, opac, col))
+    view, proj, campos = t(torch.eye(4).reshape(-1)), t(cam.projection_matrix.reshape(-1)), t(torch.zeros(3))
+    geom = torch.zeros(L.mi355gs_raster_geom_bytes(n), dtype=torch.uint8, device=dev)
+    tiles = torch.zeros(L.mi355gs_raster_tiles_bytes(W, H), dtype=torch.uint8, device=dev)
+    radii = torch.zeros(n, dtype=torch.int32, device=dev)
+    nr = torch.zeros(1, dtype=torch.int32, device=dev)
+    p, stream = _lib.ptr, _lib.stream_ptr(dev)
+    _lib.check(L.mi355gs_raster_forward_preprocess(stream, n, 0, 0, W, H, p(d_means), None, None, p(d_col), p(d_opac), p(d_scales), 1.0,
+                                                   p(d_q), None, p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles),
+                                                   p(nr), 0), "preprocess")
+    R = int(nr.item())
+    binning = torch.zeros(L.mi355gs_raster_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+    img, bg = torch.zeros(3, H, W, device=dev), torch.zeros(3, device=dev)
+    _lib.check(L.mi355gs_raster_forward_render(stream, n, W, H, R, p(bg), p(geom), p(tiles), p(binning), p(img), 0), "render")
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T, al = gx * gy, (lambda x: (x + 255) & ~255)
+    start = tiles[2 * al(T * 4): 2 * al(T * 4) + (T + 1) * 4].cpu().view(torch.int32).numpy()
+    lst = binning[al(R * 8): al(R * 8) + R * 4].cpu().view(torch.int32).numpy()
+    rec = geom[: n * 48].cpu().view(torch.float32).reshape(n, 12).numpy().astype(np.float64)
+
+    settings = RasterSettings(image_height=H, image_width=W, tanfovx=tanx, tanfovy=tany, bg=torch.zeros(3), scale_modifier=1.0,
+                              viewmatrix=torch.eye(4), projmatrix=cam.projection_matrix.cpu(), sh_degree=0, campos=torch.zeros(3),
+                              prefiltered=False, debug=False)
+    _, radii_ref, ctx = gs_ref.forward(means, opac, settings, colors_precomp=col, scales=scales, rotations=q)
+    aux = ctx.aux(W, H)
+    o_start, o_list = aux["tile_start"].numpy(), aux["list"].numpy()
+    R_ref = ctx.num_rendered
+    assert start[0] == 0 and start[T] == R and 0 < R <= R_ref
+    dropped = kept = 0
+    worst = 0.0
+    for tile in range(T):
+        mine = lst[start[tile]:start[tile + 1]]
+        theirs = o_list[o_start[tile]:o_start[tile + 1]]
+        in_mine = np.isin(theirs, mine)
+        assert len(np.unique(mine)) == len(mine) and bool(np.isin(mine, theirs).all()), tile       # subset of the reference's list
+        assert bool((theirs[in_mine] == mine).all()), tile                                          # same relative order
+        gone = theirs[~in_mine]
+        kept += len(mine)
+        dropped += len(gone)
+        if len(gone) == 0:
+            continue
+        tx, ty = tile % gx, tile // gx
+        xs = np.arange(tx * 16, min(tx * 16 + 16, W), dtype=np.float64)
+        ys = np.arange(ty * 16, min(ty * 16 + 16, H), dtype=np.float64)
+        r = rec[gone]   # x, y, hx, hy | A, C, B (log2-scaled conic), opacity | r, g, b, depth
+        dx = r[:, 0, None, None] - xs[None, None, :]
+        dy = r[:, 1, None, None] - ys[None, :, None]
+        power2 = r[:, 4, None, None] * dx * dx + r[:, 5, None, None] * dy * dy + r[:, 6, None, None] * dx * dy
+        alpha = r[:, 7, None, None] * np.exp2(np.minimum(power2, 0.0))
+        alpha = np.where(power2 > 0, 0.0, alpha)
+        worst = max(worst, float(alpha.max()))
+        assert float(alpha.max()) < 1.0 / 255.0, (tile, float(alpha.max()))
+    assert kept == R and kept + dropped == R_ref
+    return R, R_ref, worst

@@ -838,3 +838,119 @@ def check_checkpoint_save_and_resume(dev, tmp_path, Wm=10, W=24):
     assert float((r3["state"].gaussians._xyz.detach().cpu() - ck_params[1].detach().cpu()).abs().max()) > 0
     steps = [int(r3["state"].gaussians.optimizer.state[p]["step"]) for p in (r3["state"].gaussians._xyz, r3["state"].gaussians.P)]
     assert steps == [8, 8]   # 6 restored + iterations 7 and 8 (the last iteration, 9, skips the optimizer)
+
+
+# ---- compiled PyTorch binding (instantsplat_amd/csrc_torch/binding.cpp) ---------------------------------------------
+def _with_binding(name):
+    import contextlib
+    from instantsplat_amd import _lib
+
+    @contextlib.contextmanager
+    def cm():
+        prev, _lib.BINDING = _lib.BINDING, name
+        try:
+            yield
+        finally:
+            _lib.BINDING = prev
+    return cm()
+
+
+def check_compiled_binding_equals_ctypes(dev, iters=5, Wm=12, W=40, H=32):
+    """The drop-in loop (train_iteration: render -> loss -> backward -> loss.item() -> PerPointAdam.step) through the compiled
+    binding vs through the ctypes / Python autograd.Function binding: the same C-ABI calls with the same arguments, so under
+    the emulator (deterministic atomics) every loss and parameter is bit-identical; on the GPU to float-atomic order.  Also
+    the statement that the compiled Adam took the backward's gate flags for the six tensors the backward writes directly
+    (the pose table's gradient is scattered by autograd from one row and is summed by the library) — and that a run in
+    which f_rest is gated off (degree 0), trained (degree 1) and gated off again keeps matching."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training, train_iteration
+    sc = syn_pointmap(3, Wm, Wm, W, H, seed=21)
+    cuda = torch.device(dev).type == "cuda"
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
+    res = {}
+    try:
+        for binding in ("ctypes", "compiled"):
+            with _with_binding(binding):
+                st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+                losses = []
+                for degree in [0] * iters + [1, 1, 0, 0]:
+                    st.gaussians.active_sh_degree = degree
+                    losses.append(train_iteration(st))
+                g = st.gaussians
+                res[binding] = (losses, {n: getattr(g, n).detach().cpu().clone() for n in names},
+                                {n: g.optimizer.state[getattr(g, n)]["exp_avg_sq"].detach().cpu().clone() for n in names})
+                if binding == "compiled":
+                    plans = [b["compiled"] for pl in g.optimizer._plans.values() for b in pl["batches"] if "compiled" in b]
+                    assert plans and all(p.last_used_gates == 6 for p in plans), [(p.last_used_gates, p.last_gate_note) for p in plans]
+            BinningPolicy.reset("exact")
+        for a_, b_ in zip(res["ctypes"][0], res["compiled"][0]):
+            bound("compiled_vs_ctypes/loss", abs(a_ - b_) / max(abs(a_), 1e-6), 2e-4 if cuda else 0.0)
+        for n in names:
+            for k, what in ((1, "param"), (2, "exp_avg_sq")):
+                bound("compiled_vs_ctypes/%s%s" % (what, n), rel_l2(res["compiled"][k][n], res["ctypes"][k][n]),
+                      ((2e-4 if k == 1 else 2e-3) if cuda else 0.0))
+    finally:
+        BinningPolicy.reset("exact")
+
+
+def check_compiled_gate_flags_are_sound(dev, Wm=10, W=32, H=24):
+    """The compiled Adam may take the backward's gate flags only for gradients that are provably the tensors that backward
+    wrote.  Everything else must fall back to summing the gradient: a gradient accumulated over two backward passes, a
+    gradient modified in place (clipping), a gradient replaced by a copy — and in every case the update must equal the
+    ctypes binding's (which always sums)."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.fused_ssim import fused_l1_ssim_loss
+    from instantsplat_amd.gaussian_renderer import render
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training
+    sc = syn_pointmap(2, Wm, Wm, W, H, seed=4)
+    cuda = torch.device(dev).type == "cuda"
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
+
+    def one_backward(st, cam):
+        g = st.gaussians
+        img = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))["render"]
+        loss, _ = fused_l1_ssim_loss(img.unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), st.opt.lambda_dssim)
+        loss.backward()
+
+    def scenario(kind):
+        st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+        g = st.gaussians
+        g.update_learning_rate(1)
+        one_backward(st, st.cameras[0])
+        if kind == "accumulated":
+            one_backward(st, st.cameras[1])
+        elif kind == "clipped":
+            with torch.no_grad():
+                g._xyz.grad.mul_(0.5)
+        elif kind == "replaced":
+            g._opacity.grad = g._opacity.grad.clone()
+        elif kind == "zeroed":   # the flag says "non-zero" for a gradient that has since been zeroed in place
+            with torch.no_grad():
+                g._scaling.grad.zero_()
+        g.optimizer.step()
+        used = None
+        plans = [b.get("compiled") for pl in getattr(g.optimizer, "_plans", {}).values() for b in pl["batches"]]
+        if plans and plans[0] is not None:
+            used = plans[0].last_used_gates
+        return {n: getattr(g, n).detach().cpu().clone() for n in names}, {
+            n: g.optimizer.state[getattr(g, n)]["exp_avg_sq"].detach().cpu().clone() for n in names}, used
+
+    try:
+        expect = {"fresh": 6, "accumulated": 0, "clipped": 5, "replaced": 5, "zeroed": 5}
+        for kind, n_flags in expect.items():
+            with _with_binding("ctypes"):
+                pa, va, _ = scenario(kind)
+            with _with_binding("compiled"):
+                pb, vb, used = scenario(kind)
+            assert used == n_flags, (kind, used)
+            for n in names:
+                bound("compiled_gates/%s/param%s" % (kind, n), rel_l2(pb[n], pa[n]), 2e-4 if cuda else 0.0)
+                bound("compiled_gates/%s/exp_avg_sq%s" % (kind, n), rel_l2(vb[n], va[n]), 2e-3 if cuda else 0.0)
+            if kind == "zeroed":   # Adam's whole-tensor gate: a zeroed gradient must leave the second moment untouched
+                assert float(vb["_scaling"].abs().max()) == 0.0
+    finally:
+        BinningPolicy.reset("exact")

@@ -67,6 +67,16 @@ def test_bench_gpus2_spawns_two_ranks_end_to_end(emu_lib_path):
     assert out["value"] > 0 and abs(out["value"] - 2 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert out["psnr_after_mean"] == out["psnr_after_mean"] and out["psnr_after_mean"] > 5.0
     assert out["config"]["parallelism"] == "scene-per-gpu x2"
+    # what makes the 8-GPU run informative: who ran where, per-rank rates on the rank's own clock, the ranks'
+    # CPU slices, and the line's own N = 1 reference (rank 0 alone on the box) for the scaling efficiency
+    m = out["multi_gpu"]
+    assert m["ranks_seen"] == m["world_size"] == 2 and m["backend"] == "gloo"
+    assert sorted(r["rank"] for r in m["per_rank"]) == [0, 1]
+    assert all(r["iters_per_sec_median_block_own_clock"] > 0 and r["cpus"] >= 1 and "gpu" in r and r["psnr_after"] > 5.0 for r in m["per_rank"])
+    if len(os.sched_getaffinity(0)) >= 2:   # each rank pinned itself to its own slice of the CPUs
+        assert m["per_rank"][0]["first_cpu"] != m["per_rank"][1]["first_cpu"]
+    assert m["solo_rank0_iters_per_sec"] > 0 and m["scaling_efficiency_vs_solo_rank0"] > 0
+    assert out["timed_blocks"] >= 1 and len(out["block_seconds"]) == out["timed_blocks"] and "read-back" in out["loop"]
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

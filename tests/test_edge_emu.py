@@ -205,3 +205,8 @@ def test_render_glue_gradients_match_reference_autograd(emu, monkeypatch):
             assert float((a - b).norm() / b.norm()) <= 2e-5, (fused, name, float((a - b).norm() / b.norm()))
         a, b = pose.grad, T("glue_grad_pose")
         assert float((a - b).norm() / b.norm()) <= 5e-5, (fused, "pose", a, b)
+
+
+def test_tile_lists_are_the_oracles_minus_invisible_instances(emu):
+    R, R_ref, worst = edge_cases.check_tile_lists_against_oracle(emu, 400)
+    assert R < R_ref and worst < 1 / 255

@@ -49,5 +49,13 @@ def test_tile_lists_sorted(gpu, n, longer_than):
     assert edge_cases.check_tile_lists_sorted(gpu, n) > longer_than
 
 
+@pytest.mark.parametrize("n", [400, 5000])
+def test_tile_lists_are_the_oracles_minus_invisible_instances(gpu, n):
+    R, R_ref, worst = edge_cases.check_tile_lists_against_oracle(gpu, n)
+    print("tile lists: device R = %d, oracle (3-sigma rectangles) R = %d, largest alpha of a dropped instance = %.3e (< 1/255 = %.3e)"
+          % (R, R_ref, worst, 1 / 255))
+    assert R < R_ref   # the tighter rectangles do drop instances on this scene, or the test would be vacuous
+
+
 def test_operator_error_behaviour(gpu, tmp_path):
     edge_cases.check_operator_error_behaviour(gpu, tmp_path)

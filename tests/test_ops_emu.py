@@ -141,7 +141,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.mi355gs_abi_version.restype = ctypes.c_int
-    assert lib.mi355gs_abi_version() == 5
+    assert lib.mi355gs_abi_version() == 6
 
 
 def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
@@ -194,3 +194,11 @@ def test_capture_matches_reference_class(emu):
 
 def test_checkpoint_save_and_resume(emu, tmp_path):
     ops_util.check_checkpoint_save_and_resume(emu, tmp_path)
+
+
+def test_compiled_binding_equals_ctypes_binding(emu):
+    ops_util.check_compiled_binding_equals_ctypes(emu)
+
+
+def test_compiled_adam_takes_gate_flags_only_when_sound(emu):
+    ops_util.check_compiled_gate_flags_are_sound(emu)

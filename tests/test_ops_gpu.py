@@ -92,3 +92,11 @@ def test_fused_step_gradients_equal_autograd(gpu, degree):
 
 def test_one_call_train_iterations_match_cpu_oracle(gpu):
     ops_util.check_train_matches_cpu_oracle(gpu, iters=5, Wm=48, W=96, fused_step=True)
+
+
+def test_compiled_binding_equals_ctypes_binding(gpu):
+    ops_util.check_compiled_binding_equals_ctypes(gpu, iters=8, Wm=48, W=128, H=96)
+
+
+def test_compiled_adam_takes_gate_flags_only_when_sound(gpu):
+    ops_util.check_compiled_gate_flags_are_sound(gpu, Wm=32, W=96, H=64)
