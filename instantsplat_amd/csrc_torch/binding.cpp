@@ -12,9 +12,10 @@
 //
 // Built by __graft_entry__.build() -> instantsplat_amd/lib/_mi355gs_torch.so (instantsplat_amd/csrc_torch/build.py).
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // ROCm builds of PyTorch call their HIP devices "cuda"
 #include <c10/hip/HIPStream.h>
 
+#include <chrono>
 #include <mutex>
 
 #include "../../include/mi355gs.h"
@@ -72,7 +73,7 @@ void check(int code, const char* what) {
 // The launches inside the library go to the process's current device: make it the tensors' device for the call, and hand
 // over torch's current stream on it (CPU tensors: the emulated build of the CPU test tier, no stream).
 struct DeviceScope {
-  c10::hip::OptionalHIPGuard guard;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard;
   void* stream = nullptr;
   explicit DeviceScope(const Tensor& t) {
     if (t.is_cuda()) {
@@ -95,6 +96,15 @@ float* fp(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>
 Tensor empty_bytes(size_t n, const Tensor& like) {
   return at::empty({(int64_t)(n > 0 ? n : 1)}, like.options().dtype(at::kByte));
 }
+
+// ---- host-time accounting of the nodes (diagnostics for tools/host_timeline.py: where does an iteration's host time go?)
+struct HostClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double* acc;
+  explicit HostClock(double* a) : acc(a) {}
+  ~HostClock() { *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+};
+double g_host_us[6] = {0, 0, 0, 0, 0, 0};   // render fwd, render bwd, loss fwd, loss bwd, adam step, render fwd's wait for the count
 
 // ---- the gate flags of the most recent posed backward, for the optimizer (see adam_step).
 // mi355gs_posed_backward leaves "gradient of group k has a non-zero element" flags behind its gradient records.  The
@@ -123,6 +133,7 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
                                int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t D,
                                int64_t capacity, Tensor count_slot) {
     TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    HostClock clock(&g_host_us[0]);
     (void)means2D;  // its VALUE is never read (the reference's viewspace_points dummy); it only receives a gradient
     const Tensor xyz = f32c(xyz_, "xyz", xyz_), rot = f32c(rot_, "rotation", xyz), scaling = f32c(scaling_, "scaling", xyz),
                  opl = f32c(opl_, "opacity", xyz), f_dc = f32c(f_dc_, "features_dc", xyz), f_rest = f32c(f_rest_, "features_rest", xyz),
@@ -144,6 +155,7 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     if (R < 0) {
       // the reference operator's own blocking read-back of the instance count — without its device-to-host copy: the kernel
       // has stored the value in host memory, the host only waits for the stream
+      HostClock wait_clock(&g_host_us[5]);
       dev.synchronize(xyz);
       R = *reinterpret_cast<volatile int32_t*>(count);
     }
@@ -159,6 +171,7 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    HostClock clock(&g_host_us[1]);
     const auto saved = ctx->get_saved_variables();
     const Tensor &xyz = saved[0], &rot = saved[1], &scaling = saved[2], &opl = saved[3], &f_dc = saved[4], &f_rest = saved[5],
                  &pose = saved[6], &radii = saved[7], &geom = saved[8], &tiles = saved[9], &binning = saved[10], &bg = saved[11],
@@ -216,6 +229,7 @@ std::vector<Tensor> render_posed(Tensor xyz, Tensor rot, Tensor scaling, Tensor 
 struct L1SsimLossFn : public torch::autograd::Function<L1SsimLossFn> {
   static variable_list forward(AutogradContext* ctx, Tensor img1, Tensor img2, double lambda_dssim) {
     TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    HostClock clock(&g_host_us[2]);
     const Tensor a = f32c(img1, "img1", img1), b = f32c(img2, "img2", a);
     TORCH_CHECK(a.dim() == 4 && a.sizes() == b.sizes(), "fused_ssim expects two [B,C,H,W] tensors of equal shape");
     const int B = (int)a.size(0), C = (int)a.size(1), H = (int)a.size(2), W = (int)a.size(3);
@@ -232,6 +246,7 @@ struct L1SsimLossFn : public torch::autograd::Function<L1SsimLossFn> {
     return {loss, out};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    HostClock clock(&g_host_us[3]);
     const auto saved = ctx->get_saved_variables();
     Tensor none;
     return {saved[0] * grad_out[0], none, none};
@@ -281,6 +296,7 @@ struct AdamPlan {
   void step(const std::vector<Tensor>& grads, const std::vector<double>& lr, const std::vector<int64_t>& step) {
     const size_t n = params.size();
     TORCH_CHECK(grads.size() == n && lr.size() == n && step.size() == n, "AdamPlan.step: list lengths");
+    HostClock clock(&g_host_us[4]);
     const DeviceScope dev(params[0]);
     int64_t nm[8]; int32_t rw[8], st[8], gidx[8];
     float* pp[8]; const float* gg[8]; float* mm[8]; float* vv[8]; const float* ll[8]; float lrs[8];
@@ -332,6 +348,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("bind", &bind_abi, "hand over the C-ABI entry points (name -> address) of the loaded libmi355gs build");
   m.def("render_posed", &render_posed);
   m.def("l1_ssim_loss", &l1_ssim_loss);
+  m.def("host_times_us", [](bool reset) {
+    std::vector<double> v(g_host_us, g_host_us + 6);
+    if (reset) for (double& x : g_host_us) x = 0;
+    return v;
+  }, "accumulated host microseconds: render fwd (incl. the count wait), render bwd, loss fwd, loss bwd, adam step, count wait");
   m.def("forget_gates", []() { std::lock_guard<std::mutex> lock(g_gate_mutex); g_gates = GateRecord(); });
   py::class_<AdamPlan>(m, "AdamPlan")
       .def(py::init<std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, std::vector<c10::optional<Tensor>>, double, double, double>())

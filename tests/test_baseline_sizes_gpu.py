@@ -19,11 +19,13 @@ Gaussian) pair evaluations per frame NO fp32 implementation meets the small-case
     two implementations, which moves every Gaussian under them.  That is why the errors grow after 40 training iterations
     (C3 view 0: xyz 2.6e-3 for the device AND 2.6e-3 for the fp32 oracle, both against fp64).
 So the assertions are relative to what the fp32 oracle itself achieves against fp64:
-  * image: every value within 5e-3 of fp64; fraction of values off by more than 1e-4 at most 8x the fp32 oracle's (floor 2e-4);
-  * per-Gaussian gradient tensors: relative L2 against fp64 at most 8x the fp32 oracle's (floor 1e-3), also with the 64 worst
-    Gaussians set aside (floor 1e-4) — measured ratios over 30 repeated runs are 0.6 .. 2.3, with ONE run of the
-    40-iteration case above 4 (which pairs flip is luck: the trained state itself differs from run to run in the order
-    of float atomics; the iteration-0 cases repeat exactly).  A wrong kernel is off by orders of magnitude, not by 8x;
+  * image: every value within 5e-3 of fp64; fraction of values off by more than 1e-4 at most FACTOR x the fp32 oracle's (floor 2e-4);
+  * per-Gaussian gradient tensors: relative L2 against fp64 at most FACTOR x the fp32 oracle's (floor 1e-3), also with the 64
+    worst Gaussians set aside (floor 1e-4).  FACTOR = 4 for the deterministic cases (blob-200k, and C3 / C4 at iteration 0: the
+    inputs are fixed, the result repeats exactly up to float-atomic order) and 8 for the trained states (which pairs flip is
+    luck there: the trained state itself differs from run to run; measured ratios over 30 repeated runs are 0.6 .. 2.3, with
+    ONE run of the 40-iteration case above 4).  Every measured ratio is printed (pytest -s) and recorded (GS_CALIBRATE=1).  A
+    wrong kernel is off by orders of magnitude, not by 4x;
   * pose gradients (sums over all Gaussians), loss: plain relative bounds.
 """
 import pytest
@@ -34,7 +36,8 @@ from tests.ops_util import bound
 
 pytestmark = pytest.mark.gpu
 OUTLIERS = 64
-FACTOR = 8.0   # device error allowed, in units of the fp32 oracle's own error against fp64 (see the module docstring)
+FACTOR_FIXED_INPUTS = 4.0   # device error allowed, in units of the fp32 oracle's own error against fp64 (see the module docstring)
+FACTOR_TRAINED_STATE = 8.0
 
 
 def _grad_errors(a, b):
@@ -49,19 +52,23 @@ def _grad_errors(a, b):
     return full, float(keep.sum().sqrt()) / n
 
 
-def _check_image(pre, dut, c32, c64):
+def _check_image(pre, dut, c32, c64, factor):
     d = (dut.detach().double().cpu() - c64).abs()
     d_ref = (c32.detach().double() - c64).abs()
     bound(pre + "image_max", float(d.max()), 5e-3)
     frac, frac_ref = float((d > 1e-4).double().mean()), float((d_ref > 1e-4).double().mean())
-    bound(pre + "image_frac_over_1e-4[fp32 oracle: %.1e]" % frac_ref, frac, max(FACTOR * frac_ref, 2e-4))
+    print("%-46s device %.2e  fp32 oracle %.2e  ratio %.2f (limit %g)" % (pre + "image_frac_over_1e-4", frac, frac_ref,
+                                                                          frac / max(frac_ref, 1e-30), factor))
+    bound(pre + "image_frac_over_1e-4[fp32 oracle: %.1e]" % frac_ref, frac, max(factor * frac_ref, 2e-4))
 
 
-def _check_grad(pre, k, dut, c32, c64):
+def _check_grad(pre, k, dut, c32, c64, factor):
     full, robust = _grad_errors(dut, c64)
     full_ref, robust_ref = _grad_errors(c32, c64)
-    bound(pre + "grad_%s[fp32 oracle: %.1e]" % (k, full_ref), full, max(FACTOR * full_ref, 1e-3))
-    bound(pre + "grad_%s_without_%d_worst[fp32 oracle: %.1e]" % (k, OUTLIERS, robust_ref), robust, max(FACTOR * robust_ref, 1e-4))
+    print("%-46s device %.2e  fp32 oracle %.2e  ratio %.2f | without the %d worst: %.2e / %.2e  ratio %.2f (limit %g)" % (
+        pre + "grad_" + k, full, full_ref, full / max(full_ref, 1e-30), OUTLIERS, robust, robust_ref, robust / max(robust_ref, 1e-30), factor))
+    bound(pre + "grad_%s[fp32 oracle: %.1e]" % (k, full_ref), full, max(factor * full_ref, 1e-3))
+    bound(pre + "grad_%s_without_%d_worst[fp32 oracle: %.1e]" % (k, OUTLIERS, robust_ref), robust, max(factor * robust_ref, 1e-4))
 
 
 @pytest.mark.parametrize("deg", [0, 3])
@@ -100,9 +107,9 @@ def test_blob_200k_512_forward_backward_matches_oracle(gpu, deg):
     mism = res["dut"]["radii"] != res["c32"]["radii"]
     bound(pre + "radii_mismatch_frac", float(mism.float().mean()), 1e-4)
     assert int((res["dut"]["radii"] - res["c32"]["radii"]).abs().max()) <= 1
-    _check_image(pre, res["dut"]["color"], res["c32"]["color"], res["c64"]["color"])
+    _check_image(pre, res["dut"]["color"], res["c32"]["color"], res["c64"]["color"], FACTOR_FIXED_INPUTS)
     for k in res["c64"]["grads"]:
-        _check_grad(pre, k, res["dut"]["grads"][k], res["c32"]["grads"][k], res["c64"]["grads"][k])
+        _check_grad(pre, k, res["dut"]["grads"][k], res["c32"]["grads"][k], res["c64"]["grads"][k], FACTOR_FIXED_INPUTS)
 
 
 def _compare_views_with_cpu_oracle(gpu, tag, V, Wm, W, H, views, train_iters):
@@ -151,8 +158,9 @@ def _compare_views_with_cpu_oracle(gpu, tag, V, Wm, W, H, views, train_iters):
             for k in params:
                 cpu.p[k].grad = None
         pre = "%s/it%d/view%d/" % (tag, train_iters, uid)
+        factor = FACTOR_TRAINED_STATE if train_iters else FACTOR_FIXED_INPUTS
         bound(pre + "loss", abs(float(loss.detach()) - ref["c64"]["loss"]) / abs(ref["c64"]["loss"]), 5e-5)
-        _check_image(pre, img, ref["c32"]["img"], ref["c64"]["img"])
+        _check_image(pre, img, ref["c32"]["img"], ref["c64"]["img"], factor)
         g64 = ref["c64"]["grads"]
         for k, t in params.items():
             a = t.grad.detach().cpu()
@@ -164,7 +172,7 @@ def _compare_views_with_cpu_oracle(gpu, tag, V, Wm, W, H, views, train_iters):
                 bound(pre + "grad_pose[fp32 oracle: %.1e]" % e_ref, e, 1e-3)
             else:
                 assert float(g64[k].norm()) > 0, k
-                _check_grad(pre, k, a, ref["c32"]["grads"][k], g64[k])
+                _check_grad(pre, k, a, ref["c32"]["grads"][k], g64[k], factor)
             t.grad = None
 
 

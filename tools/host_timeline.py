@@ -44,9 +44,16 @@ torch.Tensor.item = timed(" loss.item() (waits for the GPU)", _item)
 T._forward_backward_step = timed("_forward_backward_step", T._forward_backward_step)
 T._optimizer_step = timed("_optimizer_step", T._optimizer_step)
 
+from instantsplat_amd import _lib
+if os.environ.get("GS_SINGLE_THREAD_AUTOGRAD") == "1":
+    torch.autograd.set_multithreading_enabled(False)   # backward on the calling thread: no hand-off to the device thread
+print("binding:", _lib.BINDING, "| multithreaded autograd:", torch.autograd.is_multithreading_enabled())
 for _ in range(100):
     T.train_iteration(st, fused_loss=True, sync_loss=True)
 torch.cuda.synchronize(); ACC.clear(); CNT.clear()
+ext = _lib.compiled()
+if ext is not None:
+    ext.host_times_us(True)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 t0 = time.perf_counter()
 for _ in range(N):
@@ -56,3 +63,8 @@ dt = time.perf_counter() - t0
 print("drop-in loop with timers: %.1f us per iteration (%.0f it/s)" % (dt / N * 1e6, N / dt))
 for k, v in ACC.items():
     print("%-70s %7.1f us/iter  (%d calls)" % (k, v / N * 1e6, CNT[k] // N))
+if ext is not None:
+    names = ("RenderPosedFn.forward (C++, incl. the count wait)", "RenderPosedFn.backward (C++)", "L1SsimLossFn.forward (C++)",
+             "L1SsimLossFn.backward (C++)", "AdamPlan.step (C++)", "  of the forward: wait for the instance count")
+    for n_, v in zip(names, ext.host_times_us(False)):
+        print("  %-68s %7.1f us/iter" % (n_, v / N))
