@@ -217,7 +217,7 @@ def main():
     BinningPolicy.reset("exact")
 
     # ---- the reference-shaped loop on the drop-in operators (autograd path, both of the reference's read-backs)
-    for _ in range(5 if not emulated else 1):
+    for _ in range(20 if not emulated else 1):   # (caching allocator, per-view count hints and the optimizer's fast path settle)
         train_iteration(st)
     autograd_loop_its = world * n_side / timed_block(lambda: train_iteration(st), n_side)
     sync_loop_its = world * args.steps / elapsed

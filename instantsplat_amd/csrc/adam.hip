@@ -55,7 +55,8 @@ struct MultiAdamArgs {
   const float* pplr[MT_MAX];
   float step_size[MT_MAX];
   const float* gate;  // caller-provided gate flags (or null)
-  int gidx[MT_MAX];   // >= 0: tensor t's moment update is decided by gate[gidx[t]]; < 0: by its own sum of squares, sumsq[t]
+  int gidx[MT_MAX];   // >= 0: tensor t's moment update is decided by gate[gidx[t]]; -1: by its own sum of squares, sumsq[t];
+                      // -2: a tensor that fits ONE workgroup (numel <= MT_CHUNK) sums its squared gradient itself, in k_adam_multi
   int sq_out[MT_MAX]; // k_adam_sumsq: where tensor t's sum goes (its own index unless the launch covers a subset of a step's tensors)
   int vec4[MT_MAX];  // numel % 4 == 0 and all four arrays 16-byte aligned: 128-bit loads/stores
   // Optional memory of gated-off tensors across launches (fused trainer only).  live[2t] = sequence number of the last
@@ -103,7 +104,20 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
   const int t = mt_find(a, blockIdx.x);
   const long long lo = (long long)(blockIdx.x - a.first_block[t]) * MT_CHUNK;
   const long long hi = min(a.numel[t], lo + MT_CHUNK);
-  const bool update = (a.gidx[t] >= 0 ? a.gate[a.gidx[t]] : sumsq[t]) > 0.f;
+  bool update;
+  if (a.gidx[t] == -2) {
+    // the whole tensor belongs to this workgroup: evaluate its gate here (any non-zero gradient element)
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    bool nz = false;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) { const float x = a.grad[t][i]; nz = nz || x * x > 0.f; }   // what sum(x^2) > 0 tests
+    if (nz) s_any = 1;   // benign same-value race
+    __syncthreads();
+    update = s_any != 0;
+  } else {
+    update = (a.gidx[t] >= 0 ? a.gate[a.gidx[t]] : sumsq[t]) > 0.f;
+  }
   if (a.live) {
     const bool first = blockIdx.x == (unsigned)a.first_block[t] && threadIdx.x == 0;
     if (update) {
@@ -180,7 +194,8 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
   MultiAdamArgs a;
   a.n = ntensors; a.gate = gate;
   int blocks = 0;
-  bool need_sumsq = false;   // some tensor's gate has to be computed from its gradient
+  bool any_ungated = false;   // some tensor's gate has to be computed from its gradient
+  bool need_sumsq = false;    // ... by the separate pass over the gradients
   for (int t = 0; t < MT_MAX; ++t) {
     a.first_block[t] = blocks;
     if (t < ntensors) {
@@ -188,7 +203,7 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
         return MI355GS_EINVAL;
       if (gate && gate_index[t] >= MT_MAX) return MI355GS_EINVAL;
       a.numel[t] = numel[t]; a.row[t] = row[t]; a.gidx[t] = gate ? gate_index[t] : -1; a.sq_out[t] = t;
-      if (a.gidx[t] < 0) need_sumsq = true;
+      if (a.gidx[t] < 0) any_ungated = true;
       a.param[t] = params[t]; a.grad[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.pplr[t] = per_point_lr[t];
       const double bc1 = 1.0 - pow((double)beta1, (double)step[t]), bc2 = 1.0 - pow((double)beta2, (double)step[t]);
       a.step_size[t] = (float)((double)lr[t] * (sqrt(bc2) / bc1));
@@ -203,6 +218,15 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
   a.live = nullptr; a.seq = 0;
   if (blocks == 0) return MI355GS_OK;
   if (!gate && g_fused.gate == scratch) { a.live = g_fused.adam_live; a.seq = g_fused.adam_seq; }
+  if (gate && any_ungated) {
+    // small leftovers (the pose table: 7 V floats) are gated inside the update kernel, by the one workgroup that owns them
+    for (int t = 0; t < ntensors; ++t) {
+      if (a.gidx[t] >= 0) continue;
+      if (a.numel[t] <= MT_CHUNK) a.gidx[t] = -2; else need_sumsq = true;
+    }
+  } else if (any_ungated) {
+    need_sumsq = true;
+  }
   if (need_sumsq && !scratch) return MI355GS_EINVAL;
   if (gate) {
     // the caller vouches that gate[gate_index[t]] > 0 <=> grads[t] has a non-zero element (the flags
@@ -213,7 +237,7 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
       MultiAdamArgs s = a;
       int k = 0, sblocks = 0;
       for (int t = 0; t < ntensors; ++t) {
-        if (a.gidx[t] >= 0) continue;
+        if (a.gidx[t] != -1) continue;
         s.first_block[k] = sblocks; s.numel[k] = a.numel[t]; s.grad[k] = a.grad[t]; s.vec4[k] = a.vec4[t]; s.sq_out[k] = t;
         sblocks += (int)((a.numel[t] + MT_CHUNK - 1) / MT_CHUNK);
         ++k;

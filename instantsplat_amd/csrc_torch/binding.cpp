@@ -86,6 +86,20 @@ struct DeviceScope {
   }
 };
 
+// The frame's instance count is stored by the tile-scan kernel into a word of pinned, device-mapped host memory that the
+// caller set to -1: poll it (the store needs no stream synchronisation to become visible: the memory is fine-grained host
+// memory), and fall back to waiting for the stream if it does not show up within a couple of milliseconds.
+void wait_for_count(const int32_t* count, const DeviceScope& dev, const Tensor& t) {
+  if (!t.is_cuda()) return;   // emulated kernels run synchronously
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    if (*reinterpret_cast<const volatile int32_t*>(count) >= 0) return;
+    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  dev.synchronize(t);
+  TORCH_CHECK(*reinterpret_cast<const volatile int32_t*>(count) >= 0, "mi355gs: the forward did not report its instance count");
+}
+
 Tensor f32c(const Tensor& t, const char* name, const Tensor& like) {
   TORCH_CHECK(t.scalar_type() == at::kFloat, "expected float32, got ", t.scalar_type(), " (", name, ")");
   TORCH_CHECK(t.device() == like.device(), "tensors on different devices: ", like.device(), " vs ", t.device(), " (", name, ")");
@@ -131,7 +145,7 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
   static variable_list forward(AutogradContext* ctx, Tensor xyz_, Tensor rot_, Tensor scaling_, Tensor opl_, Tensor f_dc_,
                                Tensor f_rest_, Tensor pose_, Tensor means2D, Tensor bg_, Tensor view_, Tensor proj_, Tensor origin_,
                                int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t D,
-                               int64_t capacity, Tensor count_slot) {
+                               int64_t capacity, int64_t count_hint, Tensor count_slot) {
     TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
     HostClock clock(&g_host_us[0]);
     (void)means2D;  // its VALUE is never read (the reference's viewspace_points dummy); it only receives a gradient
@@ -147,22 +161,46 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     Tensor color = at::empty({3, H, W}, xyz.options());
     Tensor geom = empty_bytes(g_abi.geom_bytes(P), xyz), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), xyz);
     int32_t* count = count_slot.data_ptr<int32_t>();  // pinned host memory the tile-scan kernel stores into (a CPU word under emulation)
-    check(g_abi.posed_forward_preprocess(dev.stream, P, (int)D, (int)W, (int)H, fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling),
-                                         (float)scale_modifier, fp(rot), fp(pose), fp(view), fp(proj), fp(origin), (float)tanfovx,
-                                         (float)tanfovy, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count, 0),
-          "posed_forward_preprocess");
+    auto preprocess = [&]() {
+      *reinterpret_cast<volatile int32_t*>(count) = -1;   // "not written yet" for wait_for_count
+      check(g_abi.posed_forward_preprocess(dev.stream, P, (int)D, (int)W, (int)H, fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling),
+                                           (float)scale_modifier, fp(rot), fp(pose), fp(view), fp(proj), fp(origin), (float)tanfovx,
+                                           (float)tanfovy, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count, 0),
+            "posed_forward_preprocess");
+    };
+    Tensor binning;
+    auto stage2 = [&](int64_t cap) {
+      binning = empty_bytes(g_abi.binning_bytes(cap, (int)W, (int)H), xyz);
+      check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(),
+                                 fp(color), 0),
+            "raster_forward_render");
+    };
+    preprocess();
     int64_t R = capacity;
-    if (R < 0) {
-      // the reference operator's own blocking read-back of the instance count — without its device-to-host copy: the kernel
-      // has stored the value in host memory, the host only waits for the stream
-      HostClock wait_clock(&g_host_us[5]);
-      dev.synchronize(xyz);
+    if (R >= 0) {
+      stage2(R);   // the caller's bound: no host synchronisation at all (BinningPolicy "bounded"; it verifies the count later)
+    } else {
+      // The reference operator's own blocking read-back of the instance count (its forward sizes the sort buffers from it).
+      // The blocking semantics are kept — the call returns knowing the exact count, and no instance was dropped — but the GPU
+      // does not sit idle through the round trip: when a count of an earlier frame like this one is known (`count_hint`),
+      // stage 2 is enqueued at once in buffers sized from it, and the host then merely waits for the count word, which the
+      // tile-scan kernel stores straight into pinned host memory.  A frame that outgrew the guess is projected and rendered a
+      // second time with exact buffers (identical result; rare: the guess is 1.5 x + 16384).
+      const int64_t guess = count_hint > 0 ? count_hint + count_hint / 2 + 16384 : -1;
+      if (guess > 0) stage2(guess);
+      {
+        HostClock wait_clock(&g_host_us[5]);
+        wait_for_count(count, dev, xyz);
+      }
       R = *reinterpret_cast<volatile int32_t*>(count);
+      if (guess > 0 && R <= guess) {
+        R = guess;                      // the capacity the frame's buffers were laid out for: the backward needs this number
+      } else {
+        if (guess > 0) preprocess();    // the overflowing stage 2 consumed the tile cursors: start the frame again
+        if (guess > 0) wait_for_count(count, dev, xyz);
+        stage2(R);
+      }
     }
-    Tensor binning = empty_bytes(g_abi.binning_bytes(R, (int)W, (int)H), xyz);
-    check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, R, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(),
-                               fp(color), 0),
-          "raster_forward_render");
     ctx->saved_data["dims"] = std::vector<int64_t>{P, D, W, H, R};
     ctx->saved_data["scalars"] = std::vector<double>{tanfovx, tanfovy, scale_modifier};
     ctx->save_for_backward({xyz, rot, scaling, opl, f_dc, f_rest, pose, radii, geom, tiles, binning, bg, view, proj, origin, color});
@@ -211,15 +249,16 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     }
     Tensor none;
     return {d_xyz, d_rot, d_scaling, d_opl, d_fdc, d_frest, d_pose, d_m2d, none, none, none, none,
-            none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none};
   }
 };
 
 std::vector<Tensor> render_posed(Tensor xyz, Tensor rot, Tensor scaling, Tensor opl, Tensor f_dc, Tensor f_rest, Tensor pose,
                                  Tensor means2D, Tensor bg, Tensor view, Tensor proj, Tensor origin, int64_t H, int64_t W,
-                                 double tanfovx, double tanfovy, double scale_modifier, int64_t D, int64_t capacity, Tensor count_slot) {
+                                 double tanfovx, double tanfovy, double scale_modifier, int64_t D, int64_t capacity, int64_t count_hint,
+                                 Tensor count_slot) {
   return RenderPosedFn::apply(xyz, rot, scaling, opl, f_dc, f_rest, pose, means2D, bg, view, proj, origin, H, W, tanfovx, tanfovy,
-                              scale_modifier, D, capacity, count_slot);
+                              scale_modifier, D, capacity, count_hint, count_slot);
 }
 
 // ------------------------------------------------------------------------------------------------

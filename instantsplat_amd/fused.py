@@ -131,6 +131,36 @@ class _RenderPosed(torch.autograd.Function):
         return d_xyz, d_rot, d_scaling, d_opl, d_fdc, d_frest, d_pose, d_m2d, None
 
 
+_LAST_COUNT = {}   # (P, W, H, hint key) -> instance count of the last frame like this one (sizes the speculative stage 2)
+
+
+def render_posed_compiled(ext, pc, pose, means2D, bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree):
+    """The compiled node (csrc_torch/binding.cpp) with the BinningPolicy bookkeeping of `size_and_render` around it."""
+    policy = dgr.BinningPolicy
+    xyz = pc._xyz
+    dev = xyz.device
+    slot = dgr.count_slot(dev)
+    cap = policy.deferred_capacity()
+    key = policy.current_key
+    if cap is not None:
+        color, radii = ext.render_posed(xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
+                                        bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree, cap, 0, slot)
+        policy.defer(slot, cap, dev)
+        return color, radii
+    # exact mode: the reference operator's blocking count read-back; the count of the previous frame like this one lets the
+    # node enqueue stage 2 before the count of THIS frame has arrived (see RenderPosedFn::forward)
+    ck = (xyz.shape[0], W, H, key)
+    color, radii = ext.render_posed(xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
+                                    bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree, -1, _LAST_COUNT.get(ck, 0), slot)
+    r = int(slot[0])
+    if len(_LAST_COUNT) > 256:
+        _LAST_COUNT.clear()
+    _LAST_COUNT[ck] = r
+    if key is not None:
+        policy.known[key] = r
+    return color, radii
+
+
 def render_posed(pc, pose, means2D, settings):
     """-> (image[3,H,W], radii[P]) for the default pipeline (SH colours of the active degree, scale/rotation covariance).
 
@@ -142,19 +172,8 @@ def render_posed(pc, pose, means2D, settings):
     if ext is None:
         return _RenderPosed.apply(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
                                   settings)
-    policy = dgr.BinningPolicy
-    dev = pc._xyz.device
-    slot = dgr.count_slot(dev)
-    cap = policy.deferred_capacity()
-    color, radii = ext.render_posed(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
-                                    s.bg, s.viewmatrix, s.projmatrix, s.campos, int(s.image_height), int(s.image_width),
-                                    float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), int(s.sh_degree),
-                                    -1 if cap is None else cap, slot)
-    if cap is not None:
-        policy.defer(slot, cap, dev)
-    elif policy.current_key is not None:
-        policy.known[policy.current_key] = int(slot[0])
-    return color, radii
+    return render_posed_compiled(ext, pc, pose, means2D, s.bg, s.viewmatrix, s.projmatrix, s.campos, int(s.image_height),
+                                 int(s.image_width), float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), int(s.sh_degree))
 
 
 def sh_features(pc):

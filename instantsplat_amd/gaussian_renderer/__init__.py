@@ -12,7 +12,9 @@ import math
 import torch
 
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-from ..fused import pose_activations, render_posed, sh_features
+from .. import _lib
+from .. import diff_gaussian_rasterization as _dgr
+from ..fused import pose_activations, render_posed, render_posed_compiled, sh_features
 from ..pose_utils import get_camera_from_tensor, quadmultiply
 from ..sh_utils import eval_sh
 
@@ -80,13 +82,26 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     projmatrix = viewpoint_camera.projection_matrix  # identity @ projection
     if projmatrix.device != dev:
         projmatrix = projmatrix.to(dev)
+    default_pipeline = override_color is None and not (pipe.compute_cov3D_python or pipe.convert_SHs_python)
+    if FUSED_GLUE == "posed" and default_pipeline and pc.max_sh_degree == 3 and not pipe.debug and not _dgr._KEEP_LAST_FRAME:
+        ext = _lib.compiled()
+        if ext is not None:
+            # the compiled node takes the settings as plain arguments: no settings tuple is built on this path (the training
+            # loop's path: everything between the optimizer step and the first launch of the next frame is GPU idle time)
+            fx, fy = viewpoint_camera.FoVx, viewpoint_camera.FoVy
+            tans = viewpoint_camera.__dict__.get("_gs_tanfov")
+            if tans is None or tans[0] != fx or tans[1] != fy:
+                tans = viewpoint_camera.__dict__["_gs_tanfov"] = (fx, fy, math.tan(fx * 0.5), math.tan(fy * 0.5))
+            image, radii = render_posed_compiled(ext, pc, camera_pose, screenspace_points, bg_color, view_identity, projmatrix, origin,
+                                                 int(viewpoint_camera.image_height), int(viewpoint_camera.image_width), tans[2], tans[3],
+                                                 float(scaling_modifier), int(pc.active_sh_degree))
+            return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
         scale_modifier=scaling_modifier, viewmatrix=view_identity, projmatrix=projmatrix, sh_degree=pc.active_sh_degree,
         campos=origin, prefiltered=False, debug=pipe.debug)
 
-    default_pipeline = override_color is None and not (pipe.compute_cov3D_python or pipe.convert_SHs_python)
     if FUSED_GLUE == "posed" and default_pipeline and pc.max_sh_degree == 3:
         # the whole differentiable body as one autograd node: the projection kernels take the raw parameters + the pose
         # (no GaussianRasterizer module is instantiated on this path: constructing an nn.Module costs ~10 us per call)

@@ -69,6 +69,7 @@ class PerPointAdam(Optimizer):
 
     def load_state_dict(self, state_dict):
         self._plans = {}   # the moments are new tensors
+        self._fast = None
         return super().load_state_dict(state_dict)
 
     def _plan_for(self, live):
@@ -152,11 +153,37 @@ class PerPointAdam(Optimizer):
                 hook(self, args, kwargs)
             return out
 
+    def _step_fast(self, fast):
+        """The steady state of a training loop — the same tensors with a gradient each as in the previous step, one (betas,
+        eps) batch, no weight decay — without rebuilding anything: validate, bump the step counts, one call into the compiled
+        plan.  Returns False (having changed nothing) when anything differs; the general path then takes the step."""
+        entries, plan = fast[1], fast[2]
+        grads, lrs = [], []
+        for group, p, st, ptr, sig, m in entries:
+            g = p.grad
+            if g is None or g.is_sparse or p.data_ptr() != ptr or st.get("exp_avg") is not m or group["weight_decay"] != 0 \
+                    or not self._same_sig(self._group_sig(group), sig):
+                return False
+            grads.append(g)
+            lrs.append(group["lr"])
+        steps = []
+        for _, _, st, _, _, _ in entries:
+            st["step"] += 1
+            steps.append(st["step"])
+        plan.step(grads, lrs, steps)
+        return True
+
     def _step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        ext = _lib.compiled()
+        fast = self.__dict__.get("_fast")
+        if fast is not None:
+            if fast[0] is ext and fast[3] == sum(len(g["params"]) for g in self.param_groups) and self._step_fast(fast):
+                return loss
+            self._fast = None
         state_of = self.state
         live = []
         for group in self.param_groups:
@@ -178,8 +205,8 @@ class PerPointAdam(Optimizer):
             return loss
         L = _lib.lib()
         f32 = torch.float32
-        ext = _lib.compiled()
-        for b in self._plan_for(live)["batches"]:
+        batches = self._plan_for(live)["batches"]
+        for b in batches:
             dev = b["dev"]
             if ext is not None and not any(group["weight_decay"] != 0 for group in b["groups"]):
                 # compiled binding: the same library call from C++ (csrc_torch/binding.cpp AdamPlan), which also recognises
@@ -192,6 +219,10 @@ class PerPointAdam(Optimizer):
                                                         [s_["exp_avg_sq"] for s_ in b["states"]], b["keep"], b1, b2, eps)
                     b["compiled_ext"] = ext
                 plan.step([p.grad for p in b["params"]], [group["lr"] for group in b["groups"]], [s_["step"] for s_ in b["states"]])
+                if len(batches) == 1 and len(live) == sum(len(g["params"]) for g in self.param_groups):
+                    # every parameter of the optimizer took part, in one batch: remember the line-up for _step_fast
+                    self._fast = (ext, [(g_, p_, s_, p_.data_ptr(), self._group_sig(g_), s_["exp_avg"]) for g_, p_, s_ in zip(b["groups"], b["params"], b["states"])],
+                                  plan, len(live))
                 continue
             ptrs = []
             keep = []
