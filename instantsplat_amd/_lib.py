@@ -109,8 +109,8 @@ EXT_PATH = os.path.join(_HERE, "lib", "_mi355gs_torch.so")
 _EXT = None
 _EXT_BOUND_TO = None
 _EXT_SYMBOLS = ("mi355gs_raster_geom_bytes", "mi355gs_raster_tiles_bytes", "mi355gs_raster_binning_bytes",
-                "mi355gs_raster_grad_scratch_bytes", "mi355gs_raster_grad_gate_offset", "mi355gs_posed_forward_preprocess",
-                "mi355gs_raster_forward_render", "mi355gs_posed_backward", "mi355gs_ssim_scratch_bytes", "mi355gs_l1_ssim_loss_fused",
+                "mi355gs_raster_grad_scratch_bytes", "mi355gs_raster_grad_gate_offset", "mi355gs_posed_forward_preprocess", "mi355gs_raster_forward_preprocess", "mi355gs_raster_backward",
+                "mi355gs_raster_forward_render", "mi355gs_posed_backward", "mi355gs_ssim_scratch_bytes", "mi355gs_l1_ssim_loss_fused", "mi355gs_ssim_forward", "mi355gs_ssim_backward",
                 "mi355gs_adam_multi_step", "mi355gs_error_string")
 
 

@@ -34,10 +34,14 @@ struct Abi {
   decltype(&mi355gs_raster_grad_scratch_bytes) grad_scratch_bytes = nullptr;
   decltype(&mi355gs_raster_grad_gate_offset) grad_gate_offset = nullptr;
   decltype(&mi355gs_posed_forward_preprocess) posed_forward_preprocess = nullptr;
+  decltype(&mi355gs_raster_forward_preprocess) forward_preprocess = nullptr;
+  decltype(&mi355gs_raster_backward) raster_backward = nullptr;
   decltype(&mi355gs_raster_forward_render) forward_render = nullptr;
   decltype(&mi355gs_posed_backward) posed_backward = nullptr;
   decltype(&mi355gs_ssim_scratch_bytes) ssim_scratch_bytes = nullptr;
   decltype(&mi355gs_l1_ssim_loss_fused) l1_ssim_loss_fused = nullptr;
+  decltype(&mi355gs_ssim_forward) ssim_forward = nullptr;
+  decltype(&mi355gs_ssim_backward) ssim_backward = nullptr;
   decltype(&mi355gs_adam_multi_step) adam_multi_step = nullptr;
   decltype(&mi355gs_error_string) error_string = nullptr;
   bool bound = false;
@@ -56,10 +60,14 @@ void bind_abi(const std::map<std::string, uintptr_t>& sym) {
   GS_BIND(grad_scratch_bytes, mi355gs_raster_grad_scratch_bytes);
   GS_BIND(grad_gate_offset, mi355gs_raster_grad_gate_offset);
   GS_BIND(posed_forward_preprocess, mi355gs_posed_forward_preprocess);
+  GS_BIND(forward_preprocess, mi355gs_raster_forward_preprocess);
+  GS_BIND(raster_backward, mi355gs_raster_backward);
   GS_BIND(forward_render, mi355gs_raster_forward_render);
   GS_BIND(posed_backward, mi355gs_posed_backward);
   GS_BIND(ssim_scratch_bytes, mi355gs_ssim_scratch_bytes);
   GS_BIND(l1_ssim_loss_fused, mi355gs_l1_ssim_loss_fused);
+  GS_BIND(ssim_forward, mi355gs_ssim_forward);
+  GS_BIND(ssim_backward, mi355gs_ssim_backward);
   GS_BIND(adam_multi_step, mi355gs_adam_multi_step);
   GS_BIND(error_string, mi355gs_error_string);
 #undef GS_BIND
@@ -262,6 +270,113 @@ std::vector<Tensor> render_posed(Tensor xyz, Tensor rot, Tensor scaling, Tensor 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The operator itself: GaussianRasterizer.forward of the package the reference imports at gaussian_renderer/__init__.py:14-17
+// and calls at :126-135 (Python twin: diff_gaussian_rasterization/__init__.py::_RasterizeGaussians).  Optional inputs are
+// undefined tensors; gradients come back for (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+// cov3Ds_precomp, sh_rest) like the upstream operator's.
+// ------------------------------------------------------------------------------------------------
+struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
+  using OptTensor = c10::optional<Tensor>;   // (an undefined Tensor cannot be an argument of a custom function: its metadata is recorded)
+  static variable_list forward(AutogradContext* ctx, Tensor means3D_, Tensor means2D, OptTensor sh_, OptTensor colors_, Tensor opac_,
+                               OptTensor scales_, OptTensor rot_, OptTensor cov_, OptTensor sh_rest_, Tensor bg_, Tensor view_, Tensor proj_,
+                               Tensor campos_,
+                               int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t D, bool prefiltered,
+                               int64_t capacity, int64_t count_hint, Tensor count_slot) {
+    TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    (void)means2D;
+    auto opt = [&](const OptTensor& t, const char* name, const Tensor& like) {
+      return (t.has_value() && t->defined() && t->numel()) ? f32c(*t, name, like) : Tensor();
+    };
+    const Tensor means3D = f32c(means3D_, "means3D", means3D_), opac = f32c(opac_, "opacities", means3D);
+    const Tensor sh = opt(sh_, "sh", means3D), colors = opt(colors_, "colors_precomp", means3D), scales = opt(scales_, "scales", means3D),
+                 rot = opt(rot_, "rotations", means3D), cov = opt(cov_, "cov3Ds_precomp", means3D), sh_rest = opt(sh_rest_, "sh_rest", means3D);
+    const Tensor bg = f32c(bg_, "bg", means3D), view = f32c(view_, "viewmatrix", means3D), proj = f32c(proj_, "projmatrix", means3D),
+                 campos = f32c(campos_, "campos", means3D);
+    TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
+    TORCH_CHECK(count_slot.scalar_type() == at::kInt && count_slot.numel() == 1, "count_slot must be one int32");
+    const int P = (int)means3D.size(0);
+    const int M = sh.defined() ? (int)(sh.size(1) + (sh_rest.defined() ? sh_rest.size(1) : 0)) : 0;
+    const DeviceScope dev(means3D);
+    Tensor radii = at::empty({P}, means3D.options().dtype(at::kInt));
+    Tensor color = at::empty({3, H, W}, means3D.options());
+    Tensor geom = empty_bytes(g_abi.geom_bytes(P), means3D), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), means3D);
+    int32_t* count = count_slot.data_ptr<int32_t>();
+    auto preprocess = [&]() {
+      *reinterpret_cast<volatile int32_t*>(count) = -1;
+      check(g_abi.forward_preprocess(dev.stream, P, (int)D, M, (int)W, (int)H, fp(means3D), fp(sh), fp(sh_rest), fp(colors), fp(opac), fp(scales),
+                                     (float)scale_modifier, fp(rot), fp(cov), fp(view), fp(proj), fp(campos), (float)tanfovx, (float)tanfovy,
+                                     prefiltered ? 1 : 0, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count, 0),
+            "raster_forward_preprocess");
+    };
+    Tensor binning;
+    auto stage2 = [&](int64_t cap) {
+      binning = empty_bytes(g_abi.binning_bytes(cap, (int)W, (int)H), means3D);
+      check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(), fp(color), 0),
+            "raster_forward_render");
+    };
+    preprocess();
+    int64_t R = capacity;
+    if (R >= 0) {
+      stage2(R);
+    } else {   // blocking count read-back with a speculative stage 2: see RenderPosedFn::forward
+      const int64_t guess = count_hint > 0 ? count_hint + count_hint / 2 + 16384 : -1;
+      if (guess > 0) stage2(guess);
+      wait_for_count(count, dev, means3D);
+      R = *reinterpret_cast<volatile int32_t*>(count);
+      if (guess > 0 && R <= guess) {
+        R = guess;
+      } else {
+        if (guess > 0) { preprocess(); wait_for_count(count, dev, means3D); }
+        stage2(R);
+      }
+    }
+    ctx->saved_data["dims"] = std::vector<int64_t>{P, D, M, W, H, R};
+    ctx->saved_data["scalars"] = std::vector<double>{tanfovx, tanfovy, scale_modifier};
+    ctx->saved_data["opacity_shape"] = opac_.sizes().vec();
+    ctx->save_for_backward({means3D, sh, colors, opac, scales, rot, cov, sh_rest, radii, geom, tiles, binning, bg, view, proj, campos, color});
+    ctx->mark_non_differentiable({radii});
+    return {color, radii};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &means3D = saved[0], &sh = saved[1], &colors = saved[2], &opac = saved[3], &scales = saved[4], &rot = saved[5], &cov = saved[6],
+                 &sh_rest = saved[7], &radii = saved[8], &geom = saved[9], &tiles = saved[10], &binning = saved[11], &bg = saved[12],
+                 &view = saved[13], &proj = saved[14], &campos = saved[15], &color = saved[16];
+    const auto dims = ctx->saved_data["dims"].toIntVector();
+    const auto sc = ctx->saved_data["scalars"].toDoubleVector();
+    const int P = (int)dims[0], D = (int)dims[1], M = (int)dims[2], W = (int)dims[3], H = (int)dims[4];
+    const int64_t R = dims[5];
+    const Tensor g = f32c(grad_out[0], "grad_color", means3D);
+    const DeviceScope dev(means3D);
+    const auto o = means3D.options();
+    Tensor d_means3D = at::empty({P, 3}, o), d_means2D = at::empty({P, 3}, o), d_opac = at::empty({P}, o), d_col = at::empty({P, 3}, o);
+    Tensor d_sh, d_shr, d_scales, d_rot, d_cov;
+    if (sh.defined()) d_sh = at::empty({P, sh_rest.defined() ? 1 : M, 3}, o);
+    if (sh_rest.defined()) d_shr = at::empty({P, M - 1, 3}, o);
+    if (cov.defined()) d_cov = at::empty({P, 6}, o); else { d_scales = at::empty({P, 3}, o); d_rot = at::empty({P, 4}, o); }
+    Tensor scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
+    check(g_abi.raster_backward(dev.stream, P, D, M, W, H, fp(bg), fp(means3D), fp(sh), fp(sh_rest), fp(colors), fp(opac), fp(scales), (float)sc[2],
+                                fp(rot), fp(cov), fp(view), fp(proj), fp(campos), (float)sc[0], (float)sc[1], geom.data_ptr(), tiles.data_ptr(),
+                                binning.data_ptr(), R, radii.data_ptr<int32_t>(), fp(color), fp(g), scratch.data_ptr(), fp(d_means3D), fp(d_means2D),
+                                fp(d_sh), fp(d_shr), fp(d_col), fp(d_opac), fp(d_scales), fp(d_rot), fp(d_cov), 0),
+          "raster_backward");
+    Tensor none;
+    const auto shape = ctx->saved_data["opacity_shape"].toIntVector();
+    return {d_means3D, d_means2D, d_sh, sh.defined() ? none : d_col, d_opac.reshape(shape), d_scales, d_rot, d_cov, d_shr,
+            none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+  }
+};
+
+std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, c10::optional<Tensor> sh, c10::optional<Tensor> colors, Tensor opac,
+                              c10::optional<Tensor> scales, c10::optional<Tensor> rot, c10::optional<Tensor> cov, c10::optional<Tensor> sh_rest,
+                              Tensor bg, Tensor view, Tensor proj, Tensor campos, int64_t H, int64_t W, double tanfovx, double tanfovy,
+                              double scale_modifier, int64_t D, bool prefiltered, int64_t capacity, int64_t count_hint, Tensor count_slot) {
+  return RasterizeFn::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, sh_rest, bg, view, proj, campos, H, W,
+                            tanfovx, tanfovy, scale_modifier, D, prefiltered, capacity, count_hint, count_slot);
+}
+
+// ------------------------------------------------------------------------------------------------
 // (1 - lambda) * L1 + lambda * (1 - SSIM) and its gradient from one pass over the images
 // (reference train.py:171-176; the Python twin is fused_ssim/__init__.py::_FusedL1SSIM)
 // ------------------------------------------------------------------------------------------------
@@ -293,6 +408,48 @@ struct L1SsimLossFn : public torch::autograd::Function<L1SsimLossFn> {
 };
 
 std::vector<Tensor> l1_ssim_loss(Tensor img1, Tensor img2, double lambda_dssim) { return L1SsimLossFn::apply(img1, img2, lambda_dssim); }
+
+// ------------------------------------------------------------------------------------------------
+// fused_ssim(img1, img2, padding, train): the operator the reference imports at train.py:39-43 and calls at :173
+// (Python twin: fused_ssim/__init__.py::_FusedSSIM).  Gradient with respect to img1 only, as upstream.
+// ------------------------------------------------------------------------------------------------
+struct SsimFn : public torch::autograd::Function<SsimFn> {
+  static Tensor forward(AutogradContext* ctx, Tensor img1, Tensor img2, bool train, bool valid) {
+    TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    const Tensor a = f32c(img1, "img1", img1), b = f32c(img2, "img2", a);
+    TORCH_CHECK(a.dim() == 4 && a.sizes() == b.sizes(), "fused_ssim expects two [B,C,H,W] tensors of equal shape");
+    const int B = (int)a.size(0), C = (int)a.size(1), H = (int)a.size(2), W = (int)a.size(3);
+    TORCH_CHECK(!valid || (H > 10 && W > 10), "fused_ssim(padding=\"valid\") needs images larger than the 11x11 window");
+    const DeviceScope dev(a);
+    Tensor dm1, dm2, dm3;
+    if (train) { dm1 = at::empty_like(a); dm2 = at::empty_like(a); dm3 = at::empty_like(a); }
+    Tensor scratch = empty_bytes(g_abi.ssim_scratch_bytes(B, C, H, W), a);
+    Tensor out = at::empty({2}, a.options());   // [ssim_mean, l1_mean]
+    check(g_abi.ssim_forward(dev.stream, B, C, H, W, fp(a), fp(b), fp(dm1), fp(dm2), fp(dm3), scratch.data_ptr(), fp(out),
+                             valid ? nullptr : fp(out) + 1, valid ? 1 : 0),
+          "ssim_forward");
+    if (train) ctx->save_for_backward({a, b, dm1, dm2, dm3});
+    ctx->saved_data["flags"] = std::vector<int64_t>{train ? 1 : 0, valid ? 1 : 0};
+    return out.select(0, 0).clone();
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const auto flags = ctx->saved_data["flags"].toIntVector();
+    TORCH_CHECK(flags[0] == 1, "fused_ssim was called with train=False; no gradient is available");
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &a = saved[0], &b = saved[1];
+    const int B = (int)a.size(0), C = (int)a.size(1), H = (int)a.size(2), W = (int)a.size(3);
+    const DeviceScope dev(a);
+    const Tensor scale = f32c(grad_out[0].reshape({1}), "grad", a);
+    Tensor grad = at::empty_like(a);
+    check(g_abi.ssim_backward(dev.stream, B, C, H, W, fp(a), fp(b), fp(saved[2]), fp(saved[3]), fp(saved[4]), fp(scale), nullptr, fp(grad),
+                              (int)flags[1]),
+          "ssim_backward");
+    Tensor none;
+    return {grad, none, none, none};
+  }
+};
+
+Tensor fused_ssim(Tensor img1, Tensor img2, bool train, bool valid) { return SsimFn::apply(img1, img2, train, valid); }
 
 // ------------------------------------------------------------------------------------------------
 // PerPointAdam.step over a fixed set of tensors (reference scene/per_point_adam.py:34-100; Python twin: optim.py)
@@ -386,7 +543,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled PyTorch binding of libmi355gs.so's drop-in operators (no compute of its own)";
   m.def("bind", &bind_abi, "hand over the C-ABI entry points (name -> address) of the loaded libmi355gs build");
   m.def("render_posed", &render_posed);
+  m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);
+  m.def("fused_ssim", &fused_ssim);
   m.def("host_times_us", [](bool reset) {
     std::vector<double> v(g_host_us, g_host_us + 6);
     if (reset) for (double& x : g_host_us) x = 0;

@@ -374,10 +374,38 @@ class _RasterizeGaussians(torch.autograd.Function):
                 dL_dscales, dL_drot, dL_dcov, None, dL_dshr)
 
 
+_LAST_COUNT = {}   # (P, W, H, hint key) -> instance count of the last frame like this one (sizes the speculative stage 2)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         sh_rest=None):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, sh_rest)
+    s = raster_settings
+    ext = None if (s.debug or _KEEP_LAST_FRAME) else _lib.compiled()
+    if ext is None:   # the ctypes / Python autograd.Function binding (also: the operator's debug mode with its snapshot dumps)
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                         raster_settings, sh_rest)
+    # the compiled node (csrc_torch/binding.cpp::RasterizeFn): the same three C-ABI calls, with size_and_render's bookkeeping here
+    opt = lambda t: None if (t is None or t.numel() == 0) else t
+    dev = means3D.device
+    H, W = int(s.image_height), int(s.image_width)
+    slot = count_slot(dev)
+    cap = BinningPolicy.deferred_capacity()
+    key = BinningPolicy.current_key
+    ck = (means3D.shape[0], W, H, key)
+    color, radii = ext.rasterize(means3D, means2D, opt(sh), opt(colors_precomp), opacities, opt(scales), opt(rotations), opt(cov3Ds_precomp),
+                                 opt(sh_rest), s.bg, s.viewmatrix, s.projmatrix, s.campos, H, W, float(s.tanfovx), float(s.tanfovy),
+                                 float(s.scale_modifier), int(s.sh_degree), bool(s.prefiltered), -1 if cap is None else cap,
+                                 0 if cap is not None else _LAST_COUNT.get(ck, 0), slot)
+    if cap is not None:
+        BinningPolicy.defer(slot, cap, dev)
+    else:
+        r = int(slot[0])
+        if len(_LAST_COUNT) > 256:
+            _LAST_COUNT.clear()
+        _LAST_COUNT[ck] = r
+        if key is not None:
+            BinningPolicy.known[key] = r
+    return color, radii
 
 
 class GaussianRasterizer(nn.Module):

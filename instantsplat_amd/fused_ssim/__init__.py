@@ -67,6 +67,9 @@ def fused_ssim(img1, img2, padding="same", train=True):
     mean (and the gradient) only covers the region where the 11x11 window lies inside the image."""
     if padding not in ("same", "valid"):
         raise ValueError(f'padding must be "same" or "valid", got {padding!r}')
+    ext = _lib.compiled()
+    if ext is not None:   # the same two C-ABI calls from a C++ autograd node (csrc_torch/binding.cpp::SsimFn)
+        return ext.fused_ssim(img1, img2, bool(train), padding == "valid")
     return _FusedSSIM.apply(img1, img2, train, padding == "valid")
 
 

@@ -402,3 +402,45 @@ def check_tile_lists_against_oracle(dev, n, W=80, H=48, seed=5):
         assert float(alpha.max()) < 1.0 / 255.0, (tile, float(alpha.max()))
     assert kept == R and kept + dropped == R_ref
     return R, R_ref, worst
+
+
+def check_count_slots_survive_unpolled_forwards(dev):
+    """A frame rendered without reading its count back (BinningPolicy "bounded") keeps its word of the pinned count ring until
+    poll() has read it — however many other forwards (exact mode, inference renders) run in between and take words of the
+    ring themselves.  (the ring used to hand every word out round-robin, so 256 later forwards overwrote the
+    pending frame's count and poll() verified the wrong number.)"""
+    from instantsplat_amd.diff_gaussian_rasterization import (COUNT_RING, BinningPolicy, GaussianRasterizationSettings, GaussianRasterizer,
+                                                               binning_hint)
+    from instantsplat_amd.synthetic import syn_blob
+    from tests.util import settings_for
+    dev = torch.device(dev)
+    bg = torch.zeros(3)
+
+    def frame(P, seed):
+        sc = syn_blob(P, 64, 48, seed=seed, scale_mean=0.05)
+        st = settings_for(sc.camera, 0, GaussianRasterizationSettings, bg, device=dev)
+        kw = dict(means3D=sc.means3D.to(dev), means2D=torch.zeros(P, 3, device=dev), opacities=torch.sigmoid(sc.opacity_logit).to(dev),
+                  shs=sc.shs.to(dev), scales=torch.exp(sc.scaling_logit).to(dev), rotations=sc.rotation.to(dev))
+        return lambda: GaussianRasterizer(st)(**kw)
+
+    a, b = frame(900, 1), frame(300, 2)
+    try:
+        BinningPolicy.reset("exact")
+        with torch.no_grad():
+            with binning_hint("a"):
+                a()
+            with binning_hint("b"):
+                b()
+            ra, rb = BinningPolicy.known["a"], BinningPolicy.known["b"]
+            assert ra != rb and ra > 0 and rb > 0
+            BinningPolicy.mode = "bounded"
+            BinningPolicy.known["a"] = ra + 7          # a stale number: poll() must replace it by the frame's true count
+            with binning_hint("a", tag="pending"):
+                a()                                     # queued, count not read
+            assert len(BinningPolicy.pending) == 1
+            BinningPolicy.mode = "exact"
+            for _ in range(2 * COUNT_RING + 3):         # unhinted exact forwards of ANOTHER scene walk the whole ring twice
+                b()
+            assert BinningPolicy.poll(block=True) == [] and BinningPolicy.known["a"] == ra and not BinningPolicy.pending
+    finally:
+        BinningPolicy.reset("exact")

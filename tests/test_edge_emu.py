@@ -210,3 +210,7 @@ def test_render_glue_gradients_match_reference_autograd(emu, monkeypatch):
 def test_tile_lists_are_the_oracles_minus_invisible_instances(emu):
     R, R_ref, worst = edge_cases.check_tile_lists_against_oracle(emu, 400)
     assert R < R_ref and worst < 1 / 255
+
+
+def test_pending_frames_are_verified_with_their_own_count(emu):
+    edge_cases.check_count_slots_survive_unpolled_forwards(emu)   # (CPU: every frame has a word of its own; the bookkeeping is what runs)

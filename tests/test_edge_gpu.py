@@ -59,3 +59,10 @@ def test_tile_lists_are_the_oracles_minus_invisible_instances(gpu, n):
 
 def test_operator_error_behaviour(gpu, tmp_path):
     edge_cases.check_operator_error_behaviour(gpu, tmp_path)
+
+
+@pytest.mark.parametrize("binding", ["compiled", "ctypes"])
+def test_count_slots_survive_unpolled_forwards(gpu, binding):
+    from tests.ops_util import _with_binding
+    with _with_binding(binding):
+        edge_cases.check_count_slots_survive_unpolled_forwards(gpu)

@@ -202,3 +202,7 @@ def test_compiled_binding_equals_ctypes_binding(emu):
 
 def test_compiled_adam_takes_gate_flags_only_when_sound(emu):
     ops_util.check_compiled_gate_flags_are_sound(emu)
+
+
+def test_operator_bindings_agree(emu):
+    ops_util.check_operator_bindings_agree(emu)

@@ -100,3 +100,7 @@ def test_compiled_binding_equals_ctypes_binding(gpu):
 
 def test_compiled_adam_takes_gate_flags_only_when_sound(gpu):
     ops_util.check_compiled_gate_flags_are_sound(gpu, Wm=32, W=96, H=64)
+
+
+def test_operator_bindings_agree(gpu):
+    ops_util.check_operator_bindings_agree(gpu)
