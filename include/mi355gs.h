@@ -259,7 +259,7 @@ int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float
  * replaces: the body of the loop at reference train.py:140-211 — render(camera_pose=P[view]) -> (1-l)*L1 +
  *   l*(1-SSIM) -> backward -> PerPointAdam.step() — for the configuration the reference's scripts run: SH colours
  *   (active degree sh_degree 0..3 over 16 stored coefficients), scale/rotation covariance, --pp_optimizer
- *   --optim_pose.  12 launches, no host sync.
+ *   --optim_pose.  11 launches, no host sync.
  *   Parameter tensors use the reference's GaussianModel layouts (scene/gaussian_model.py:166-171): xyz[P,3],
  *   f_dc[P,1,3], f_rest[P,15,3], opacity[P,1], scaling[P,3], rotation[P,4], poses[V,7]; exp_avg/exp_avg_sq: host
  *   arrays of 7 device pointers in the optimizer's group order (xyz, f_dc, f_rest, opacity, scaling, rotation, pose).

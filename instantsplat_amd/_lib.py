@@ -133,7 +133,7 @@ def compiled():
         _EXT = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(_EXT)
     _EXT.forget_gates()
-    _EXT.bind({name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value for name in _EXT_SYMBOLS})
+    _EXT.bind({name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value for name in _EXT_SYMBOLS}, _TEST_MODE)
     _EXT_BOUND_TO = L
     return _EXT
 

@@ -7,7 +7,8 @@
 //   -> (1-l)*L1 + l*(1-SSIM) -> SSIM/L1 backward -> composite backward -> projection backward
 //   -> pose/activation backward (incl. the 7 pose gradients) -> PerPointAdam over all 7 parameter groups
 //
-// 17 kernel launches, no host synchronisation, no temporary allocation: every buffer lives in one caller-provided
+// 11 kernel launches (projection, tile count, tile scan, scatter, tile sort, composite, fused loss, composite backward,
+// projection backward, pose finish + loss value, PerPointAdam), no host synchronisation, no temporary allocation: every buffer lives in one caller-provided
 // workspace that the trainer carves up once.  The same kernels (and launch helpers) as the op-by-op path are used,
 // so results are identical up to the order of float atomics.  The instance buffers have a fixed capacity; the
 // true count is written to *num_rendered every step so the caller can verify it asynchronously.

@@ -45,9 +45,11 @@ struct Abi {
   decltype(&mi355gs_adam_multi_step) adam_multi_step = nullptr;
   decltype(&mi355gs_error_string) error_string = nullptr;
   bool bound = false;
+  bool allow_cpu = false;   // only the CPU test tier (SIMT-emulated build of the kernels) runs on CPU tensors
 } g_abi;
 
-void bind_abi(const std::map<std::string, uintptr_t>& sym) {
+void bind_abi(const std::map<std::string, uintptr_t>& sym, bool allow_cpu_tensors) {
+  g_abi.allow_cpu = allow_cpu_tensors;
   auto get = [&](const char* name) {
     auto it = sym.find(name);
     TORCH_CHECK(it != sym.end() && it->second, "mi355gs torch binding: entry point ", name, " was not provided");
@@ -109,6 +111,7 @@ void wait_for_count(const int32_t* count, const DeviceScope& dev, const Tensor& 
 }
 
 Tensor f32c(const Tensor& t, const char* name, const Tensor& like) {
+  TORCH_CHECK(t.is_cuda() || g_abi.allow_cpu, "instantsplat_amd operators run on the GPU only (got a CPU tensor; there is no CPU fallback)");
   TORCH_CHECK(t.scalar_type() == at::kFloat, "expected float32, got ", t.scalar_type(), " (", name, ")");
   TORCH_CHECK(t.device() == like.device(), "tensors on different devices: ", like.device(), " vs ", t.device(), " (", name, ")");
   return t.is_contiguous() ? t : t.contiguous();
@@ -469,6 +472,7 @@ struct AdamPlan {
     TORCH_CHECK(n >= 1 && n <= 8 && exp_avg.size() == n && exp_avg_sq.size() == n && pp.size() == n, "AdamPlan: 1..8 tensors, equal-length lists");
     for (size_t t = 0; t < n; ++t) {
       const Tensor& q = params[t];
+      TORCH_CHECK(q.is_cuda() || g_abi.allow_cpu, "instantsplat_amd operators run on the GPU only (got a CPU tensor; there is no CPU fallback)");
       TORCH_CHECK(q.scalar_type() == at::kFloat && q.is_contiguous(), "AdamPlan: parameters must be contiguous float32");
       for (const Tensor* s : {&exp_avg[t], &exp_avg_sq[t]})
         TORCH_CHECK(s->scalar_type() == at::kFloat && s->is_contiguous() && s->device() == q.device() && s->numel() == q.numel(),
@@ -541,7 +545,7 @@ struct AdamPlan {
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled PyTorch binding of libmi355gs.so's drop-in operators (no compute of its own)";
-  m.def("bind", &bind_abi, "hand over the C-ABI entry points (name -> address) of the loaded libmi355gs build");
+  m.def("bind", &bind_abi, "hand over the C-ABI entry points (name -> address) of the loaded libmi355gs build; allow_cpu_tensors: test tier only");
   m.def("render_posed", &render_posed);
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);

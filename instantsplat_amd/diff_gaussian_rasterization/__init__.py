@@ -234,6 +234,9 @@ class _CountRing:
 
     def __init__(self):
         self.words = torch.zeros(2 * COUNT_RING, dtype=torch.int32, pin_memory=True)
+        self.views = [self.words[k:k + 1] for k in range(2 * COUNT_RING)]   # made once: slicing a tensor costs ~2 us per frame
+        self.values = self.words.numpy()                                    # the same memory, for reading a count without a tensor op
+        self.index_of = {v.data_ptr(): k for k, v in enumerate(self.views)}
         self.next = 0
         self.free = list(range(2 * COUNT_RING - 1, COUNT_RING - 1, -1))
         self.reserved = {}   # address of a handed-out reserved word -> its index, until BinningPolicy.defer() takes it over
@@ -257,13 +260,24 @@ def count_slot(dev):
     if BinningPolicy.deferred_capacity() is None:
         k = ring.next
         ring.next = (k + 1) % COUNT_RING
-        return ring.words[k:k + 1]
+        return ring.views[k]
     if not ring.free:
         raise RuntimeError(f"more unverified frames than count slots: call BinningPolicy.poll() at least every {COUNT_RING} forwards")
     k = ring.free.pop()
-    slot = ring.words[k:k + 1]
+    slot = ring.views[k]
     ring.reserved[slot.data_ptr()] = k
     return slot
+
+
+def read_count(slot) -> int:
+    """The value of a count word (after the frame's tile scan is known to have run)."""
+    if _COUNT_RINGS:
+        ptr = slot.data_ptr()
+        for ring in _COUNT_RINGS.values():
+            k = ring.index_of.get(ptr)
+            if k is not None:
+                return int(ring.values[k])
+    return int(slot[0])
 
 
 def _cpu_deep_copy_tuple(input_tuple):

@@ -152,7 +152,7 @@ def render_posed_compiled(ext, pc, pose, means2D, bg, view, proj, origin, H, W, 
     ck = (xyz.shape[0], W, H, key)
     color, radii = ext.render_posed(xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
                                     bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree, -1, _LAST_COUNT.get(ck, 0), slot)
-    r = int(slot[0])
+    r = dgr.read_count(slot)
     if len(_LAST_COUNT) > 256:
         _LAST_COUNT.clear()
     _LAST_COUNT[ck] = r

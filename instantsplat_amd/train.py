@@ -190,7 +190,7 @@ def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = T
 
 class FusedTrainer:
     """Whole iteration in one library call (mi355gs_trainer_step): same kernels as the op-by-op path, no autograd
-    graph, no temporaries, 12 launches.  Used by RunAhead whenever the configuration is the one the reference's
+    graph, no temporaries, 11 launches.  Used by RunAhead whenever the configuration is the one the reference's
     scripts run (SH colours of any active degree, scale/rotation covariance, PerPointAdam with pose optimisation)."""
 
     ORDER = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")

@@ -886,7 +886,7 @@ def check_compiled_binding_equals_ctypes(dev, iters=5, Wm=12, W=40, H=32):
                     assert plans and all(p.last_used_gates == 6 for p in plans), [(p.last_used_gates, p.last_gate_note) for p in plans]
             BinningPolicy.reset("exact")
         for a_, b_ in zip(res["ctypes"][0], res["compiled"][0]):
-            bound("compiled_vs_ctypes/loss", abs(a_ - b_) / max(abs(a_), 1e-6), 2e-4 if cuda else 0.0)
+            bound("compiled_vs_ctypes/loss", abs(a_ - b_) / max(abs(a_), 1e-6), 1e-3 if cuda else 0.0)   # MI355X, two runs of one binding: 1.4e-4
         for n in names:
             for k, what in ((1, "param"), (2, "exp_avg_sq")):
                 # GPU: float-atomic order only.  f_rest takes its first Adam steps in this run (degree 1), and a first step is
