@@ -282,15 +282,25 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
 // A lane owns FOUR pixels, one in each 8x8 quadrant of the tile (same lane -> (x, y) offset inside every quadrant), so
 //  * culling stays wave-uniform per quadrant (four ballots, one scalar mask walk over their union), and
 //  * the nine moments of a Gaussian are first accumulated in registers over the lane's pixels (plain FMAs) and cross the
-//    lanes ONCE per (Gaussian, tile) instead of once per (Gaussian, quadrant): the 64-lane transposed reduction is
-//    ~125 issue cycles (8 v_permlane*_swap at 8 cycles, 9 DPP / select ops at 4; tools/ubench/valu_rate.hip) against
-//    ~100 for one quadrant's pixel math, and a Gaussian touches 1.5-2 quadrants of a tile on the benchmark scenes —
-//    round 1 paid the reduction (and nine atomics) for every one of them.
+//    lanes ONCE per (Gaussian, tile) instead of once per (Gaussian, quadrant) — a Gaussian touches 1.5-2 quadrants of a tile
+//    on the benchmark scenes, and round 1 paid the reduction (and nine atomics) for every one of them.  The reduction itself
+//    goes through LDS since round 3 (BW_REDUCE_LDS below: ~50 VALU issue cycles); rounds 1-2 transposed it in registers
+//    (8 v_permlane*_swap at 8 cycles + 9 DPP / select ops: ~125 issue cycles, more than a quadrant's pixel math).
 constexpr uint32_t BW_XCD_RUN = 64;   // consecutive units sent to the same XCD (C3, FETCH_SIZE per launch: none 90 MB, 16: 56, 32: 50, 64: 47; time 124.6 / 122.1 / 122.0 / 122.7 us)
 #ifndef GS_BW_MFMA
 #define GS_BW_MFMA 0
 #endif
-constexpr bool BW_REDUCE_MFMA = GS_BW_MFMA != 0;   // A/B build switch of the experiment in replay_one (tools/variants.sh)
+#ifndef GS_BW_LDS
+#define GS_BW_LDS 1   // shipped: measured on MI355X at C3 124.5 -> 109.4 us against the register-transposed reduction (GS_BW_LDS=0),
+#endif                // 182 us with the cross-row half on the matrix pipe (GS_BW_MFMA=1); profiles/r03_ab_bwd_*
+constexpr bool BW_REDUCE_MFMA = GS_BW_MFMA != 0;   // A/B build switches of the reduction in replay_one (tools/build_variant.sh)
+constexpr bool BW_REDUCE_LDS = GS_BW_LDS != 0;
+// BW_REDUCE_LDS: the nine per-lane moments cross the wave through LDS: nine moment-major rows of 64 floats (pitch RED_PITCH:
+// 64 + 4, so that the 16-float quarters four neighbouring readers take start in different banks), written with nine
+// ds_write_b32 (lane = column) and read back by 36 lanes — moment = lane / 4, quarter = lane % 4 — as four ds_read_b128 each;
+// 15 adds, two quad_perm steps and lanes 0, 4, .., 32 hold the nine sums.  The LDS crossbar moves the data on its own pipe;
+// the VALU is left with the additions (~40 issue cycles instead of ~128 for the register-transposed form).
+constexpr int RED_PITCH = 68;
 constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgroups give the dispatcher the finest grain (129.4 -> 128.2 us at C3 against 4)
 
 // CHUNKS: 64-instance chunks per unit (1, or 0 = the frame's own value from meta[2] for the longer units of big frames; the
@@ -311,6 +321,7 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
   __shared__ float4 s_q0[BW_UNITS][GS_SEG];
   __shared__ float4 s_q1[BW_UNITS][GS_SEG];
   __shared__ float4 s_q2[BW_UNITS][GS_SEG];
+  __shared__ __attribute__((aligned(16))) float s_red[BW_UNITS][BW_REDUCE_LDS ? 9 * RED_PITCH : 4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // Workgroup p runs on XCD p mod 8 (round-robin dispatch), each XCD behind its own L2.  Consecutive units are mostly units of
   // one tile and re-read the same 8 KiB of per-pixel state, so they should share an L2: inside every block of 8 * BW_XCD_RUN
@@ -458,7 +469,29 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
 #ifdef GS_PROBE
     pr_steps += 1;
 #endif
-    if constexpr (BW_REDUCE_MFMA) {
+    if constexpr (BW_REDUCE_LDS) {
+      if (any_valid) {
+        float* __restrict__ red = s_red[wave];
+        // (LDS operations of one wave execute in program order: the reads below see this step's writes, and the next step's
+        // writes come after these reads — no barrier; the fences keep the compiler from reordering across lanes' accesses)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        red[0 * RED_PITCH + lane] = m0; red[1 * RED_PITCH + lane] = m1; red[2 * RED_PITCH + lane] = m2;
+        red[3 * RED_PITCH + lane] = m3; red[4 * RED_PITCH + lane] = m4; red[5 * RED_PITCH + lane] = m5;
+        red[6 * RED_PITCH + lane] = m6; red[7 * RED_PITCH + lane] = m7; red[8 * RED_PITCH + lane] = m8;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float part = 0.f;
+        if (lane < 36) {
+          const float4* q = reinterpret_cast<const float4*>(red + (lane >> 2) * RED_PITCH + (lane & 3) * 16);
+          const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+          part = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+        }
+        part += gs_dpp<0xB1>(part);   // quad_perm [1,0,3,2]
+        part += gs_dpp<0x4E>(part);   // quad_perm [2,3,0,1]: every lane of the quad holds the moment's sum over the wave
+        if ((lane & 3) == 0 && lane < 36) atomicAdd(reinterpret_cast<float*>(grads + id) + (lane >> 2), part);
+      }
+    } else if constexpr (BW_REDUCE_MFMA) {
       if (any_valid) {
         // EXPERIMENT: the cross-row half of the reduction on the matrix pipe.  v_mfma_f32_16x16x4_f32 computes
         // D[i][j] += sum_k A[i][k] B[k][j] with A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[4 R + t][j] in register t of
