@@ -278,8 +278,11 @@ def main():
         finally:
             _lib.check(L.mi355gs_profile_work_counters(None), "profile_work_counters")
         steps_c, quads, quads_valid, lanes, reduced, waves = [float(x) / V for x in ctr.tolist()[:6]]
-        CYC = {"step": 34.0, "quad": 28.0, "quad_valid": 58.0, "reduce": 128.0}     # VALU issue cycles per part
-        INS = {"step": 12.0, "quad": 8.0, "quad_valid": 24.0, "reduce": 30.0}       # VALU wave-instructions per part
+        # per-part costs of the SHIPPED binary (tools/isa_cost.py on hipcc -S of composite.hip; the reduction is the LDS form of
+        # round 3: 22 VALU instructions / 52 cycles + 9 LDS instructions; rounds 1-2's register-transposed form was 30 / 128).
+        # tools/validate_issue_model.py checks the instruction total against SQ_INSTS_VALU on a fixed frame (profiles/).
+        CYC = {"step": 34.0, "quad": 28.0, "quad_valid": 58.0, "reduce": 52.0}      # VALU issue cycles per part
+        INS = {"step": 12.0, "quad": 8.0, "quad_valid": 24.0, "reduce": 22.0}       # VALU wave-instructions per part
         cyc = steps_c * CYC["step"] + quads * CYC["quad"] + quads_valid * CYC["quad_valid"] + reduced * CYC["reduce"]
         ins = steps_c * INS["step"] + quads * INS["quad"] + quads_valid * INS["quad_valid"] + reduced * INS["reduce"]
         n_simd, clock = 1024.0, 2.4e9
@@ -326,16 +329,19 @@ def main():
                 out.setdefault(k.replace("void ", "").split("<")[0], row)
         return out
 
-    traffic, traffic_src = None, None
+    traffic, traffic_src, fwd_traffic = None, None, None
     try:  # HBM-side bytes per launch: rocprofv3 --pmc passes of this command, collected separately (counters cannot run inside a
         # timed bench) and committed under profiles/; the newest round present is used and named
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
-                f_, w_ = pmc_rows(f"{rnd}_pmc_c3_FETCH_SIZE.csv")["k_composite_bwd"], pmc_rows(f"{rnd}_pmc_c3_WRITE_SIZE.csv")["k_composite_bwd"]
+                fr, wr = pmc_rows(f"{rnd}_pmc_c3_FETCH_SIZE.csv"), pmc_rows(f"{rnd}_pmc_c3_WRITE_SIZE.csv")
+                f_, w_ = fr["k_composite_bwd"], wr["k_composite_bwd"]
             except (OSError, KeyError):
                 continue
             # counters are in KiB; gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2
             traffic = (2.0 * float(f_["mean_FETCH_SIZE"]) + float(w_["mean_WRITE_SIZE"])) * 1024.0
+            if "k_composite_fwd" in fr and "k_composite_fwd" in wr:
+                fwd_traffic = (2.0 * float(fr["k_composite_fwd"]["mean_FETCH_SIZE"]) + float(wr["k_composite_fwd"]["mean_WRITE_SIZE"])) * 1024.0
             traffic_src = f"profiles/{rnd}_pmc_c3_FETCH_SIZE.csv + {rnd}_pmc_c3_WRITE_SIZE.csv (separate rocprofv3 --pmc passes of this command)"
             break
     except Exception:
@@ -343,7 +349,7 @@ def main():
 
     valu = None
     try:  # SQ counter pass of the same command (separate run)
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 row = pmc_rows(f"{rnd}_pmc_c3_SQ_counters.csv")["k_composite_bwd"]
             except (OSError, KeyError):
@@ -421,7 +427,11 @@ def main():
                                  "64-instance units (DESIGN.md 4.2b) that re-read a 16 B/pixel boundary record and 32 B/pixel of pixel state "
                                  "per unit, L2 / Infinity-Cache resident at this size; units grow to 512 instances on large frames",
                          "composite_fwd": {"avg_kernel_ms": fwd_ms, "launches": fwd_n, "algorithmic_bytes_per_launch": fwd_bytes,
-                                           "achieved": fwd_bytes / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0}},
+                                           "achieved": fwd_bytes / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0,
+                                           "frac": (fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fwd_ms > 0 else 0.0,
+                                           "traffic": fwd_traffic,
+                                           "note": "traffic above the algorithmic bytes: the forward leaves a 16 B/pixel boundary record per "
+                                                   "64-instance unit of every tile for the segmented backward (DESIGN.md 4.2b)"}},
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
