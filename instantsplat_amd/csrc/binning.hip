@@ -376,9 +376,16 @@ __device__ __forceinline__ uint32_t sort_xor32(uint32_t u) {
   const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return (threadIdx.x & 32) ? p[0] : p[1];
 }
+#ifndef GS_SORT_BPERMUTE
+#define GS_SORT_BPERMUTE 0
+#endif
+// A/B build switch (tools/build_variant.sh): every lane exchange of the network through the LDS crossbar (ds_bpermute_b32: no
+// VALU issue cycles, its own pipe) instead of DPP moves / row swaps
+constexpr bool SORT_BPERMUTE = GS_SORT_BPERMUTE != 0;
 template <int LM>
 __device__ __forceinline__ uint32_t lane_xchg32(uint32_t v) {
-  if constexpr (LM == 1) return sort_dpp<0xB1>(v);
+  if constexpr (SORT_BPERMUTE) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ LM) << 2), (int)v);
+  else if constexpr (LM == 1) return sort_dpp<0xB1>(v);
   else if constexpr (LM == 2) return sort_dpp<0x4E>(v);
   else if constexpr (LM == 3) return sort_dpp<0x1B>(v);
   else if constexpr (LM == 4) {

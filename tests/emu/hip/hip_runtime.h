@@ -354,6 +354,13 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
   if (sl < 0 || !emu::lane_in_op(buf, (unsigned)sl)) return bound_ctrl ? 0 : old;
   return emu::from_bits<int>(emu::ctx().waves[emu::wave_id()].val[buf][sl]);
 }
+// ds_bpermute_b32: every lane reads `src` of the lane whose index is addr / 4 (mod 64)
+static inline int __builtin_amdgcn_ds_bpermute(int addr, int src) {
+  int buf = emu::wave_exchange(emu::to_bits(src), true);
+  const unsigned sl = ((unsigned)addr >> 2) & 63u;
+  if (!emu::lane_in_op(buf, sl)) return 0;
+  return emu::from_bits<int>(emu::ctx().waves[emu::wave_id()].val[buf][sl]);
+}
 // gfx950 row swaps: returns {new first operand, new second operand}
 struct emu_uint2v { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
 // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second

@@ -2,7 +2,10 @@
 tools/ubench/valu_rate.hip on MI355X (cycles per wave64 instruction per SIMD with >= 4 waves resident):
   plain fp32 add/mul/fma/fmac/mov/sub ........ 2      packed fp32 (v_pk_*), DPP, v_cmp*, v_cndmask, v_min/max/med3, cvt,
   integer/logic VALU, v_readlane, v_mad_u64 ... 4      transcendental (v_exp/log/rcp/rsq/sqrt), v_permlane*_swap ........ 8
-usage: python tools/isa_cost.py file.s kernel_substring [first_label last_label]"""
+usage: python tools/isa_cost.py file.s kernel_substring [first_label last_label]
+       python tools/isa_cost.py --bwd-model file.s      -> JSON: per-part VALU instructions / issue cycles of k_composite_bwd<1,false>
+       (the table bench.py's roofline.compute multiplies the kernel's work counters with; __graft_entry__.build() regenerates it
+       from the compiler's output of the shipped source into instantsplat_amd/lib/bwd_issue_model.json)"""
 import re, sys, collections
 
 FAST = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mov_b32", "v_mac_f32", "v_fmaak_f32", "v_fmamk_f32",
@@ -25,7 +28,68 @@ def cost(op, line):
     return 4, "other-valu"
 
 
+def bwd_model(path):
+    """Per-part costs of the backward composite kernel's replay loop, from its basic blocks.  A block is recognised by what it
+    contains: v_exp_f32 = a quadrant body up to the `any lane valid` test ("quad"), v_rcp_f32 inside the loop = the rest of the
+    body ("quad_valid"), the LDS write .. atomic group = the reduction ("reduce"), blocks made of nothing but v_mov (the
+    moments' initialisation the compiler peeled out of the first quadrant body: executed when that body does not run) =
+    "init", everything else inside the loop = "step"; everything outside the loop = "wave" (prologue / epilogue, once per
+    unit).  The loop is unrolled by two (ping-pong record registers): every part is averaged over its copies."""
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "k_composite_bwdILi1ELb0" in l and ":" in l and not l.startswith("\t"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    blocks, cur = [], []
+    for l in lines[start:end + 1]:
+        t = l.strip()
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            blocks.append(cur); cur = []
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        cur.append(t)
+        if t.split()[0].startswith("s_cbranch") or t.split()[0] == "s_branch":
+            blocks.append(cur); cur = []
+    blocks.append(cur)
+    has = lambda b, op: any(t.split()[0].startswith(op) for t in b)
+    valu = lambda b: [t for t in b if t.startswith("v_")]
+    first = next(i for i in range(len(blocks) - 1) if has(blocks[i], "s_flbit") and has(blocks[i + 1], "v_exp_f32"))
+    last = max(i for i, b in enumerate(blocks) if has(b, "global_atomic"))
+    parts = {k: [0, 0] for k in ("step", "quad", "quad_valid", "reduce", "init", "wave")}
+    copies = sum(1 for b in blocks[first:last + 1] if has(b, "ds_write"))
+    in_reduce = False
+    for i, b in enumerate(blocks):
+        v = valu(b)
+        n, c = len(v), sum(cost(t.split()[0], t)[0] for t in v)
+        if i < first or i > last:
+            k = "wave"
+        else:
+            if has(b, "ds_write"):
+                in_reduce = True
+            if in_reduce:
+                k = "reduce"
+                if has(b, "global_atomic"):
+                    in_reduce = False
+            elif has(b, "v_exp_f32"):
+                k = "quad"
+            elif has(b, "v_rcp_f32"):
+                k = "quad_valid"
+            elif n >= 8 and all(t.split()[0].startswith("v_mov_b32") for t in v):
+                k = "init"
+            else:
+                k = "step"
+        parts[k][0] += n; parts[k][1] += c
+    per = {"step": copies, "quad": 4 * copies, "quad_valid": 4 * copies, "reduce": copies, "init": max(1, sum(
+        1 for b in blocks[first:last + 1] if len(valu(b)) >= 8 and all(t.split()[0].startswith("v_mov_b32") for t in valu(b)))), "wave": 1}
+    import json
+    out = {"INS": {k: parts[k][0] / per[k] for k in parts}, "CYC": {k: parts[k][1] / per[k] for k in parts},
+           "loop_copies": copies, "source": "hipcc -S of instantsplat_amd/csrc/composite.hip, k_composite_bwd<1, false>; tools/isa_cost.py --bwd-model",
+           "note": "init = the peeled initialisation of the nine moments: runs once per step in which the first quadrant body does not"}
+    print(json.dumps(out))
+
+
 def main():
+    if sys.argv[1] == "--bwd-model":
+        return bwd_model(sys.argv[2])
     path, kern = sys.argv[1], sys.argv[2]
     lo = sys.argv[3] if len(sys.argv) > 3 else None
     hi = sys.argv[4] if len(sys.argv) > 4 else None

@@ -47,13 +47,12 @@ for cam in st.cameras:
 torch.cuda.synchronize()
 _lib.check(L.mi355gs_profile_work_counters(None), "work_counters")
 steps, quads, quads_valid, lanes, reduced, waves = [float(x) / len(st.cameras) for x in ctr.tolist()[:6]]
-import re
-src = open(os.path.join(ROOT, "bench.py")).read()
-INS = eval(re.search(r"INS = (\{[^}]*\})", src).group(1))
-CYC = eval(re.search(r"CYC = (\{[^}]*\})", src).group(1))
-ins = steps * INS["step"] + quads * INS["quad"] + quads_valid * INS["quad_valid"] + reduced * INS["reduce"]
-cyc = steps * CYC["step"] + quads * CYC["quad"] + quads_valid * CYC["quad_valid"] + reduced * CYC["reduce"]
+tab = json.load(open(os.path.join(ROOT, "instantsplat_amd", "lib", "bwd_issue_model.json")))
+INS, CYC = tab["INS"], tab["CYC"]
+inits = max(steps - quads_valid / 4.0, 0.0)
+ins = steps * INS["step"] + quads * INS["quad"] + quads_valid * INS["quad_valid"] + reduced * INS["reduce"] + inits * INS["init"] + waves * INS["wave"]
+cyc = steps * CYC["step"] + quads * CYC["quad"] + quads_valid * CYC["quad_valid"] + reduced * CYC["reduce"] + inits * CYC["init"] + waves * CYC["wave"]
 print(json.dumps({"frames": "C3 after 200 iterations, frozen; mean over the 3 views", "steps": steps, "quadrant_bodies": quads,
-                  "quadrant_bodies_with_valid_lanes": quads_valid, "reductions": reduced,
+                  "quadrant_bodies_with_valid_lanes": quads_valid, "reductions": reduced, "waves_with_work": waves,
                   "model_valu_wave_instructions_per_launch": ins, "model_valu_issue_cycles_per_launch": cyc,
                   "compare_with": "mean_SQ_INSTS_VALU of `k_composite_bwd<1, false>` in the PMC csv of this command"}))
