@@ -377,13 +377,16 @@ __device__ __forceinline__ uint32_t sort_xor32(uint32_t u) {
   return (threadIdx.x & 32) ? p[0] : p[1];
 }
 #ifndef GS_SORT_BPERMUTE
-#define GS_SORT_BPERMUTE 0
+#define GS_SORT_BPERMUTE 2   // shipped: 14.35 -> 13.55 us at C3 (profiles/r03_ab_sort_bpermute_kernel_avg.txt)
 #endif
-// A/B build switch (tools/build_variant.sh): every lane exchange of the network through the LDS crossbar (ds_bpermute_b32: no
+// A/B build switch (tools/build_variant.sh): lane exchanges of the network through the LDS crossbar (ds_bpermute_b32: no
 // VALU issue cycles, its own pipe) instead of DPP moves / row swaps
-constexpr bool SORT_BPERMUTE = GS_SORT_BPERMUTE != 0;
+// (0: none — rounds 1-2; 1: all exchanges; 2: only the ones that would need a v_permlane*_swap + select — lane masks 16, 31,
+// 32, 63: 12 VALU issue cycles per 32-bit word against one ds_bpermute.  Measured at C3: 0: 14.3 us, 1: 18.7 us (the network is
+// a chain of dependent stages and the crossbar's latency is not covered when every stage takes it), 2: 13.5 us)
 template <int LM>
 __device__ __forceinline__ uint32_t lane_xchg32(uint32_t v) {
+  constexpr bool SORT_BPERMUTE = GS_SORT_BPERMUTE == 1 || (GS_SORT_BPERMUTE == 2 && LM >= 16);
   if constexpr (SORT_BPERMUTE) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ LM) << 2), (int)v);
   else if constexpr (LM == 1) return sort_dpp<0xB1>(v);
   else if constexpr (LM == 2) return sort_dpp<0x4E>(v);

@@ -11,7 +11,7 @@ mkdir -p "$tmp/../include_stub" "$ROOT/instantsplat_amd/lib/variants"
 # the sources include ../../include/mi355gs.h relative to csrc/: rebuild that layout around the temporary directory
 work="$(mktemp -d)"; mkdir -p "$work/pkg/csrc" "$work/include" "$work/pkg/lib"
 cp "$tmp"/* "$work/pkg/csrc/"; cp "$ROOT/include/mi355gs.h" "$work/include/"
-make -C "$work/pkg/csrc" -j8 EXTRA="$*" > "$work/build.log" 2>&1 || { tail -20 "$work/build.log"; exit 1; }
+make -C "$work/pkg/csrc" -j8 EXTRA="$*" ../lib/libmi355gs.so > "$work/build.log" 2>&1 || { tail -20 "$work/build.log"; exit 1; }
 cp "$work/pkg/lib/libmi355gs.so" "$ROOT/instantsplat_amd/lib/variants/$name.so"
 rm -rf "$tmp" "$work"
 echo "built instantsplat_amd/lib/variants/$name.so ($*)"
