@@ -122,7 +122,10 @@ __device__ __forceinline__ float gs_power2(float dx, float dy, float A, float C,
 // form, bit-identical images — a wave that finishes early no longer waits for its tile's slowest quadrant, 59 VGPRs keep eight
 // waves per SIMD, and neither the scheduler's atomics nor its bookkeeping in k_scan_tiles exist any more.
 // ------------------------------------------------------------------------------------------------
-constexpr int FWD_GROUP = 2;
+#ifndef GS_FWD_GROUP
+#define GS_FWD_GROUP 2
+#endif
+constexpr int FWD_GROUP = GS_FWD_GROUP;   // hits per walk step (A/B build switch)
 
 __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uint32_t capacity, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ list, const GsRec* __restrict__ recs,
@@ -132,15 +135,17 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
                                                         const uint32_t* __restrict__ part_first, uint4* __restrict__ unit_tile,
                                                         float4* __restrict__ bstate, uint32_t max_units,
                                                         const uint32_t* __restrict__ meta) {
-  __shared__ float4 s_q0[4][GS_SEG];
-  __shared__ float4 s_q1[4][GS_SEG];
-  __shared__ float4 s_q2[4][GS_SEG];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // The wave's staged group: 64 records of three float4 each, record-major (48 B apiece), at an address the SCALAR unit knows —
+  // the wave index is read into an SGPR and the walk's record index is scalar already, so a hit's three broadcast reads take
+  // ONE address register filled by a v_mov from an SGPR plus immediate offsets.  (Three separate arrays indexed through the
+  // per-thread wave index cost three v_add_u32 per hit: 12 of the ~78 VALU issue cycles of a hit.)  Lane i's three 16-byte
+  // stores at a 48-byte pitch are bank-conflict-free (12 i mod 64 enumerates sixteen disjoint groups of four banks).
+  __shared__ float4 s_rec[4][GS_SEG][3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
   const int tile = (int)order[blockIdx.x];      // heaviest tiles first
   const uint32_t seg_len = meta[2] * GS_SEG;    // instances per backward unit of this frame (k_scan_tiles)
-  float4* __restrict__ q0s = s_q0[wave];
-  float4* __restrict__ q1s = s_q1[wave];
-  float4* __restrict__ q2s = s_q2[wave];
+  float4 (*__restrict__ recl)[3] = s_rec[wave];
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
     const int cnt = (int)min((uint32_t)GS_SEG, end - base);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the previous group's LDS reads are done (only this wave reads its staging area)
-    reinterpret_cast<v4f*>(q0s)[lane] = r0; reinterpret_cast<v4f*>(q1s)[lane] = r1; reinterpret_cast<v4f*>(q2s)[lane] = r2;
+    *reinterpret_cast<v4f*>(&recl[lane][0]) = r0; *reinterpret_cast<v4f*>(&recl[lane][1]) = r1; *reinterpret_cast<v4f*>(&recl[lane][2]) = r2;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool hit = lane < cnt && quad_hit(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r1[0], r1[1], r1[2], r1[3]), q);
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
       float4 col[FWD_GROUP];
 #pragma unroll
       for (int u = 0; u < FWD_GROUP; ++u) {
-        const float4 a0 = q0s[idx[u]], a1 = q1s[idx[u]];
-        col[u] = q2s[idx[u]];
+        const float4 a0 = recl[idx[u]][0], a1 = recl[idx[u]][1];
+        col[u] = recl[idx[u]][2];
         const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
         const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
         const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
@@ -243,6 +248,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
         C0 += col[u].x * w; C1 += col[u].y * w; C2 += col[u].z * w;
         // blended <=> alpha passed the tests and this is not the stopping Gaussian (w > 0 exactly then): mask logic
         // on the two compare results instead of a third compare
+        // (carrying this position in the staged record's unused depth slot — one broadcast read wider, no scalar-to-vector move
+        // per hit — measured slower: 75.5 -> 78.1 us at C3; three or four hits per walk step: 78.2 / 81.7 us)
         last = (valid[u] && !stop) ? (base - start) + (uint32_t)idx[u] + 1u : last;
         Tr = stop ? -fabsf(Tr) : test_T;
       }
@@ -318,11 +325,10 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
                                                         const uint4* __restrict__ unit_tile, const float4* __restrict__ bstate,
                                                         const uint32_t* __restrict__ meta, uint32_t max_units,
                                                         unsigned long long* __restrict__ counters) {
-  __shared__ float4 s_q0[BW_UNITS][GS_SEG];
-  __shared__ float4 s_q1[BW_UNITS][GS_SEG];
-  __shared__ float4 s_q2[BW_UNITS][GS_SEG];
+  __shared__ float4 s_rec[BW_UNITS][GS_SEG][3];   // the staged chunk, record-major, at a scalar address (see k_composite_fwd)
   __shared__ __attribute__((aligned(16))) float s_red[BW_UNITS][BW_REDUCE_LDS ? 9 * RED_PITCH : 4];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = BW_UNITS == 1 ? 0 : (int)__builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
   // Workgroup p runs on XCD p mod 8 (round-robin dispatch), each XCD behind its own L2.  Consecutive units are mostly units of
   // one tile and re-read the same 8 KiB of per-pixel state, so they should share an L2: inside every block of 8 * BW_XCD_RUN
   // launch positions the index is transposed, and units RUN b .. RUN b + RUN - 1 of the block all land on XCD b.
@@ -356,9 +362,7 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t chunks = CHUNKS ? (uint32_t)CHUNKS : meta[2], seg_len = chunks * GS_SEG;   // instances per unit
   const uint32_t boff = seg * seg_len;  // contributor index (0-based) of this unit's first instance
-  float4* __restrict__ q0s = s_q0[wave];
-  float4* __restrict__ q1s = s_q1[wave];
-  float4* __restrict__ q2s = s_q2[wave];
+  float4 (*__restrict__ recl)[3] = s_rec[wave];
 
   // ---- the lane's four pixels
   const int px0 = tx * GS_TILE + (lane & 7), py0 = ty * GS_TILE + (lane >> 3);
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
       const uint32_t id = list[start + cb + lane];
       const GsRec* r = recs + id;
       const float4 col = r->q2;  // (r, g, b, depth): depth is not used here, its slot carries the Gaussian's index
-      q0s[lane] = r->q0; q1s[lane] = r->q1; q2s[lane] = make_float4(col.x, col.y, col.z, __uint_as_float(id));
+      recl[lane][0] = r->q0; recl[lane][1] = r->q1; recl[lane][2] = make_float4(col.x, col.y, col.z, __uint_as_float(id));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
     // cull: record `lane` against the four quadrant boxes; instances behind every pixel of a quadrant are dropped too
     {
       float4 r0 = make_float4(0.f, 0.f, -1.f, -1.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lane < cnt) { r0 = q0s[lane]; r1 = q1s[lane]; }
+      if (lane < cnt) { r0 = recl[lane][0]; r1 = recl[lane][1]; }
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         Quad q;
@@ -570,21 +574,21 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
     if (!many) continue;
     // back-to-front walk over the union mask, unrolled by two with ping-pong record registers: the next record's LDS reads
     // (wave-uniform addresses: broadcasts) are issued before the current record's math
-    auto xy = [&](int i) { const float4& r = q0s[i]; return make_float2(r.x, r.y); };   // the walk only needs the centre
+    auto xy = [&](int i) { const float4& r = recl[i][0]; return make_float2(r.x, r.y); };   // the walk only needs the centre
     int iA = 63 - __clzll((long long)many), iB = iA;
     float2 A0 = xy(iA), B0 = A0;
-    float4 A1 = q1s[iA], A2 = q2s[iA], B1 = A1, B2 = A2;
+    float4 A1 = recl[iA][1], A2 = recl[iA][2], B1 = A1, B2 = A2;
     for (;;) {
       many &= ~(1ull << iA);
       const bool moreB = many != 0;
       if (moreB) iB = 63 - __clzll((long long)many);
-      B0 = xy(iB); B1 = q1s[iB]; B2 = q2s[iB];
+      B0 = xy(iB); B1 = recl[iB][1]; B2 = recl[iB][2];
       replay_one(A0, A1, A2, iA);
       if (!moreB) break;
       many &= ~(1ull << iB);
       const bool moreA = many != 0;
       if (moreA) iA = 63 - __clzll((long long)many);
-      A0 = xy(iA); A1 = q1s[iA]; A2 = q2s[iA];
+      A0 = xy(iA); A1 = recl[iA][1]; A2 = recl[iA][2];
       replay_one(B0, B1, B2, iB);
       if (!moreA) break;
     }
