@@ -124,8 +124,9 @@ int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, in
 /* Tuning / test knob of the segmented backward (csrc/common.h, GS_MIN_UNITS): a frame's backward units are lengthened
  * (2, 4, 8 chunks of 64 instances) only while at least `min_units` of them remain.  Returns the previous value;
  * min_units <= 0 only queries.  Process-wide; the default (40960) is what every measurement uses — tests lower it to
- * run the multi-chunk path on small scenes.  It also enters the buffer-size queries: set it before sizing a frame's buffers
- * and keep it until that frame's backward has been enqueued. */
+ * run the multi-chunk path on small scenes.  It also enters the buffer-size queries: for the per-operator entry points set it
+ * before sizing a frame's buffers and keep it until that frame's backward has been enqueued; a trainer handle takes a
+ * snapshot of it at mi355gs_trainer_create and uses that for all its calls. */
 int mi355gs_tune_min_units(int min_units);
 
 /* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that

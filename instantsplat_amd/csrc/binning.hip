@@ -581,17 +581,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_tiles(int T, const uint32
 }  // namespace
 
 static int g_min_units = GS_MIN_UNITS;
+thread_local int g_min_units_pinned = 0;   // a trainer handle's snapshot of the knob, in force for the duration of its calls
 extern "C" int mi355gs_tune_min_units(int min_units) {
   const int old = g_min_units;
   if (min_units > 0) g_min_units = min_units;
   return old;
 }
-int gs_min_units() { return g_min_units; }
+int gs_min_units() { return g_min_units_pinned > 0 ? g_min_units_pinned : g_min_units; }
+void gs_pin_min_units(int v) { g_min_units_pinned = v; }
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
                          uint32_t* meta, uint32_t* seg_first, uint32_t* part_first) {
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order, meta, seg_first,
-                     part_first, (uint32_t)g_min_units);
+                     part_first, (uint32_t)gs_min_units());
   return 0;
 }
 

@@ -56,7 +56,8 @@ __host__ __device__ inline int gs_unit_level_for(long long instances, long long 
   while (level + 1 < GS_UNIT_LEVELS && instances / ((long long)(2 * 64) << level) >= min_units) ++level;
   return level;
 }
-int gs_min_units();               // binning.hip: the mi355gs_tune_min_units knob
+int gs_min_units();               // binning.hip: the mi355gs_tune_min_units knob (or the value a trainer handle pinned for its calls)
+void gs_pin_min_units(int v);     // > 0: this thread sizes and launches with v until it is reset to 0 (trainer.hip)
 constexpr int GS_MIN_UNITS = 40960;  // lengthen units only while at least this many remain (6-7 rounds of the 6144 resident waves:
                                      // measured at C4, 7.3 M instances: 512-instance units 2.34 ms/view, 256: 2.28, 128: 2.21, 64: 2.24)
 

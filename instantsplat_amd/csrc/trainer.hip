@@ -40,6 +40,9 @@ struct Trainer {
   uint32_t* adam_live;  // see MultiAdamArgs::live
   uint32_t adam_seq;
   bool consts_ready;
+  int min_units;   // the unit-length knob as it stood when the workspace was carved: every later call of the handle sizes and
+                   // launches with THIS value, whatever mi355gs_tune_min_units has been set to since (the buffers were laid
+                   // out for it)
 };
 
 struct Carver {
@@ -161,6 +164,7 @@ void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float
     t->m[k] = exp_avg[k]; t->v[k] = exp_avg_sq[k];
   }
   t->pplr = per_point_lr;
+  t->min_units = gs_min_units();
   carve(*t, workspace);
   t->consts_ready = false;
   return t;
@@ -194,11 +198,12 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     t->consts_ready = true;
   }
   struct HookScope {
-    HookScope(float* gate, const GsPrologue& pro, const GsPosed& posed) {
+    HookScope(float* gate, const GsPrologue& pro, const GsPosed& posed, int min_units) {
+      gs_pin_min_units(min_units);
       g_fused.skip_memsets = true; g_fused.gate = gate; g_fused.prologue = pro; g_fused.posed = posed;
       g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_sh_rest = 2; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5; g_fused.gate_pose = 6;
     }
-    ~HookScope() { g_fused = GsFusedStepHooks(); }
+    ~HookScope() { g_fused = GsFusedStepHooks(); gs_pin_min_units(0); }
   };
   GsPrologue pro;  // the step's accumulators are cleared by its first kernel (k_pose_fwd)
   {
@@ -209,7 +214,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   }
   GsPosed posed;
   posed.pose = t->poses + 7 * (size_t)view; posed.acc = t->pose_scratch; posed.partial = t->pose_partial;
-  HookScope hook_scope(t->adam_scratch, pro, posed);
+  HookScope hook_scope(t->adam_scratch, pro, posed, t->min_units);
   const float* view_m = t->consts;
   const float* campos = t->consts + 16;
   const float* pose = t->poses + 7 * (size_t)view;

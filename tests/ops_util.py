@@ -991,3 +991,39 @@ def check_operator_bindings_agree(dev):
                 vals[binding] = (float(v.detach()), xi.grad.detach().cpu().clone())
         bound("bindings/ssim_%s/value" % padding, abs(vals["ctypes"][0] - vals["compiled"][0]), 1e-7 if cuda else 0.0)
         bound("bindings/ssim_%s/grad" % padding, relerr(vals["compiled"][1], vals["ctypes"][1]), 1e-6 if cuda else 0.0)
+
+
+def check_trainer_keeps_its_unit_length_knob(dev, Wm=14, W=48, H=32):
+    """A trainer handle lays its workspace out for the unit-length knob (mi355gs_tune_min_units) as it stood at create; later
+    steps must keep sizing and launching with that value even if the process-wide knob has been changed since (ADVICE r2:
+    the step used to re-read the knob, so a change between create and step moved the unit table past its allocation)."""
+    from instantsplat_amd import _lib
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training, train_iteration
+    L = _lib.lib()
+    sc = syn_pointmap(3, Wm, Wm, W, H, seed=13)
+    names = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation", "P")
+    old = L.mi355gs_tune_min_units(0)
+    cuda = torch.device(dev).type == "cuda"
+    res = {}
+    try:
+        for change in (False, True):
+            L.mi355gs_tune_min_units(2)          # long units on this small scene: the multi-chunk layout
+            st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+            losses = [train_iteration(st, fused_step=True)]
+            assert getattr(st, "_trainer", None) is not None
+            if change:
+                L.mi355gs_tune_min_units(old)    # the handle must not notice
+            losses += [train_iteration(st, fused_step=True) for _ in range(4)]
+            res[change] = (losses, {n: getattr(st.gaussians, n).detach().cpu().clone() for n in names})
+            st._trainer.close()
+            BinningPolicy.reset("exact")
+        for a_, b_ in zip(res[False][0], res[True][0]):
+            bound("trainer_knob/loss", abs(a_ - b_) / max(abs(a_), 1e-6), 1e-3 if cuda else 0.0)
+        for n in names:
+            bound("trainer_knob/param" + n, rel_l2(res[True][1][n], res[False][1][n]), 2e-4 if cuda else 0.0)
+    finally:
+        L.mi355gs_tune_min_units(old)
+        BinningPolicy.reset("exact")

@@ -206,3 +206,7 @@ def test_compiled_adam_takes_gate_flags_only_when_sound(emu):
 
 def test_operator_bindings_agree(emu):
     ops_util.check_operator_bindings_agree(emu)
+
+
+def test_trainer_keeps_its_unit_length_knob(emu):
+    ops_util.check_trainer_keeps_its_unit_length_knob(emu)

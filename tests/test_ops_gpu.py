@@ -104,3 +104,7 @@ def test_compiled_adam_takes_gate_flags_only_when_sound(gpu):
 
 def test_operator_bindings_agree(gpu):
     ops_util.check_operator_bindings_agree(gpu)
+
+
+def test_trainer_keeps_its_unit_length_knob(gpu):
+    ops_util.check_trainer_keeps_its_unit_length_knob(gpu, Wm=40, W=128, H=96)
