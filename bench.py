@@ -111,6 +111,11 @@ def main():
     st = setup_training(scene, dev, opt=opt)
     P = st.gaussians.get_xyz.shape[0]
     st.gaussians.active_sh_degree = args.sh_degree
+    # The line is quoted on the regime of the reference's first 1000 iterations (SH degree 0, train.py:149-150 raises it every
+    # 1000).  Warm-up + repeated blocks + the sibling loops run more than 1000 iterations of the SAME state in total, so the degree
+    # is pinned for the whole measurement (--sh-degree picks another one): without this the later blocks and both sibling loops
+    # silently ran at degree 1 (Adam over f_rest, SH backward: +25 us per iteration).
+    st.gaussians.oneupSHdegree = lambda: None
     if args.sh_degree:
         args.cpu_iters = 0   # the CPU trainer restates the degree-0 schedule only
 
