@@ -272,6 +272,20 @@ constexpr int FTHREADS = 512;      // eight waves per workgroup: the tile's LDS 
                                    // what puts four waves on every SIMD
 constexpr int F_STAGE_ITERS = (FR2 * FXP + FTHREADS - 1) / FTHREADS;   // 6
 constexpr int FER = FT * FT / FTHREADS;   // output rows per thread in the last pass (2)
+// Run lengths of the column pass C and the row pass D (outputs per item).  A longer run reads fewer inputs per output (run + 10
+// for run outputs) but makes fewer items: 7 / 8 give 252 / 168 items for 512 threads, i.e. phase C runs on four of the
+// workgroup's eight waves.  Shorter runs that fill the workgroup were measured and are slower at 512^2 (A/B build switches,
+// profiles/r03_ab_ssim_run_lengths_kernel_avg.txt): C/D = 7/8 17.2 us (shipped), 4/8 17.5, 4/4 18.0, 6/4 18.9 — the second
+// resident workgroup of the CU already fills the SIMDs, and the extra LDS reads per output cost more than the idle waves.
+#ifndef GS_SSIM_RUN_C
+#define GS_SSIM_RUN_C 7
+#endif
+#ifndef GS_SSIM_RUN_D
+#define GS_SSIM_RUN_D 8
+#endif
+constexpr int FCR = GS_SSIM_RUN_C, FC_GROUPS = (FR1 + FCR - 1) / FCR;   // 7 -> 6 groups x 42 columns = 252 items; 4 -> 11 x 42 = 462
+constexpr int FDR = GS_SSIM_RUN_D, FD_GROUPS = FT / FDR;                // 8 -> 4 groups x 42 rows = 168 items; 4 -> 8 x 42 = 336
+static_assert(FC_GROUPS * FR1 <= FTHREADS && FD_GROUPS * FR1 <= FTHREADS && FT % FDR == 0 && FDR % 2 == 0, "one item per thread");
 
 __global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                         float ks /* d loss / d ssim_mean / N */, float kl /* d loss / d l1_mean / N */,
@@ -349,16 +363,16 @@ __global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const 
   __syncthreads();
   // ---- C: forward column pass + SSIM formula, item = (column, 7 consecutive rows): 17 inputs per moment -> 7 outputs
   float val = 0.f;
-  if (tid < FR1 * 6) {
-    const int c = tid % FR1, r0 = (tid / FR1) * 7;
-    float mo[5][7];
+  if (tid < FR1 * FC_GROUPS) {
+    const int c = tid % FR1, r0 = (tid / FR1) * FCR;
+    float mo[5][FCR];
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      float v[17];
+      float v[FCR + 10];
 #pragma unroll
-      for (int t = 0; t < 17; ++t) v[t] = s_h[m][r0 + t][c];
+      for (int t = 0; t < FCR + 10; ++t) v[t] = s_h[m][min(r0 + t, FR2 - 1)][c];   // (rows past the last one feed outputs that are not kept)
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
+      for (int j = 0; j < FCR; ++j) {
         float a = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k) a = fmaf(gw(k), v[j + k], a);
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const 
     }
     const int gx = ox + c - HALO;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < FCR; ++j) {
       const int r = r0 + j, gy = oy + r - HALO;
       const float mu1 = mo[0][j], mu2 = mo[1][j];
       const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const 
       const float d1 = (mu2 * 2.f * Dd) * invAB - (mu2 * 2.f * Cc) * invAB - t * invA + t * invB;
       const float d2 = -m * invB;
       const float d3 = 2.f * Cc * invAB;
-      const bool in_img = gx >= 0 && gx < W && gy >= 0 && gy < H;
+      const bool in_img = gx >= 0 && gx < W && gy >= 0 && gy < H && r < FR1;
       // (the staged inputs stay readable until the barrier below: s_d aliases them, and phase C reads only s_h)
       mo[0][j] = in_img ? d1 : 0.f; mo[1][j] = in_img ? d2 : 0.f; mo[2][j] = in_img ? d3 : 0.f;
       const bool in_tile = c >= HALO && c < HALO + FT && r >= HALO && r < HALO + FT;
@@ -387,22 +401,23 @@ __global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const 
     }
     // all phase-B readers of s_xy are past the barrier above, so the maps may overwrite it
 #pragma unroll
-    for (int j = 0; j < 7; ++j) { s_d[0][r0 + j][c] = mo[0][j]; s_d[1][r0 + j][c] = mo[1][j]; s_d[2][r0 + j][c] = mo[2][j]; }
+    for (int j = 0; j < FCR; ++j)
+      if (FR1 % FCR == 0 || r0 + j < FR1) { s_d[0][r0 + j][c] = mo[0][j]; s_d[1][r0 + j][c] = mo[1][j]; s_d[2][r0 + j][c] = mo[2][j]; }
   }
   __syncthreads();
   // ---- D: backward row pass, item = (row, 8 consecutive columns): 18 inputs per map -> 8 outputs
-  if (tid < FR1 * 4) {
-    const int r = tid % FR1, c0 = (tid / FR1) * 8;   // rows vary fastest across lanes
+  if (tid < FR1 * FD_GROUPS) {
+    const int r = tid % FR1, c0 = (tid / FR1) * FDR;   // rows vary fastest across lanes
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      float v[18];
+      float v[FDR + 10];
 #pragma unroll
-      for (int t = 0; t < 18; t += 2) {
+      for (int t = 0; t < FDR + 10; t += 2) {
         const float2 a = *reinterpret_cast<const float2*>(&s_d[m][r][c0 + t]);
         v[t] = a.x; v[t + 1] = a.y;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < FDR; ++j) {
         float a = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k) a = fmaf(gw(k), v[j + k], a);
