@@ -93,7 +93,8 @@ constexpr int GS_SEG = 64;
 // on the number of units for the buffers.
 
 struct BinningLayout {
-  size_t keys, list, unit_tile, bstate, total;
+  size_t keys, list, unit_tile, bstate, hitmask, total;
+  uint32_t max_chunks;  // 64-instance chunks the hit-mask table has room for
   uint32_t max_units;  // table / boundary slots available: an upper bound on the units of any frame with <= R instances
   bool may_loop;       // a frame with this capacity can have units longer than one chunk
   __host__ BinningLayout(int64_t R, int T) {
@@ -110,6 +111,12 @@ struct BinningLayout {
     max_units = (uint32_t)((lim > by_top ? lim : by_top) + (size_t)(T > 0 ? T : 1));
     unit_tile = o; o += gs_align((size_t)max_units * 16);  // uint4 per unit, in launch order: (tile x | tile y << 16, segment, slot, 0)
     bstate = o; o += gs_align((size_t)max_units * 256 * sizeof(float4));  // per boundary: 256 pixels x (T, C0, C1, C2)
+    // Per 64-instance chunk of a tile's list, the four quadrants' hit masks the forward's cull produced (which of the chunk's
+    // instances can reach alpha >= 1/255 somewhere in the quadrant): the backward reads them instead of repeating the test
+    // (4 x ~60 VALU instructions per unit).  Chunk index = (first unit of the tile + unit) * chunks per unit + chunk, which is
+    // below instances / 64 + 8 per tile at every unit length.
+    max_chunks = (uint32_t)(by_chunks + 8 * (size_t)(T > 0 ? T : 1) + 8);
+    hitmask = o; o += gs_align((size_t)max_chunks * 4 * sizeof(uint64_t));
     total = o;
   }
 };

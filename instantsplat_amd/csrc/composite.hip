@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ seg_first,
                                                         const uint32_t* __restrict__ part_first, uint4* __restrict__ unit_tile,
                                                         float4* __restrict__ bstate, uint32_t max_units,
-                                                        const uint32_t* __restrict__ meta) {
+                                                        const uint32_t* __restrict__ meta, unsigned long long* __restrict__ hitmask,
+                                                        uint32_t max_chunks) {
   // The wave's staged group: 64 records of three float4 each, record-major (48 B apiece), at an address the SCALAR unit knows —
   // the wave index is read into an SGPR and the walk's record index is scalar already, so a hit's three broadcast reads take
   // ONE address register filled by a v_mov from an SGPR plus immediate offsets.  (Three separate arrays indexed through the
@@ -198,6 +199,11 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
     __builtin_amdgcn_wave_barrier();
     const bool hit = lane < cnt && quad_hit(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r1[0], r1[1], r1[2], r1[3]), q);
     unsigned long long mask = __ballot(hit);
+    {
+      // the backward's cull of this chunk for this quadrant, done: chunk index = first unit of the tile * chunks per unit + group
+      const uint32_t chunk = seg0 * meta[2] + (base - start) / GS_SEG;
+      if (lane == 0 && chunk < max_chunks) hitmask[(size_t)chunk * 4 + wave] = mask;
+    }
     if (base + GS_SEG < end) {
       fetch(id_next, r0, r1, r2);
       id_next = list_at(base + 2 * GS_SEG + (uint32_t)lane);
@@ -324,7 +330,8 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
                                                         const float* __restrict__ out_color,
                                                         const uint4* __restrict__ unit_tile, const float4* __restrict__ bstate,
                                                         const uint32_t* __restrict__ meta, uint32_t max_units,
-                                                        unsigned long long* __restrict__ counters) {
+                                                        unsigned long long* __restrict__ counters,
+                                                        const unsigned long long* __restrict__ hitmask, uint32_t max_chunks) {
   __shared__ float4 s_rec[BW_UNITS][GS_SEG][3];   // the staged chunk, record-major, at a scalar address (see k_composite_fwd)
   __shared__ __attribute__((aligned(16))) float s_red[BW_UNITS][BW_REDUCE_LDS ? 9 * RED_PITCH : 4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -557,17 +564,17 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // cull: record `lane` against the four quadrant boxes; instances behind every pixel of a quadrant are dropped too
+    // cull: the forward has tested every staged record against the four quadrants (quad_hit) and left the four masks of this
+    // chunk; instances behind every pixel of a quadrant are dropped here (scalar mask arithmetic).  A quadrant whose forward
+    // wave stopped before this chunk never wrote its mask — and has no pixel that reaches the chunk (wmaxq <= cb): masked off.
     {
-      float4 r0 = make_float4(0.f, 0.f, -1.f, -1.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lane < cnt) { r0 = recl[lane][0]; r1 = recl[lane][1]; }
+      const uint32_t chunk = slot * chunks + (uint32_t)c;
+      const unsigned long long* hm = hitmask + (size_t)min(chunk, max_chunks - 1u) * 4;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        Quad q;
-        q.x0 = (float)(tx * GS_TILE + (qd & 1) * 8); q.x1 = q.x0 + 7.f;
-        q.y0 = (float)(ty * GS_TILE + (qd >> 1) * 8); q.y1 = q.y0 + 7.f;
-        const bool hit = lane < cnt && cb + (uint32_t)lane < wmaxq[qd] && quad_hit(r0, r1, q);
-        mq[qd] = __ballot(hit);
+        const uint32_t reach = wmaxq[qd] > cb ? wmaxq[qd] - cb : 0u;   // instances of the chunk at or in front of the quadrant's last contributor
+        const unsigned long long keep = reach >= 64u ? ~0ull : ((1ull << reach) - 1ull);
+        mq[qd] = chunk < max_chunks ? (hm[qd] & keep) : 0ull;
       }
     }
     unsigned long long many = (mq[0] | mq[1]) | (mq[2] | mq[3]);
@@ -633,9 +640,10 @@ int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const
 int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uint32_t capacity, const uint32_t* tile_start,
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
                             uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, const uint32_t* part_first,
-                            uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta) {
+                            uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta, unsigned long long* hitmask,
+                            uint32_t max_chunks) {
   hipLaunchKernelGGL(k_composite_fwd, dim3(T), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T,
-                     n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta);
+                     n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks);
   return 0;
 }
 
@@ -645,13 +653,14 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint32_t* list, const GsRec* recs, const float* bg, const float* final_T,
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
-                            uint32_t max_units, bool may_loop, unsigned long long* counters) {
+                            uint32_t max_units, bool may_loop, const unsigned long long* hitmask, uint32_t max_chunks,
+                            unsigned long long* counters) {
   const uint32_t blk = 8u * BW_XCD_RUN;   // whole blocks of launch positions (see the index transposition in the kernel)
   const dim3 grid((max_units + blk - 1u) / blk * blk);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
 #define GS_BWD(CH, CNT)                                                                                                               \
   hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
-                     n_contrib, dL_dpix, grads, out_color, unit_tile, bstate, meta, max_units, counters)
+                     n_contrib, dL_dpix, grads, out_color, unit_tile, bstate, meta, max_units, counters, hitmask, max_chunks)
   if (counters) { if (!may_loop) GS_BWD(1, true); else GS_BWD(0, true); }
   else { if (!may_loop) GS_BWD(1, false); else GS_BWD(0, false); }
 #undef GS_BWD
