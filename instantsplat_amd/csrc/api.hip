@@ -16,10 +16,11 @@ int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, co
                       const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             float*, float*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint4*, float4*, uint32_t,
-                            const uint32_t*, unsigned long long*, uint32_t);
+                            const uint32_t*, unsigned long long*, uint32_t, uint32_t*);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint4*,
-                            const float4*, const uint32_t*, uint32_t, bool, const unsigned long long*, uint32_t, unsigned long long*);
+                            const float4*, const uint32_t*, uint32_t, bool, const unsigned long long*, uint32_t, const uint32_t*,
+                            unsigned long long*);
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
 // ---- optional per-kernel timing (HIP events on the launch stream)
@@ -149,7 +150,7 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
                             (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.seg_first), (const uint32_t*)(t + tl.part_first),
                             (uint4*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, (const uint32_t*)(t + tl.meta),
-                            (unsigned long long*)(b + bl.hitmask), bl.max_chunks);
+                            (unsigned long long*)(b + bl.hitmask), bl.max_chunks, (uint32_t*)(t + tl.qmax));
   }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;
@@ -194,7 +195,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                               (const GsRec*)(g + gl.rec), bg, (const float*)(t + tl.final_T), (const uint32_t*)(t + tl.n_contrib),
                               dL_dpix, grads, out_color, (const uint4*)(b + bl.unit_tile),
                               (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, bl.may_loop,
-                              (const unsigned long long*)(b + bl.hitmask), bl.max_chunks,
+                              (const unsigned long long*)(b + bl.hitmask), bl.max_chunks, (const uint32_t*)(t + tl.qmax),
                               g_prof.work_counters);
     }
     GS_CHECK_LAUNCH("composite_bwd");

@@ -62,7 +62,7 @@ constexpr int GS_MIN_UNITS = 40960;  // lengthen units only while at least this 
                                      // measured at C4, 7.3 M instances: 512-instance units 2.34 ms/view, 256: 2.28, 128: 2.21, 64: 2.24)
 
 struct TilesLayout {
-  size_t count, start, cursor, final_T, n_contrib, order, seg_first, part_first, meta, total;
+  size_t count, start, cursor, final_T, n_contrib, order, seg_first, part_first, meta, qmax, total;
   int gx, gy, T;
   __host__ TilesLayout(int W, int H) {
     gx = (W + GS_TILE - 1) / GS_TILE; gy = (H + GS_TILE - 1) / GS_TILE; T = gx * gy;
@@ -76,6 +76,7 @@ struct TilesLayout {
     seg_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of ceil(count / unit length): first unit of a tile
     part_first = o; o += gs_align(((size_t)T + 1) * 4);  // prefix over tiles of "the tile's last unit is shorter than the unit length"
     meta = o; o += gs_align(16);   // [1]: backward units of the frame, [2]: chunks of GS_SEG instances per unit, [3]: short units
+    qmax = o; o += gs_align((size_t)T * 4 * 4);   // per tile and 8x8 quadrant: the largest per-pixel contributor count (forward -> backward)
     total = o;
   }
 };

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
                                                         const uint32_t* __restrict__ part_first, uint4* __restrict__ unit_tile,
                                                         float4* __restrict__ bstate, uint32_t max_units,
                                                         const uint32_t* __restrict__ meta, unsigned long long* __restrict__ hitmask,
-                                                        uint32_t max_chunks) {
+                                                        uint32_t max_chunks, uint32_t* __restrict__ qmax) {
   // The wave's staged group: 64 records of three float4 each, record-major (48 B apiece), at an address the SCALAR unit knows —
   // the wave index is read into an SGPR and the walk's record index is scalar already, so a hit's three broadcast reads take
   // ONE address register filled by a v_mov from an SGPR plus immediate offsets.  (Three separate arrays indexed through the
@@ -269,6 +269,12 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
   const float Tfin = fabsf(Tr);
   for (uint32_t sg = next_boundary; sg + 1u < nseg; ++sg)
     if (seg0 + sg < max_units) bstate[(size_t)(seg0 + sg) * 256 + tid] = make_float4(Tfin, C0, C1, C2);
+  {
+    // the quadrant's largest contributor count: every backward unit of the tile needs it, and computed there it is a wave
+    // reduction per unit and quadrant (4 x 11 k per C3 frame) instead of one per forward wave
+    const uint32_t wmax = gs_wave_max_u32(last);
+    if (lane == 0) qmax[(size_t)tile * 4 + wave] = wmax;
+  }
   if (q.inside) {
     const size_t pix = (size_t)q.py * W + q.px, plane = (size_t)W * H;
     final_T[pix] = Tfin;
@@ -331,7 +337,8 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
                                                         const uint4* __restrict__ unit_tile, const float4* __restrict__ bstate,
                                                         const uint32_t* __restrict__ meta, uint32_t max_units,
                                                         unsigned long long* __restrict__ counters,
-                                                        const unsigned long long* __restrict__ hitmask, uint32_t max_chunks) {
+                                                        const unsigned long long* __restrict__ hitmask, uint32_t max_chunks,
+                                                        const uint32_t* __restrict__ qmax) {
   __shared__ float4 s_rec[BW_UNITS][GS_SEG][3];   // the staged chunk, record-major, at a scalar address (see k_composite_fwd)
   __shared__ __attribute__((aligned(16))) float s_red[BW_UNITS][BW_REDUCE_LDS ? 9 * RED_PITCH : 4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, 
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     behind[qd] = Tr[qd] * (bg0 * g0[qd] + bg1 * g1[qd] + bg2 * g2[qd]);  // dL/dC . (everything behind, background included)
-    wmaxq[qd] = __builtin_amdgcn_readfirstlane(gs_wave_max_u32((uint32_t)lastq[qd]));   // wave-uniform: keep it in an SGPR
+    wmaxq[qd] = qmax[(size_t)tile * 4 + qd];   // the forward's wave maximum of `last` over the quadrant: a scalar load
   }
   // the tile only needs instances [0, max over pixels of last)
   const uint32_t tile_max = min(max(max(wmaxq[0], wmaxq[1]), max(wmaxq[2], wmaxq[3])), end - start);
@@ -641,9 +648,9 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
                             uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, const uint32_t* part_first,
                             uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta, unsigned long long* hitmask,
-                            uint32_t max_chunks) {
+                            uint32_t max_chunks, uint32_t* qmax) {
   hipLaunchKernelGGL(k_composite_fwd, dim3(T), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T,
-                     n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks);
+                     n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax);
   return 0;
 }
 
@@ -654,13 +661,13 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units, bool may_loop, const unsigned long long* hitmask, uint32_t max_chunks,
-                            unsigned long long* counters) {
+                            const uint32_t* qmax, unsigned long long* counters) {
   const uint32_t blk = 8u * BW_XCD_RUN;   // whole blocks of launch positions (see the index transposition in the kernel)
   const dim3 grid((max_units + blk - 1u) / blk * blk);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
 #define GS_BWD(CH, CNT)                                                                                                               \
   hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
-                     n_contrib, dL_dpix, grads, out_color, unit_tile, bstate, meta, max_units, counters, hitmask, max_chunks)
+                     n_contrib, dL_dpix, grads, out_color, unit_tile, bstate, meta, max_units, counters, hitmask, max_chunks, qmax)
   if (counters) { if (!may_loop) GS_BWD(1, true); else GS_BWD(0, true); }
   else { if (!may_loop) GS_BWD(1, false); else GS_BWD(0, false); }
 #undef GS_BWD
