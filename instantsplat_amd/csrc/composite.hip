@@ -327,8 +327,13 @@ constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgro
 // COUNT: the measurement instantiation (mi355gs_profile_work_counters): the same kernel also adds up, per wave, how many
 // (Gaussian, tile) steps it ran, how many quadrant bodies, and how many lanes of those bodies were valid pixels — the inputs
 // of the VALU-issue model bench.py reports next to the HBM roofline.  The shipped launches use COUNT = false: no counters exist.
+#ifdef GS_BW_MIN_WAVES
+#define GS_BW_BOUNDS __launch_bounds__(64 * BW_UNITS, GS_BW_MIN_WAVES)   // A/B build switch: force a register budget
+#else
+#define GS_BW_BOUNDS __launch_bounds__(64 * BW_UNITS)
+#endif
 template <int CHUNKS, bool COUNT = false>
-__global__ __launch_bounds__(64 * BW_UNITS) void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
+__global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
                                                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
