@@ -444,3 +444,46 @@ def check_count_slots_survive_unpolled_forwards(dev):
             assert BinningPolicy.poll(block=True) == [] and BinningPolicy.known["a"] == ra and not BinningPolicy.pending
     finally:
         BinningPolicy.reset("exact")
+
+
+def check_speculative_stage2_overflow_is_rerendered(dev):
+    """The compiled nodes enqueue stage 2 of a forward before the frame's count has arrived, in buffers sized from the previous
+    frame of the same shape (1.5 x + 16384).  A frame that outgrows that guess must be projected and rendered again with exact
+    buffers: same image, radii and gradients as the ctypes binding (which always sizes exactly)."""
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy, GaussianRasterizationSettings, GaussianRasterizer
+    from instantsplat_amd.synthetic import syn_blob
+    from tests.ops_util import _with_binding
+    from tests.util import settings_for
+    dev = torch.device(dev)
+    P, W, H = 6000, 160, 128
+    bg = torch.zeros(3)
+
+    def run(scale_mean, seed):
+        sc = syn_blob(P, W, H, seed=seed, scale_mean=scale_mean)
+        st = settings_for(sc.camera, 0, GaussianRasterizationSettings, bg, device=dev)
+        means = sc.means3D.to(dev).requires_grad_(True)
+        color, radii = GaussianRasterizer(st)(means3D=means, means2D=torch.zeros(P, 3, device=dev, requires_grad=True),
+                                              opacities=torch.sigmoid(sc.opacity_logit).to(dev), shs=sc.shs.to(dev),
+                                              scales=torch.exp(sc.scaling_logit).to(dev), rotations=sc.rotation.to(dev))
+        color.sum().backward()
+        return color.detach().cpu(), radii.cpu(), means.grad.detach().cpu()
+
+    res = {}
+    try:
+        for binding in ("ctypes", "compiled"):
+            with _with_binding(binding):
+                BinningPolicy.reset("exact")
+                small = run(0.004, 1)       # a few thousand instances: the hint for the next frame of this shape
+                big = run(0.25, 2)          # > 20 x as many: far beyond 1.5 x + 16384
+                res[binding] = (small, big)
+        from instantsplat_amd import diff_gaussian_rasterization as dgr
+        counts = [v for k, v in dgr._LAST_COUNT.items() if k[:3] == (P, W, H)]
+        assert counts and max(counts) > 1.5 * 3000 + 16384 + 3000, counts   # the second frame did outgrow any guess from the first
+        cuda = dev.type == "cuda"
+        for i in (0, 1):
+            a, b = res["ctypes"][i], res["compiled"][i]
+            assert bool((a[1] == b[1]).all())
+            assert float((a[0] - b[0]).abs().max()) <= (1e-5 if cuda else 0.0)
+            assert float((a[2] - b[2]).norm() / (a[2].norm() + 1e-30)) <= (1e-5 if cuda else 0.0)
+    finally:
+        BinningPolicy.reset("exact")

@@ -214,3 +214,7 @@ def test_tile_lists_are_the_oracles_minus_invisible_instances(emu):
 
 def test_pending_frames_are_verified_with_their_own_count(emu):
     edge_cases.check_count_slots_survive_unpolled_forwards(emu)   # (CPU: every frame has a word of its own; the bookkeeping is what runs)
+
+
+def test_speculative_stage2_overflow_is_rerendered(emu):
+    edge_cases.check_speculative_stage2_overflow_is_rerendered(emu)

@@ -66,3 +66,7 @@ def test_count_slots_survive_unpolled_forwards(gpu, binding):
     from tests.ops_util import _with_binding
     with _with_binding(binding):
         edge_cases.check_count_slots_survive_unpolled_forwards(gpu)
+
+
+def test_speculative_stage2_overflow_is_rerendered(gpu):
+    edge_cases.check_speculative_stage2_overflow_is_rerendered(gpu)
