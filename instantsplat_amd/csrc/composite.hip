@@ -45,7 +45,7 @@ struct Quad {
 };
 
 __device__ __forceinline__ Quad make_quad_xy(int tx, int ty, int W, int H) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = (threadIdx.x >> 6) & 3, lane = threadIdx.x & 63;   // (the forward runs FWD_TILES tiles of four waves per workgroup)
   const int bx = tx * GS_TILE + (wave & 1) * 8, by = ty * GS_TILE + (wave >> 1) * 8;
   Quad q;
   q.px = bx + (lane & 7);
@@ -127,7 +127,19 @@ __device__ __forceinline__ float gs_power2(float dx, float dy, float A, float C,
 #endif
 constexpr int FWD_GROUP = GS_FWD_GROUP;   // hits per walk step (A/B build switch)
 
-__global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uint32_t capacity, const uint32_t* __restrict__ tile_start,
+// FWD_TILES tiles per workgroup, dealt serpentine from the heaviest-first order (positions p, 2Q - 1 - p, 2Q + p, 4Q - 1 - p):
+// sixteen independent waves, four per SIMD — quadrant q of all four tiles.  A 512^2 frame is one resident round of 4096 waves,
+// nothing rebalances it, and the kernel lasts as long as its busiest CU (probe: hits per CU up to 1.17x the mean, correlation
+// with the finish time 0.92).  Which CU a workgroup lands on cannot be chosen, but what a workgroup weighs can: a heavy, a light
+// and two middling tiles weigh about the same in every workgroup, and with 256 workgroups for 256 CUs a CU's load is one
+// workgroup's.  Measured at C3 (profiles/r03_ab_fwd_tiles_per_workgroup_kernel_avg.txt): 1 tile per workgroup 77.15 us, 2: 75.1, 4: 74.1.
+#ifndef GS_FWD_TILES
+#define GS_FWD_TILES 4
+#endif
+constexpr int FWD_TILES = GS_FWD_TILES;
+static_assert(FWD_TILES == 1 || FWD_TILES == 2 || FWD_TILES == 4, "one tile, a heavy + light pair, or two such pairs per workgroup");
+
+__global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ list, const GsRec* __restrict__ recs,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -141,12 +153,18 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int gx, int W, int H, uin
   // ONE address register filled by a v_mov from an SGPR plus immediate offsets.  (Three separate arrays indexed through the
   // per-thread wave index cost three v_add_u32 per hit: 12 of the ~78 VALU issue cycles of a hit.)  Lane i's three 16-byte
   // stores at a 48-byte pitch are bank-conflict-free (12 i mod 64 enumerates sixteen disjoint groups of four banks).
-  __shared__ float4 s_rec[4][GS_SEG][3];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
-  const int tile = (int)order[blockIdx.x];      // heaviest tiles first
+  __shared__ float4 s_rec[4 * FWD_TILES][GS_SEG][3];
+  const int tid = threadIdx.x & 255, lane = tid & 63;   // tid: the thread's index inside its TILE (pixel state, boundary records)
+  const int wave_wg = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 .. 4 FWD_TILES - 1
+  const int wave = wave_wg & 3;                                               // the quadrant
+  // position in the heaviest-first order: tile group j of workgroup p takes p, 2Q - 1 - p, 2Q + p, 4Q - 1 - p (Q workgroups): a
+  // serpentine deal, every position exactly once
+  const int nwg = (T + FWD_TILES - 1) / FWD_TILES, j = wave_wg >> 2;
+  const int pos = (j & 1) ? (j + 1) * nwg - 1 - (int)blockIdx.x : j * nwg + (int)blockIdx.x;
+  if (pos >= T) return;   // (tile count not a multiple of FWD_TILES; no workgroup barrier below)
+  const int tile = (int)order[pos];
   const uint32_t seg_len = meta[2] * GS_SEG;    // instances per backward unit of this frame (k_scan_tiles)
-  float4 (*__restrict__ recl)[3] = s_rec[wave];
+  float4 (*__restrict__ recl)[3] = s_rec[wave_wg];
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   [[maybe_unused]] const unsigned long long pr_t0 = GS_PROBE_CLOCK();
@@ -654,7 +672,7 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
                             uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, const uint32_t* part_first,
                             uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta, unsigned long long* hitmask,
                             uint32_t max_chunks, uint32_t* qmax) {
-  hipLaunchKernelGGL(k_composite_fwd, dim3(T), dim3(256), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T,
+  hipLaunchKernelGGL(k_composite_fwd, dim3((T + FWD_TILES - 1) / FWD_TILES), dim3(256 * FWD_TILES), 0, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T,
                      n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax);
   return 0;
 }
