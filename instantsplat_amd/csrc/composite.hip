@@ -133,12 +133,12 @@ constexpr int FWD_GROUP = GS_FWD_GROUP;   // hits per walk step (A/B build switc
 // with the finish time 0.92).  Which CU a workgroup lands on cannot be chosen, but what a workgroup weighs can: a heavy, a light
 // and two middling tiles weigh about the same in every workgroup, and with 256 workgroups for 256 CUs a CU's load is one
 // workgroup's.  Measured at C3 (profiles/r03_ab_fwd_tiles_per_workgroup_kernel_avg.txt): 1 tile per workgroup 77.15 us, 2: 75.1, 4: 74.1.
+// A frame with more tiles than that runs in several rounds, which the dispatcher balances by itself, and big workgroups only
+// coarsen its grain (C4, 8160 tiles: 581 us with one tile per workgroup, 606 with four): the launcher picks FWD_TILES per frame.
 #ifndef GS_FWD_TILES
-#define GS_FWD_TILES 4
+#define GS_FWD_TILES 0   // 0: by the frame's tile count (gs_launch_composite_fwd); 1, 2, 4: forced (A/B builds)
 #endif
-constexpr int FWD_TILES = GS_FWD_TILES;
-static_assert(FWD_TILES == 1 || FWD_TILES == 2 || FWD_TILES == 4, "one tile, a heavy + light pair, or two such pairs per workgroup");
-
+template <int FWD_TILES>
 __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ list, const GsRec* __restrict__ recs,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
@@ -672,8 +672,19 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
                             uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, const uint32_t* part_first,
                             uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta, unsigned long long* hitmask,
                             uint32_t max_chunks, uint32_t* qmax) {
-  hipLaunchKernelGGL(k_composite_fwd, dim3((T + FWD_TILES - 1) / FWD_TILES), dim3(256 * FWD_TILES), 0, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, out_color, final_T,
-                     n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax);
+  // equal-weight workgroups of 4 (2) tiles while the whole frame is one resident round of at most one (two) workgroups per CU
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  const int per_wg = GS_FWD_TILES ? GS_FWD_TILES : (T <= 4 * cus ? 4 : (T <= 4 * cus * 2 ? 2 : 1));
+#define GS_FWD(N)                                                                                                                   \
+  hipLaunchKernelGGL((k_composite_fwd<N>), dim3((T + N - 1) / N), dim3(256 * N), 0, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, \
+                     out_color, final_T, n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax)
+  if (per_wg == 4) GS_FWD(4); else if (per_wg == 2) GS_FWD(2); else GS_FWD(1);
+#undef GS_FWD
   return 0;
 }
 
