@@ -17,8 +17,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def emu_lib_path():
-    """g++ build of the UNMODIFIED kernel sources against the SIMT emulator (tests/emu)."""
+    """g++ build of the UNMODIFIED kernel sources against the SIMT emulator (tests/emu), and the compiled PyTorch binding
+    (host code only; a no-op when __graft_entry__.build() has already made it) that the operators go through by default."""
     subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "instantsplat_amd", "csrc_torch", "build.py")])
     return os.path.join(ROOT, "tests", "emu", "libmi355gs_emu.so")
 
 
