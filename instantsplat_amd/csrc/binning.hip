@@ -34,13 +34,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
   const int lo = tid * per, hi = min(T, lo + per);
   uint32_t local = 0;
   for (int i = lo; i < hi; ++i) local += count[i];
-  // wave inclusive scan
-  uint32_t incl = local;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t o = __shfl_up(incl, d);
-    if (lane >= d) incl += o;
-  }
+  // wave inclusive scan (DPP: this single-workgroup kernel is a chain of latencies, and a __shfl_up step is an LDS round trip)
+  const uint32_t incl = gs_wave_scan_incl_u32(local);
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
   uint32_t wave_off = 0, total = 0;
@@ -56,8 +51,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     __shared__ uint32_t s_max;
     uint32_t mx = 0;
     for (int i = lo; i < hi; ++i) mx = max(mx, count[i]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+    mx = gs_wave_max_u32(mx);
     hist[tid] = 0u;
     if (tid == 0) s_max = 0u;
     __syncthreads();
@@ -69,12 +63,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     __syncthreads();
     // exclusive scan of the 1024 bucket sizes (one per thread)
     const uint32_t h = hist[tid];
-    uint32_t hi_ = h;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t o = __shfl_up(hi_, d);
-      if (lane >= d) hi_ += o;
-    }
+    const uint32_t hi_ = gs_wave_scan_incl_u32(h);
     __shared__ uint32_t hist_wave[SCAN_THREADS / GS_WAVE];
     if (lane == 63) hist_wave[wave] = hi_;
     __syncthreads();
@@ -96,12 +85,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     // the full-length units first and the short ones last, where they shorten the tail of the kernel (composite.hip)
     uint32_t lseg = 0, lpart = 0;
     for (int i = lo; i < hi; ++i) { lseg += (count[i] + seg_len - 1) / seg_len; lpart += (count[i] % seg_len) != 0u; }
-    uint32_t iseg = lseg, ipart = lpart;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t o = __shfl_up(iseg, d), op = __shfl_up(ipart, d);
-      if (lane >= d) { iseg += o; ipart += op; }
-    }
+    const uint32_t iseg = gs_wave_scan_incl_u32(lseg), ipart = gs_wave_scan_incl_u32(lpart);
     __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
     __shared__ uint32_t part_wave[SCAN_THREADS / GS_WAVE];
     if (lane == 63) { seg_wave[wave] = iseg; part_wave[wave] = ipart; }

@@ -189,6 +189,22 @@ __device__ __forceinline__ uint32_t gs_wave_max_u32(uint32_t v) {
   return max(b[0], b[1]);
 }
 
+// wave64 inclusive prefix sum in six DPP adds (row_shr:1/2/4/8 inside the rows of 16, then row_bcast:15 and row_bcast:31 carry
+// the row totals on): no LDS crossbar round trip per step (a __shfl_up is a ds_bpermute).  All lanes must be active.
+__device__ __forceinline__ uint32_t gs_wave_scan_incl_u32(uint32_t v) {
+  auto up = [](uint32_t x, auto ctrl, auto rows) {   // lanes without a source (or in a masked row) receive 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(rows)::value, 0xF, false);
+  };
+  using all = std::integral_constant<int, 0xF>;
+  v += up(v, std::integral_constant<int, 0x111>{}, all{});   // row_shr:1
+  v += up(v, std::integral_constant<int, 0x112>{}, all{});   // row_shr:2
+  v += up(v, std::integral_constant<int, 0x114>{}, all{});   // row_shr:4
+  v += up(v, std::integral_constant<int, 0x118>{}, all{});   // row_shr:8  -> inclusive scan inside every row
+  v += up(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast:15 into rows 1 and 3
+  v += up(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // Transposed pair step of a multi-value wave reduction: lanes whose `bit` is clear keep `a`, the others keep
 // `b`; each lane adds its exchange partner's copy of the value it keeps.  Two values in, one out, and the
 // surviving value differs per lane — so after log2 steps nine values are reduced with ~1/3 of the DPP traffic

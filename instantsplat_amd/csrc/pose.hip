@@ -114,8 +114,19 @@ __global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __re
                                                                float* __restrict__ d_pose, float* __restrict__ pose_gate,
                                                                const float* __restrict__ loss_partial, int loss_nblocks,
                                                                double loss_inv_n, float lambda_dssim, float* __restrict__ loss) {
-  __shared__ float s_sum[64][17];
+  __shared__ float s_sum[16][17];
   __shared__ float s_tot[16];
+  // the rows of pose sums first: their loads are in flight while the loss partials are reduced (this kernel is pure latency)
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;  // 64 row groups x 16 sums; a wave reads 4 consecutive rows (256 B)
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  {
+    int r = g;
+    for (; r + 192 < nrows; r += 256) {
+      v0 += partial[(size_t)r * 16 + k]; v1 += partial[(size_t)(r + 64) * 16 + k];
+      v2 += partial[(size_t)(r + 128) * 16 + k]; v3 += partial[(size_t)(r + 192) * 16 + k];
+    }
+    for (; r < nrows; r += 64) v0 += partial[(size_t)r * 16 + k];
+  }
   // One-call train step: this single-workgroup, latency-bound kernel also sums the loss kernel's per-workgroup partials into the
   // loss VALUE (reference train.py:176; only ever read by the host) — in a fixed order, double accumulation — instead of a
   // finishing launch of its own.
@@ -133,20 +144,14 @@ __global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __re
       *loss = (1.0f - lambda_dssim) * (float)(tb * loss_inv_n) + lambda_dssim * (1.0f - (float)(ta * loss_inv_n));
     }
   }
-  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;  // 64 row groups x 16 sums; a wave reads 4 consecutive rows (256 B)
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;           // independent loads in flight: this kernel is pure latency
-  int r = g;
-  for (; r + 192 < nrows; r += 256) {
-    v0 += partial[(size_t)r * 16 + k]; v1 += partial[(size_t)(r + 64) * 16 + k];
-    v2 += partial[(size_t)(r + 128) * 16 + k]; v3 += partial[(size_t)(r + 192) * 16 + k];
-  }
-  for (; r < nrows; r += 64) v0 += partial[(size_t)r * 16 + k];
-  s_sum[g][k] = (v0 + v1) + (v2 + v3);
+  // a wave holds four row groups (its four rows of 16 lanes): add them with the row swaps, then 16 waves x 16 sums through LDS
+  const float wsum = gs_sum_rows((v0 + v1) + (v2 + v3));
+  if ((threadIdx.x & 63) < 16) s_sum[threadIdx.x >> 6][k] = wsum;
   __syncthreads();
   if (threadIdx.x < 16) {
     float t = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < 64; ++q) t += s_sum[q][threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s_sum[q][threadIdx.x];
     s_tot[threadIdx.x] = t;
   }
   __syncthreads();
