@@ -141,12 +141,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(int n, const uint32_t* __res
   for (int it = 0; it < SCAN_CHUNK / 256; ++it) {
     const int i = blockIdx.x * SCAN_CHUNK + it * 256 + tid;
     const uint32_t v = i < n ? in[i] : 0u;
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
+    const uint32_t incl = gs_wave_scan_incl_u32(v);
     __syncthreads();
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();

@@ -164,6 +164,24 @@ __device__ __forceinline__ float gs_wave_sum_row3(float v) {
   return v;
 }
 
+// the same for a double (two 32-bit DPP moves per step): the total lands in lanes 48..63
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double gs_dpp_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));   // lanes without a source read +0.0
+}
+__device__ __forceinline__ double gs_wave_sum_row3_f64(double v) {
+  v += gs_dpp_f64<0xB1>(v);
+  v += gs_dpp_f64<0x4E>(v);
+  v += gs_dpp_f64<0x141>(v);
+  v += gs_dpp_f64<0x140>(v);
+  v += gs_dpp_f64<0x142, 0xA>(v);
+  v += gs_dpp_f64<0x143, 0xC>(v);
+  return v;
+}
+
 // Two floats in an aligned VGPR pair: element-wise arithmetic on it compiles to CDNA3/4's full-rate packed-FP32 ops
 // (v_pk_add/mul/fma_f32: two lanes' worth of work per issue slot).
 typedef float gs_v2f __attribute__((vector_size(8)));

@@ -134,9 +134,8 @@ __global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __re
     __shared__ double s_la[16], s_lb[16];
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < loss_nblocks; i += 1024) { a += (double)loss_partial[2 * i]; b += (double)loss_partial[2 * i + 1]; }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-    if ((threadIdx.x & 63) == 0) { s_la[threadIdx.x >> 6] = a; s_lb[threadIdx.x >> 6] = b; }
+    a = gs_wave_sum_row3_f64(a); b = gs_wave_sum_row3_f64(b);   // DPP: a 64-bit shuffle butterfly is twelve LDS-crossbar round trips per value
+    if ((threadIdx.x & 63) == 63) { s_la[threadIdx.x >> 6] = a; s_lb[threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
       double ta = 0.0, tb = 0.0;

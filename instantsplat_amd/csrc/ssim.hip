@@ -126,10 +126,10 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __r
       }
     }
   }
-  val = gs_wave_sum(val);
-  l1 = gs_wave_sum(l1);
+  val = gs_wave_sum_row3(val);   // six DPP adds each (a shuffle butterfly is six LDS-crossbar round trips); the total is in lane 63
+  l1 = gs_wave_sum_row3(l1);
   const int wave = tid >> 6, lane = tid & 63;
-  if (lane == 0) { s_red[0][wave] = val; s_red[1][wave] = l1; }
+  if (lane == 63) { s_red[0][wave] = val; s_red[1][wave] = l1; }
   __syncthreads();
   if (tid == 0) {
     const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -145,10 +145,9 @@ __global__ __launch_bounds__(1024) void k_ssim_finish(int nblocks, double inv_n,
   __shared__ double s_a[16], s_b[16];
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 1024) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+  a = gs_wave_sum_row3_f64(a); b = gs_wave_sum_row3_f64(b);   // DPP adds; the totals are in lane 63
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { s_a[wave] = a; s_b[wave] = b; }
+  if (lane == 63) { s_a[wave] = a; s_b[wave] = b; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double ta = 0.0, tb = 0.0;
@@ -455,10 +454,10 @@ __global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const 
       }
     }
   }
-  val = gs_wave_sum(val);
-  l1 = gs_wave_sum(l1);
+  val = gs_wave_sum_row3(val);   // six DPP adds each (a shuffle butterfly is six LDS-crossbar round trips); the total is in lane 63
+  l1 = gs_wave_sum_row3(l1);
   const int wave = tid >> 6, lane = tid & 63;
-  if (lane == 0) { s_red[0][wave] = val; s_red[1][wave] = l1; }
+  if (lane == 63) { s_red[0][wave] = val; s_red[1][wave] = l1; }
   __syncthreads();
   if (tid == 0) {
     const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;

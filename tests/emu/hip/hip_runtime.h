@@ -425,6 +425,8 @@ static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v)
 static inline int __clzll(long long v) { return v == 0 ? 64 : __builtin_clzll((unsigned long long)v); }
 
 static inline unsigned __float_as_uint(float f) { return emu::from_bits<unsigned>(emu::to_bits(f)); }
+static inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, 8); return r; }
+static inline double __longlong_as_double(long long b) { double r; std::memcpy(&r, &b, 8); return r; }
 static inline int __float_as_int(float f) { return emu::from_bits<int>(emu::to_bits(f)); }
 static inline float __uint_as_float(unsigned u) { return emu::from_bits<float>(emu::to_bits(u)); }
 static inline float __int_as_float(int u) { return emu::from_bits<float>(emu::to_bits(u)); }
