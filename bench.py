@@ -65,6 +65,12 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         os.execv(sys.executable, cmd)
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (gloo announces every connection on stdout): keep the
+    # real stdout aside for the line and send everything else this process prints on descriptor 1 to stderr.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -453,7 +459,7 @@ def main():
                                                    "64-instance unit of every tile for the segmented backward (DESIGN.md 4.2b)"}},
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), file=line_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

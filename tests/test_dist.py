@@ -61,6 +61,8 @@ def test_bench_gpus2_spawns_two_ranks_end_to_end(emu_lib_path):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout     # rank 0 only
+    # ... and nothing else on stdout: gloo's connection announcements ("[Gloo] Rank 0 is connected to ...") go to stderr
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["collective_backend"] == "gloo" and "EMULATED" in out["data"]

@@ -23,7 +23,7 @@ done
 cp gpurun_out/pmc_c4_FETCH_SIZE.csv gpurun_out/${R}_pmc_c4_FETCH_SIZE.csv; cp gpurun_out/pmc_c4_WRITE_SIZE.csv gpurun_out/${R}_pmc_c4_WRITE_SIZE.csv
 cp gpurun_out/pmc_c4_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS_SQ_ACTIVE_INST_VALU_SQ_WAVE_CYCLES_SQ_BUSY_CYCLES_SQ_WAVES.csv gpurun_out/${R}_pmc_c4_SQ_counters.csv
 timeout 600 python tools/configs.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_baseline_configs_c1_c2_c4.txt; cat gpurun_out/${R}_baseline_configs_c1_c2_c4.txt
-timeout 300 python bench.py --gpus 2 --steps 100 --cpu-iters 0 > gpurun_out/${R}_bench_gpus2_shared_gpu.json 2> gpurun_out/bench_gpus2.err; tail -c 200 gpurun_out/bench_gpus2.err
+timeout 300 python bench.py --gpus 2 --steps 100 --cpu-iters 0 2> gpurun_out/bench_gpus2.err | grep "^{" > gpurun_out/${R}_bench_gpus2_shared_gpu.json; tail -c 200 gpurun_out/bench_gpus2.err   # (gloo announces its connections on stdout: keep the JSON line only)
 MI355GS_BINDING=compiled timeout 300 python tools/host_timeline.py 600 2>&1 | grep -v amdgpu > gpurun_out/${R}_dropin_host_timeline_compiled.txt
 MI355GS_BINDING=ctypes timeout 300 python tools/host_timeline.py 600 2>&1 | grep -v amdgpu > gpurun_out/${R}_dropin_host_timeline_ctypes.txt
 head -3 gpurun_out/${R}_dropin_host_timeline_compiled.txt gpurun_out/${R}_dropin_host_timeline_ctypes.txt
