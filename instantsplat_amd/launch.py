@@ -63,7 +63,9 @@ def device_identity(dev) -> dict:
 def assert_one_rank_per_device(reports: list, device_count: int):
     """With at least as many GPUs as ranks, two ranks on one device is a launcher bug that would silently halve the
     measured scaling: refuse it."""
-    seen = [r["gpu"].get("uuid") or r["gpu"].get("pci_bus_id") or r["gpu"]["device"] for r in reports]
+    # What decides it is the device index each rank selected on its host; uuid / PCI ids are reported, not trusted for this
+    # (a runtime that fills them with the same value for every GPU must not turn a correct launch into an error).
+    seen = [(r.get("host"), r["gpu"]["device"]) for r in reports]
     if device_count >= len(reports) and len(set(seen)) != len(seen):
         raise RuntimeError(f"ranks share a GPU although {device_count} are visible: {seen}")
 

@@ -87,3 +87,17 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in r.stderr
+
+
+def test_rank_device_collision_check():
+    """Two ranks on one device index of one host is refused when enough GPUs are visible; equal uuids alone (a runtime that
+    reports the same identity for every GPU) and the same index on different hosts are not."""
+    import pytest
+    from instantsplat_amd.launch import assert_one_rank_per_device
+    def rep(host, dev, uuid="u"):
+        return {"host": host, "gpu": {"device": dev, "uuid": uuid}}
+    assert_one_rank_per_device([rep("a", "cuda:0"), rep("a", "cuda:1")], 8)          # same uuid, different devices: fine
+    assert_one_rank_per_device([rep("a", "cuda:0"), rep("b", "cuda:0")], 8)          # two hosts
+    assert_one_rank_per_device([rep("a", "cuda:0"), rep("a", "cuda:0")], 1)          # a 1-GPU box sharing on purpose
+    with pytest.raises(RuntimeError):
+        assert_one_rank_per_device([rep("a", "cuda:0", "x"), rep("a", "cuda:0", "y")], 8)
