@@ -5,7 +5,10 @@ import torch
 from tests.util import assert_raster_parity, run_blob_case
 
 
-@pytest.mark.parametrize("P,W,H,deg,sm", [(400, 64, 48, 0, 0.15), (400, 50, 37, 3, 0.15), (1500, 96, 64, 2, 0.05)])
+@pytest.mark.parametrize("P,W,H,deg,sm", [
+    (400, 64, 48, 0, 0.15), (400, 50, 37, 3, 0.15), (1500, 96, 64, 2, 0.05),
+    # the forward picks 4 / 2 / 1 tiles per workgroup from the tile count and the CU count (20 under the emulator): 88 and 180 tiles
+    (700, 176, 128, 0, 0.1), (900, 240, 192, 1, 0.1)])
 def test_raster_fwd_bwd_matches_oracle(emu, P, W, H, deg, sm):
     assert_raster_parity(run_blob_case(emu, P, W, H, deg, scale_mean=sm))
 

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
     (400, 64, 48, 0, 0.15), (400, 50, 37, 3, 0.15), (5000, 128, 96, 2, 0.05),
     (50000, 512, 512, 3, 0.02),   # BASELINE config C2 shape
     (20000, 400, 300, 0, 0.2),    # long per-tile lists (exercises multi-batch + global-memory sort fallback)
+    (30000, 640, 480, 1, 0.05),   # 1200 tiles: the forward's two-tiles-per-workgroup instantiation (1024 < T <= 2048 on 256 CUs)
 ])
 def test_raster_fwd_bwd_matches_oracle(gpu, P, W, H, deg, sm):
     assert_raster_parity(run_blob_case(gpu, P, W, H, deg, scale_mean=sm))
