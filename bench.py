@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--emulated-kernels", default=None, metavar="LIBMI355GS_EMU_SO",
                     help="TEST MODE for the CPU tier only (tests/test_dist.py): run the spawn / rendezvous / reduction plumbing with "
                          "the g++-built SIMT emulation of the kernels on CPU tensors over gloo.  Never a measurement; the line says so.")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="create the process group (RCCL on a GPU) and run barrier / all_reduce / all_gather_object even at N = 1: "
+                         "proves the init path and the collectives of the N > 1 line on a 1-GPU box; `multi_gpu` is then filled")
     args = ap.parse_args()
 
     # ---- N > 1 without a launcher: become the launcher (what replaces reference scripts/run_infer.sh:22-27,104-124 — one
@@ -90,16 +93,16 @@ def main():
         dev = torch.device("cuda", local_rank % ndev)
         backend = "gloo" if shared_gpu else "nccl"
     red_dev = dev if backend == "nccl" else torch.device("cpu")
-    from instantsplat_amd.launch import assert_one_rank_per_device, device_identity, gather_rank_reports, pin_rank_to_cpu_slice
+    from instantsplat_amd.launch import (assert_one_rank_per_device, collective_selftest, device_identity, gather_rank_reports,
+                                         init_collectives, local_world_size, pin_rank_to_cpu_slice)
     # N Python hosts on one socket: each rank keeps to its own slice of the CPUs (the scaling risk is host
     # contention, not the fabric)
-    cpus = pin_rank_to_cpu_slice(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else sorted(os.sched_getaffinity(0))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpus = pin_rank_to_cpu_slice(local_rank, local_world_size(world)) if world > 1 else sorted(os.sched_getaffinity(0))
+    collectives = world > 1 or args.force_collectives   # a process group exists: every barrier / reduction below goes through it
+    selftest = None
+    if collectives:
+        init_collectives(backend, rank, world, dev)
+        selftest = collective_selftest(dev)
 
     from instantsplat_amd import _lib
     from instantsplat_amd.arguments import OptimizationParams
@@ -144,12 +147,12 @@ def main():
 
     def sync():
         dev_sync()
-        if world > 1:
+        if collectives:
             dist.barrier()
             dev_sync()
 
     def reduce_max(x):
-        if world > 1:
+        if collectives:
             t = torch.tensor([x], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -263,7 +266,7 @@ def main():
 
     # ---- final metric reduction: the only collective on the path
     red = torch.tensor([psnr_after, 1.0, float(args.steps), elapsed], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if collectives:
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
     mean_psnr = float(red[0] / red[1])
 
@@ -403,7 +406,7 @@ def main():
 
     # ---- N > 1: who ran where, and how the ranks compare (the driver gets one shot at the 8-GPU node: make it informative)
     multi = None
-    if world > 1:
+    if collectives:
         import socket
         mine = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "gpu": device_identity(dev), "cpus": len(cpus),
                 "first_cpu": cpus[0] if cpus else None,
@@ -413,7 +416,7 @@ def main():
             assert_one_rank_per_device(reports, torch.cuda.device_count())
         multi = {"per_rank": reports, "ranks_seen": len(reports), "world_size": dist.get_world_size(), "backend": backend,
                  "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None),
-                 "solo_rank0_iters_per_sec": None, "scaling_efficiency_vs_solo_rank0": None}
+                 "collective_selftest": selftest, "solo_rank0_iters_per_sec": None, "scaling_efficiency_vs_solo_rank0": None}
         t = torch.tensor([solo_its or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         solo = float(t.item())
@@ -427,7 +430,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not emulated else "synthetic — EMULATED KERNELS ON CPU (plumbing test mode, not a measurement)",
-            "collective_backend": (backend if world > 1 else None), "ranks_share_a_gpu": shared_gpu,
+            "collective_backend": (backend if collectives else None), "ranks_share_a_gpu": shared_gpu,
             "config": {"workload": f"BASELINE configs[2]: {V}-view sparse scene, {P} Gaussians, {res}x{res}, joint pose+Gaussian "
                                    f"optimisation (PerPointAdam, lambda_dssim 0.2, SH degree {args.sh_degree}"
                                    f"{' as in the reference first 1000 iterations' if args.sh_degree == 0 else ' (exploratory)'}"
@@ -460,7 +463,7 @@ def main():
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), file=line_out, flush=True)
-    if world > 1:
+    if collectives:
         dist.destroy_process_group()
 
 

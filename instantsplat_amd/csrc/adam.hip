@@ -202,7 +202,9 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
       if (numel[t] < 0 || row[t] <= 0 || step[t] <= 0 || (numel[t] > 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t])))
         return MI355GS_EINVAL;
       if (gate && gate_index[t] >= MT_MAX) return MI355GS_EINVAL;
-      a.numel[t] = numel[t]; a.row[t] = row[t]; a.gidx[t] = gate ? gate_index[t] : -1; a.sq_out[t] = t;
+      // every negative index means "no flag for this tensor: derive its gate from the gradient" (-1 in the header); -2 is this
+      // function's own marker for a tensor gated by the workgroup that owns it and must not be reachable from outside
+      a.numel[t] = numel[t]; a.row[t] = row[t]; a.gidx[t] = (gate && gate_index[t] >= 0) ? gate_index[t] : -1; a.sq_out[t] = t;
       if (a.gidx[t] < 0) any_ungated = true;
       a.param[t] = params[t]; a.grad[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.pplr[t] = per_point_lr[t];
       const double bc1 = 1.0 - pow((double)beta1, (double)step[t]), bc2 = 1.0 - pow((double)beta2, (double)step[t]);

@@ -673,11 +673,17 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
                             uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta, unsigned long long* hitmask,
                             uint32_t max_chunks, uint32_t* qmax) {
   // equal-weight workgroups of 4 (2) tiles while the whole frame is one resident round of at most one (two) workgroups per CU
-  static int cus = 0;
+  // (the count belongs to the device the launch goes to — the process's current one — not to whichever device was current
+  // the first time: a process that drives two different GPUs gets each one's own; a device attribute read is host-only and cheap,
+  // the table just saves it)
+  static int cus_of[64] = {};   // racing writers store the same value
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int cus = cus_of[dev];
   if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus = n;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus_of[dev] = cus = n;
   }
   const int per_wg = GS_FWD_TILES ? GS_FWD_TILES : (T <= 4 * cus ? 4 : (T <= 4 * cus * 2 ? 2 : 1));
 #define GS_FWD(N)                                                                                                                   \

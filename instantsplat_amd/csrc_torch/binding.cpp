@@ -16,6 +16,7 @@
 #include <c10/hip/HIPStream.h>
 
 #include <chrono>
+#include <optional>
 #include <mutex>
 
 #include "../../include/mi355gs.h"
@@ -101,6 +102,10 @@ struct DeviceScope {
 // memory), and fall back to waiting for the stream if it does not show up within a couple of milliseconds.
 void wait_for_count(const int32_t* count, const DeviceScope& dev, const Tensor& t) {
   if (!t.is_cuda()) return;   // emulated kernels run synchronously
+  // the forward is called from Python: other Python threads (a data loader, a progress reporter) run while this one spins or
+  // waits for the stream.  (The autograd engine's threads never get here, and they do not hold the GIL.)
+  std::optional<py::gil_scoped_release> nogil;
+  if (PyGILState_Check()) nogil.emplace();
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spin = 0;; ++spin) {
     if (*reinterpret_cast<const volatile int32_t*>(count) >= 0) return;

@@ -14,6 +14,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
 
 import torch
 import torch.distributed as dist
@@ -27,7 +28,7 @@ def pin_rank_to_cpu_slice(local_rank: int, local_world: int) -> list:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:   # not Linux
         return []
-    if local_world <= 1 or len(cpus) < local_world:
+    if local_world <= 1 or len(cpus) < local_world:   # (0: a multi-node job without LOCAL_WORLD_SIZE — not sliced)
         return cpus
     per = len(cpus) // local_world
     mine = cpus[local_rank * per:(local_rank + 1) * per]
@@ -38,9 +39,63 @@ def pin_rank_to_cpu_slice(local_rank: int, local_world: int) -> list:
     return mine
 
 
+def local_world_size(world: int) -> int:
+    """Ranks on THIS node.  torchrun exports LOCAL_WORLD_SIZE; without it a one-node job has `world` of them, and a job that
+    spans nodes (RANK >= what one node can hold is unknowable here) is not sliced at all: 0 = do not pin."""
+    v = os.environ.get("LOCAL_WORLD_SIZE")
+    if v is not None:
+        return int(v)
+    return world if int(os.environ.get("GROUP_WORLD_SIZE", os.environ.get("NNODES", "1")) or 1) <= 1 else 0
+
+
+def init_collectives(backend: str, rank: int, world: int, dev) -> None:
+    """The one process group of the path (backend "nccl" = RCCL over xGMI on ROCm).  Also valid at world size 1: the
+    communicator is created, and the collectives below run through RCCL on the one device — which is how the init path
+    is proven on a 1-GPU box before the 8-GPU run (`--force-collectives`)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:   # no launcher (single process): any free port will do
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+
+
+def collective_selftest(dev, rounds: int = 50) -> dict:
+    """Every collective the path uses, once, with a known answer — barrier, SUM and MAX all_reduce of a float64 vector,
+    all_gather_object — plus the latency of the 40-byte all_reduce the final metric reduction is (SURVEY.md 8e:
+    latency-bound).  Raises if an answer is wrong; returns what was measured."""
+    import time
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = dist.get_backend()
+    red_dev = torch.device(dev) if backend == "nccl" else torch.device("cpu")
+    sync = (lambda: torch.cuda.synchronize(red_dev)) if red_dev.type == "cuda" else (lambda: None)
+    dist.barrier()
+    s = torch.tensor([float(rank + 1), 1.0, 2.5, 0.0, 0.0], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    mx = torch.tensor([float(rank)], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    got = [None] * world
+    dist.all_gather_object(got, {"rank": rank})
+    assert s.tolist() == [world * (world + 1) / 2.0, float(world), 2.5 * world, 0.0, 0.0], s.tolist()
+    assert mx.item() == float(world - 1) and [g["rank"] for g in got] == list(range(world)), (mx.item(), got)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    sync()
+    us = 1e6 * (time.perf_counter() - t0) / rounds
+    rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+    return {"backend": backend, "world_size": world, "rccl_version": rccl, "all_reduce_40B_us": us,
+            "checked": ["barrier", "all_reduce SUM", "all_reduce MAX", "all_gather_object"]}
+
+
 def gather_rank_reports(report: dict) -> list:
     """all_gather of one small dict per rank (rank 0 prints them); a list of one without a process group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    report.setdefault("host", socket.gethostname())
+    if dist.is_available() and dist.is_initialized():
         out = [None] * dist.get_world_size()
         dist.all_gather_object(out, report)
         return out
@@ -74,7 +129,7 @@ def reduce_scene_metrics(psnr: float, n_images: int, iterations: int, seconds: f
     """SUM-reduce [psnr*n_images, n_images, iterations, 1] and MAX-reduce [seconds] over all ranks."""
     s = torch.tensor([psnr * n_images, float(n_images), float(iterations), 1.0], dtype=torch.float64, device=device)
     mx = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     s, mx = s.cpu(), mx.cpu()
@@ -87,26 +142,30 @@ def main():
     ap.add_argument("--iterations", type=int, default=1000)
     ap.add_argument("--pointmap", type=int, default=256)
     ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="create the RCCL process group and run the collectives even at world size 1 (init-path check on one GPU)")
     args = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cpus = pin_rank_to_cpu_slice(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    reports = gather_rank_reports({"rank": rank, "gpu": device_identity(dev), "cpus": len(cpus)})
+    cpus = pin_rank_to_cpu_slice(local, local_world_size(world))
+    selftest = None
+    if world > 1 or args.force_collectives:
+        init_collectives("nccl", rank, world, dev)
+        selftest = collective_selftest(dev)
+    reports = gather_rank_reports({"rank": rank, "host": socket.gethostname(), "gpu": device_identity(dev), "cpus": len(cpus)})
     assert_one_rank_per_device(reports, torch.cuda.device_count())
     from .synthetic import syn_pointmap
     from .train import training
     scene = syn_pointmap(3, args.pointmap, args.pointmap, args.res, args.res, seed=rank)  # scene i -> rank i
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     r = training(scene, dev, iterations=args.iterations)
     m = reduce_scene_metrics(r["psnr_after"], len(scene.cameras), args.iterations, r["seconds"], dev)
+    m["collectives"] = selftest
     if rank == 0:
         print(json.dumps(m))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

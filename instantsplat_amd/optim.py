@@ -38,6 +38,14 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
 
 
 class PerPointAdam(Optimizer):
+    # Contract of the gate shortcut (compiled binding only): a `.grad` that is exactly the tensor the last render backward
+    # returned — same storage, offset 0, same size, unchanged `_version()` — takes the whole-tensor gate flag that backward left
+    # on the device instead of a pass over the gradient.  `_version()` sees every in-place torch op on the tensor itself; it does
+    # NOT see writes through `.grad.data` / `.detach()` views made before the backward, or raw-pointer kernels.  Code that edits
+    # gradients that way sets `use_backward_gates = False` (class or instance): every step then sums the squared gradients itself,
+    # exactly like the reference's `grad.norm() > 0` (one more ~20 us launch per step).
+    use_backward_gates = True
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         if not all(0.0 <= x for x in [lr, eps, weight_decay]):
             raise ValueError(f"Invalid learning parameters: lr={lr}, eps={eps}, weight_decay={weight_decay}")
@@ -170,6 +178,8 @@ class PerPointAdam(Optimizer):
         for _, _, st, _, _, _ in entries:
             st["step"] += 1
             steps.append(st["step"])
+        if not self.use_backward_gates:
+            fast[0].forget_gates()
         plan.step(grads, lrs, steps)
         return True
 
@@ -218,6 +228,8 @@ class PerPointAdam(Optimizer):
                     plan = b["compiled"] = ext.AdamPlan([p.data for p in b["params"]], [s_["exp_avg"] for s_ in b["states"]],
                                                         [s_["exp_avg_sq"] for s_ in b["states"]], b["keep"], b1, b2, eps)
                     b["compiled_ext"] = ext
+                if not self.use_backward_gates:
+                    ext.forget_gates()
                 plan.step([p.grad for p in b["params"]], [group["lr"] for group in b["groups"]], [s_["step"] for s_ in b["states"]])
                 if len(batches) == 1 and len(live) == sum(len(g["params"]) for g in self.param_groups):
                     # every parameter of the optimizer took part, in one batch: remember the line-up for _step_fast

@@ -101,3 +101,33 @@ def test_rank_device_collision_check():
     assert_one_rank_per_device([rep("a", "cuda:0"), rep("a", "cuda:0")], 1)          # a 1-GPU box sharing on purpose
     with pytest.raises(RuntimeError):
         assert_one_rank_per_device([rep("a", "cuda:0", "x"), rep("a", "cuda:0", "y")], 8)
+
+
+def test_bench_force_collectives_at_world_size_one(emu_lib_path):
+    """`--force-collectives` at N = 1: the process group is created and every collective of the N > 1 line runs through it (gloo
+    here; the GPU tier runs the same command over RCCL, tests/test_rccl_gpu.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collectives", "--steps", "3", "--warmup", "1",
+                        "--pointmap", "6", "--res", "32", "--cpu-iters", "0", "--emulated-kernels", emu_lib_path], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["collective_backend"] == "gloo"
+    m = out["multi_gpu"]
+    assert m["ranks_seen"] == m["world_size"] == 1 and m["per_rank"][0]["host"]
+    assert m["collective_selftest"]["checked"] == ["barrier", "all_reduce SUM", "all_reduce MAX", "all_gather_object"]
+
+
+def test_launch_report_carries_the_host_and_multi_node_is_not_sliced(monkeypatch):
+    """`launch.main()`'s report had no "host", so two nodes' cuda:0 collided in assert_one_rank_per_device; and the CPU
+    slices must come from LOCAL_WORLD_SIZE, not from the global world size, on a multi-node job."""
+    from instantsplat_amd import launch
+    rep = launch.gather_rank_reports({"rank": 0, "gpu": {"device": "cuda:0"}})
+    assert rep[0]["host"] == socket.gethostname()
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setenv("NNODES", "2")
+    assert launch.local_world_size(8) == 0 and launch.pin_rank_to_cpu_slice(0, 0) == sorted(os.sched_getaffinity(0))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert launch.local_world_size(8) == 4

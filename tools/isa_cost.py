@@ -89,7 +89,12 @@ def bwd_model(path):
 
 def main():
     if sys.argv[1] == "--bwd-model":
-        return bwd_model(sys.argv[2])
+        try:   # pattern matching on compiler output: a different LLVM or a variant build may not have these blocks
+            return bwd_model(sys.argv[2])
+        except (StopIteration, ValueError, ZeroDivisionError, IndexError, OSError) as e:
+            sys.stderr.write("isa_cost.py --bwd-model: the replay loop's blocks were not recognised in %s (%s: %s); "
+                             "no table written\n" % (sys.argv[2], type(e).__name__, e))
+            sys.exit(3)
     path, kern = sys.argv[1], sys.argv[2]
     lo = sys.argv[3] if len(sys.argv) > 3 else None
     hi = sys.argv[4] if len(sys.argv) > 4 else None
