@@ -66,6 +66,9 @@ struct MultiAdamArgs {
   // f_rest before the SH degree is raised costs nothing instead of 4 B per element.
   uint32_t* live;
   uint32_t seq;
+  // commit gate (fused trainer only): if *commit_count > commit_capacity the launch writes nothing at all
+  const uint32_t* commit_count;
+  unsigned long long commit_capacity;
 };
 
 __device__ __forceinline__ int mt_find(const MultiAdamArgs& a, int b) {
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256) void k_adam_sumsq(MultiAdamArgs a, float* __re
 
 __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float* __restrict__ sumsq, float beta1, float beta2,
                                                      float eps) {
+  if (a.commit_count && (unsigned long long)*a.commit_count > a.commit_capacity) return;   // wave-uniform (one scalar load)
   const int t = mt_find(a, blockIdx.x);
   const long long lo = (long long)(blockIdx.x - a.first_block[t]) * MT_CHUNK;
   const long long hi = min(a.numel[t], lo + MT_CHUNK);
@@ -217,9 +221,12 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
     }
   }
   a.first_block[MT_MAX] = blocks;
-  a.live = nullptr; a.seq = 0;
+  a.live = nullptr; a.seq = 0; a.commit_count = nullptr; a.commit_capacity = 0;
   if (blocks == 0) return MI355GS_OK;
-  if (!gate && g_fused.gate == scratch) { a.live = g_fused.adam_live; a.seq = g_fused.adam_seq; }
+  if (!gate && g_fused.gate == scratch) {
+    a.live = g_fused.adam_live; a.seq = g_fused.adam_seq;
+    a.commit_count = g_fused.commit_count; a.commit_capacity = g_fused.commit_capacity;
+  }
   if (gate && any_ungated) {
     // small leftovers (the pose table: 7 V floats) are gated inside the update kernel, by the one workgroup that owns them
     for (int t = 0; t < ntensors; ++t) {

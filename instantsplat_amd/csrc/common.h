@@ -304,6 +304,11 @@ struct GsFusedStepHooks {
   bool gate_tail = false;  // the flags live right behind the GsGrad records (mi355gs_raster_grad_gate_offset) and are cleared with them
   uint32_t* adam_live = nullptr;  // device uint32[16] persisting across steps (see k_adam_multi) or null
   uint32_t adam_seq = 0;          // launch sequence number (never 0) for adam_live
+  // Commit gate of the one-call step (trainer.hip): the frame's true instance count (device word written by the tile scan)
+  // and the capacity of the instance buffers.  An Adam launch that finds count > capacity writes NOTHING — the frame dropped
+  // instances, its gradients are not the iteration's — so the step can be enqueued whole, before the host has seen the count.
+  const uint32_t* commit_count = nullptr;
+  unsigned long long commit_capacity = 0;
   int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_sh_rest = -1, gate_pose = -1;
 };
 extern thread_local GsFusedStepHooks g_fused;

@@ -73,7 +73,10 @@ size_t carve(Trainer& t, void* workspace) {
   return c.off;
 }
 
-int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t* step, float beta1, float beta2, float eps) {
+// commit_gate: the launch is part of the step that produced the gradients and has not been cleared by the host — it must
+// turn itself into a no-op when that frame's instance count exceeded the buffers (see GsFusedStepHooks::commit_count)
+int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
+                 bool commit_gate) {
   const int P = t->P;
   const int64_t numel[7] = {3LL * P, 3LL * P, 45LL * P, (int64_t)P, 3LL * P, 4LL * P, 7LL * t->V};
   const int32_t row[7] = {3, 1, 1, 1, 1, 1, 1};
@@ -82,6 +85,11 @@ int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t*
   const float* pplr[7] = {t->pplr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (++t->adam_seq == 0u) t->adam_seq = 1u;
   g_fused.adam_live = t->adam_live; g_fused.adam_seq = t->adam_seq;
+  if (commit_gate) {
+    const TilesLayout tl(t->W, t->H);
+    g_fused.commit_count = (const uint32_t*)(t->tiles + tl.start) + tl.T;   // tile_start[T]: the frame's instance count
+    g_fused.commit_capacity = (unsigned long long)t->capacity;
+  }
   return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch, nullptr, nullptr);
 }
 
@@ -242,7 +250,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
                                  (const float*)t->ssim_scratch, gs_loss_fused_nblocks(3, H, W), 1.0 / (3.0 * H * W), lambda_dssim, loss_out);
   GS_CHECK_LAUNCH("pose_finish");
   // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
-  if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps);
+  if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps, true);
   return MI355GS_OK;
 }
 
@@ -252,7 +260,7 @@ int mi355gs_trainer_optimizer_step(void* handle, void* stream_, const float* lr,
   if (!t || !lr || !step || !t->consts_ready) return MI355GS_EINVAL;  // needs the gradients of a preceding step
   // gate flags of the gradients produced by the preceding mi355gs_trainer_step(..., do_optimizer_step = 0) are still in place
   g_fused.gate = t->adam_scratch;
-  const int rc = trainer_adam(t, (hipStream_t)stream_, lr, step, beta1, beta2, eps);
+  const int rc = trainer_adam(t, (hipStream_t)stream_, lr, step, beta1, beta2, eps, false);   // the caller has seen the count
   g_fused = GsFusedStepHooks();
   return rc;
 }

@@ -52,6 +52,16 @@ class PerPointAdam(Optimizer):
         if not all(0.0 <= beta < 1.0 for beta in betas):
             raise ValueError(f"Invalid beta parameters: {betas}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, per_point_lr=None))
+        # The kernels update parameters in place through raw pointers, row-major.  The reference's GaussianModel hands over a
+        # COLUMN-major `_xyz` whenever the points come from a PLY file (`np.vstack([x, y, z]).T` through `torch.tensor`,
+        # scene/dataset_readers.py:217 -> scene/gaussian_model.py:148, keeps the strides): re-lay such a parameter out once, here —
+        # same Parameter object, same values, and everything else that touches it (elementwise torch code, the operators'
+        # own `.contiguous()`) is layout-agnostic.
+        with torch.no_grad():
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if not p.is_contiguous():
+                        p.data = p.data.contiguous()
 
     def zero_grad(self, set_to_none: bool = True):
         """Same contract as torch.optim.Optimizer.zero_grad (the reference calls it with set_to_none=True, train.py:211),

@@ -117,14 +117,17 @@ class GaussianModel:
         return self.P[idx]
 
     # ---- initialisation from a point cloud (reference :146-172)
-    def create_from_pcd(self, points: torch.Tensor, colors: torch.Tensor, spatial_lr_scale: float, device):
+    def create_from_pcd(self, points: torch.Tensor, colors: torch.Tensor, spatial_lr_scale: float, device, scale_gaussian=None):
+        """scale_gaussian: optional per-point cap on the initial scale (reference :157-159, `--init_scale_from_view_depth`)."""
         self.spatial_lr_scale = spatial_lr_scale
-        pts = points.float().to(device)
-        fused_color = RGB2SH(colors.float().to(device))
+        pts = torch.as_tensor(points).float().to(device).contiguous()   # (a [3,N] array's transpose arrives with its strides)
+        fused_color = RGB2SH(torch.as_tensor(colors).float().to(device))
         n = pts.shape[0]
         features = torch.zeros((n, 3, (self.max_sh_degree + 1) ** 2), dtype=torch.float32, device=device)
         features[:, :3, 0] = fused_color
         dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        if scale_gaussian is not None:
+            dist2 = torch.min(torch.as_tensor(scale_gaussian ** 2).float().to(device), dist2)
         scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
         rots = torch.zeros((n, 4), device=device)
         rots[:, 0] = 1

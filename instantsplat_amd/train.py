@@ -53,10 +53,38 @@ class TrainState:
     _loss_slot: Optional[torch.Tensor] = None
 
 
-def setup_training(scene: PointmapScene, device, opt: OptimizationParams | None = None, pipe: PipelineParams | None = None,
+def setup_training_from_init(scene, device, opt: OptimizationParams | None = None, pipe: PipelineParams | None = None,
+                             model: ModelParams | None = None) -> TrainState:
+    """The state reference train.py:90-118 builds from an init directory (`scene_io.load_init_scene`): Gaussians from the point
+    cloud with the camera-based extent (scene/__init__.py:94-100), poses from the COLMAP extrinsics, the per-point or the plain
+    optimizer, the loaded images as ground truth — no teacher, nothing synthetic."""
+    opt = opt or OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)
+    pipe = pipe or PipelineParams()
+    model = model or ModelParams()
+    dev = torch.device(device)
+    bg = torch.tensor([1.0, 1.0, 1.0] if model.white_background else [0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+    g = GaussianModel(model.sh_degree)
+    g.create_from_pcd(scene.points, scene.colors, scene.cameras_extent, dev, scale_gaussian=scene.scale_gaussian)
+    cams = [c.to(dev) for c in scene.cameras]
+    g.init_RT_seq(cams, dev)
+    if opt.pp_optimizer:
+        if scene.confidence_lr is None:   # train.py:95 np.load()s the file unconditionally; the per-point optimizer cannot do without
+            raise FileNotFoundError("pp_optimizer needs sparse_<n>/0/confidence_dsp.npy")
+        g.training_setup_pp(opt, scene.confidence_lr.to(dev))
+    else:
+        g.training_setup(opt)
+    st = TrainState(g, cams, [c.original_image.to(dev).contiguous() for c in cams], bg, opt, pipe)
+    st.rng = scene.rng   # the view sampling continues on the stream the camera shuffle drew from (one `random` module in the reference)
+    return st
+
+
+def setup_training(scene, device, opt: OptimizationParams | None = None, pipe: PipelineParams | None = None,
                    model: ModelParams | None = None) -> TrainState:
-    """Teacher = create_from_pcd(scene points) at the true poses -> ground-truth images.
+    """An init directory's scene (`scene_io.InitScene`): see setup_training_from_init.  A synthetic PointmapScene:
+    Teacher = create_from_pcd(scene points) at the true poses -> ground-truth images.
     Student = teacher with perturbed positions / colours / poses (what MASt3R noise would look like)."""
+    if not isinstance(scene, PointmapScene):
+        return setup_training_from_init(scene, device, opt, pipe, model)
     opt = opt or OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)
     pipe = pipe or PipelineParams()
     model = model or ModelParams()
@@ -133,9 +161,12 @@ def _optimizer_step(st: TrainState):
 
 
 def _fused_synced_iteration(st: TrainState):
-    """The reference's loop shape — loss read back on the host every iteration — on the one-call fused step: forward +
-    backward are enqueued, loss and instance count come back in ONE read-back, and only then is the optimizer update
-    committed; an iteration whose instance count exceeded the buffers is redone on the exact-sizing autograd path."""
+    """The reference's loop shape — loss read back on the host every iteration — on the one-call fused step: the WHOLE
+    iteration is enqueued (forward, backward, optimizer), loss and instance count come back in ONE read-back.  The optimizer
+    launch carries a device-side commit gate (it writes nothing when the frame's instance count exceeded the buffers,
+    csrc/trainer.hip), so the host does not have to see the count before the update is enqueued — the GPU never idles waiting
+    for the host between backward and Adam — and an iteration that did overflow is simply redone on the exact-sizing
+    autograd path: parameters and moments are still the ones it started from."""
     tr = getattr(st, "_trainer", None)
     if tr is None:
         with torch.no_grad():
@@ -151,12 +182,12 @@ def _fused_synced_iteration(st: TrainState):
         st._loss_slot = st._host_words[0:1].view(torch.float32)
     saved = (st.iteration, list(st.viewpoint_stack), st.rng.getstate(), st.gaussians.active_sh_degree,
              [st.gaussians.optimizer.state[p]["step"] for p in tr.params], [g["lr"] for g in st.gaussians.optimizer.param_groups])
-    cam = tr.step(st._loss_slot, defer_optimizer=True, verify_async=False, count_out=st._host_words[1:2])
+    cam = tr.step(st._loss_slot, defer_optimizer=False, verify_async=False, count_out=st._host_words[1:2])
     if tr.dev.type == "cuda":
         torch.cuda.current_stream(tr.dev).synchronize()
     loss, r = float(st._loss_slot[0]), int(st._host_words[1])
     BinningPolicy.known[("train", cam.uid)] = int(r)
-    if r > tr.capacity:   # dropped instances: discard, redo exactly, and grow the buffers for the next iterations
+    if r > tr.capacity:   # dropped instances (the device left the update out): redo exactly, and grow the buffers for the next iterations
         st.iteration, st.viewpoint_stack, st.gaussians.active_sh_degree = saved[0], saved[1], saved[3]
         st.rng.setstate(saved[2])
         for p, s0 in zip(tr.params, saved[4]):
@@ -166,7 +197,6 @@ def _fused_synced_iteration(st: TrainState):
         tr.close()
         st._trainer = None
         return None
-    tr.apply_optimizer()
     if r * 1.2 + 1024 > tr.capacity:
         tr.close()
         st._trainer = None
@@ -472,11 +502,17 @@ def _save_outputs(st: TrainState, iteration: int, model_path: str, colmap_ids):
     save_pose(os.path.join(model_path, "pose", f"ours_{iteration}", "pose_optimized.npy"), st.gaussians.P, colmap_ids)
 
 
-def training(scene: PointmapScene, device, iterations: int = 1000, log_every: int = 0, run_ahead: bool = True,
+def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahead: bool = True,
              fused_loss: bool = True, model_path: str | None = None, saving_iterations=(), checkpoint_iterations=(),
-             start_checkpoint: str | None = None) -> dict:
+             start_checkpoint: str | None = None, opt: OptimizationParams | None = None, n_views: int | None = None,
+             model: ModelParams | None = None, after_setup=None, resolution=1) -> dict:
     """Train one scene. run_ahead=True uses the sync-free driver (identical results, see RunAhead);
     run_ahead=False reproduces the reference's per-iteration host read-backs.
+
+    scene: a synthetic PointmapScene, a `scene_io.InitScene`, or the path of an init directory (`-s <source_path>` with
+    `n_views` and `-r <resolution>`; loaded with `scene_io.load_init_scene`, which also leaves input.ply and cameras.json in
+    `model_path` like the reference's Scene).  opt: the optimisation parameters (default: the scripts' `--pp_optimizer --optim_pose`); its
+    `iterations` is overridden by the argument.  after_setup(state): hook between set-up and the first iteration (tests).
 
     model_path / saving_iterations / checkpoint_iterations / start_checkpoint: the reference's outputs and resume
     (train.py:103-110,220-227): pose/ours_<it>/pose_org.npy before training, point_cloud.ply + pose_optimized.npy at every saving
@@ -484,8 +520,21 @@ def training(scene: PointmapScene, device, iterations: int = 1000, log_every: in
     such a file continues at its iteration with its optimizer state."""
     import os
     from .io_formats import save_pose
-    opt = OptimizationParams(iterations=iterations, pp_optimizer=True, optim_pose=True)
-    st = setup_training(scene, device, opt=opt)
+    import dataclasses
+    opt = dataclasses.replace(opt, iterations=iterations) if opt is not None else OptimizationParams(iterations=iterations, pp_optimizer=True, optim_pose=True)
+    if isinstance(scene, (str, os.PathLike)):
+        from .scene_io import load_init_scene
+        if n_views is None:
+            raise ValueError("training(<source_path>) needs n_views (the sparse_<n_views> directory to read)")
+        scene = load_init_scene(os.fspath(scene), n_views, resolution=resolution, device=device, model_path=model_path)
+    if model_path:   # reference train.py:233-246 (prepare_output_and_logger): the run's arguments next to its outputs
+        os.makedirs(model_path, exist_ok=True)
+        with open(os.path.join(model_path, "cfg_args"), "w") as f:
+            f.write(repr(dict(dataclasses.asdict(opt), model_path=model_path, source_path=getattr(scene, "source_path", None),
+                              n_views=getattr(scene, "n_views", n_views), sh_degree=(model or ModelParams()).sh_degree)))
+    st = setup_training(scene, device, opt=opt, model=model)
+    if after_setup is not None:
+        after_setup(st)
     first_iter = 0
     if start_checkpoint:
         model_params, first_iter = torch.load(start_checkpoint, map_location=device, weights_only=False)

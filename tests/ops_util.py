@@ -558,6 +558,56 @@ def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=Fa
         BinningPolicy.reset("exact")
 
 
+def check_commit_gate_leaves_an_overflowed_step_uncommitted(dev, Wm=12, W=32):
+    """mi355gs_trainer_step(do_optimizer_step = 1) enqueues the optimizer before the host has seen the frame's instance count:
+    the Adam launch itself must write NOTHING — parameters, both moments — when the count exceeded the capacity of the instance
+    buffers (device-side commit gate, csrc/trainer.hip), and must update everything when it did not."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.gaussian_renderer import render
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import FusedTrainer, binning_hint, setup_training
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=19)
+    st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+    g = st.gaussians
+    try:
+        BinningPolicy.reset("exact")
+        with torch.no_grad():
+            for cam in st.cameras:
+                with binning_hint(("train", cam.uid)):
+                    render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+        need = min(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
+        words = torch.zeros(2, dtype=torch.int32, pin_memory=(torch.device(dev).type == "cuda"))
+        loss_slot = words[0:1].view(torch.float32)
+        sync = (lambda: torch.cuda.synchronize(dev)) if torch.device(dev).type == "cuda" else (lambda: None)
+
+        def state():
+            out = [getattr(g, n).detach().clone() for n in TRAIN_TENSORS]
+            for n in TRAIN_TENSORS:
+                s_ = g.optimizer.state[getattr(g, n)]
+                out += [s_["exp_avg"].clone(), s_["exp_avg_sq"].clone()]
+            return out
+        big = FusedTrainer(st, 4 * max(BinningPolicy.known[("train", c.uid)] for c in st.cameras) + 1024)
+        before = state()
+        big.step(loss_slot, verify_async=False, count_out=words[1:2])     # fits: commits (moments become non-zero)
+        sync()
+        assert int(words[1]) <= big.capacity
+        after = state()
+        for n, a, b in zip(TRAIN_TENSORS, before, after):   # (f_rest has no gradient at SH degree 0: its step is p - s * 0)
+            assert torch.equal(a, b) == (n == "_features_rest"), n
+        big.close()
+        small = FusedTrainer(st, max(need // 2, 1))
+        for _ in range(3):                                                # every view overflows this capacity
+            small.step(loss_slot, verify_async=False, count_out=words[1:2])
+            sync()
+            assert int(words[1]) > small.capacity
+        for a, b in zip(after, state()):
+            assert torch.equal(a, b)                                      # bit for bit: nothing was written
+        small.close()
+    finally:
+        BinningPolicy.reset("exact")
+
+
 TRAIN_TENSORS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
 
 

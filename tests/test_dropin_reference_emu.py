@@ -225,3 +225,96 @@ def test_reference_pose_tracking_runs_on_our_operators(emu, monkeypatch, referen
     assert float((torch.stack(track["poses"]) - T("track_pose_sequence")).abs().max()) <= 2e-5
     assert np.allclose(track["losses"], G["track_losses"], rtol=2e-4, atol=0)
     assert float((track["saved"][0] - T("track_final_render")).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize("fused_glue", [False, True])
+def test_reference_training_from_an_init_directory_on_our_operators(emu, monkeypatch, reference_modules_cleanup, fused_glue):
+    """the committed init directory (tests/golden/init_scene, written by the reference's own writers) trains
+    under the reference's UNMODIFIED `training()` — its real `Scene` (dataset readers, getNerfppNorm, loadCam, shuffle),
+    `prepare_output_and_logger`, `save_pose`, `scene.save()` — with the three operator packages aliased to ours, and lands on the
+    trajectory the same code produced around the C oracle operator (tests/golden/initdir_vectors.npz)."""
+    import random as _random
+    from argparse import Namespace
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    try:
+        import ref_loader
+    finally:
+        sys.path.pop(0)
+    import instantsplat_amd.diff_gaussian_rasterization as dgr
+    import instantsplat_amd.fused_ssim as fs
+    import instantsplat_amd.simple_knn._C as skc
+    G = np.load(os.path.join(ROOT, "tests", "golden", "initdir_vectors.npz"))
+    V, _, _, _, iters = [int(x) for x in G["initdir_config"]]
+    scene_dir = os.path.join(ROOT, "tests", "golden", "init_scene")
+    monkeypatch.syspath_prepend(REF)
+    _zeros = torch.zeros
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: _zeros(*a, **{kk: ("cpu" if (kk == "device" and vv == "cuda") else vv)
+                                                                    for kk, vv in k.items()}))
+    R = ref_loader.load(monkeypatch.setitem, monkeypatch.delitem, dgr, skc, fs)
+    assert R.gr.GaussianRasterizer is dgr.GaussianRasterizer and R.gm.distCUDA2 is skc.distCUDA2   # ours, through the aliases
+    if fused_glue:
+        import instantsplat_amd.gaussian_renderer as our_gr
+        import instantsplat_amd.optim as our_optim
+        R.gm.PerPointAdam = our_optim.PerPointAdam
+        R.gr.render = our_gr.render
+    track = {"models": [], "loss": [], "uids": []}
+
+    class TrackedModel(R.gm.GaussianModel):
+        def __init__(self, sh_degree):
+            super().__init__(sh_degree)
+            track["models"].append(self)
+
+    class SceneFromDisk(R.Scene):   # the reference's Scene + the recorded run's generic start (make_golden_initdir.py)
+        def __init__(self, args, gaussians, *a, **k):
+            super().__init__(args, gaussians, *a, **k)
+            with torch.no_grad():
+                gaussians._scaling.add_(torch.from_numpy(G["initdir_init_scaling_delta"]))
+                gaussians._rotation.copy_(torch.from_numpy(G["initdir_init_rotation"]))
+
+    class Quiet:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            return lambda *a, **k: 0.0
+
+    def fused_ssim_tracked(a, b):
+        v = fs.fused_ssim(a, b)
+        l1 = R.loss_utils.l1_loss(a[0], b[0])
+        track["loss"].append(float(((1.0 - 0.2) * l1 + 0.2 * (1.0 - v)).detach()))
+        return v
+
+    def render_tracked(cam, *a, **k):
+        track["uids"].append(cam.uid)
+        return R.gr.render(cam, *a, **k)
+
+    ns = {"os": os, "np": np, "torch": torch, "Namespace": Namespace, "TENSORBOARD_FOUND": False, "GaussianModel": TrackedModel,
+          "Scene": SceneFromDisk, "tqdm": Quiet, "time": __import__("time").time, "randint": _random.randint, "render": render_tracked,
+          "l1_loss": R.loss_utils.l1_loss, "ssim": R.loss_utils.ssim, "FUSED_SSIM_AVAILABLE": True, "fused_ssim": fused_ssim_tracked,
+          "save_time": lambda *a, **k: None, "training_report": lambda *a, **k: None, "Quiet": Quiet,
+          "get_camera_from_tensor": R.pose_utils.get_camera_from_tensor}
+    for name in ("load_and_prepare_confidence", "save_pose", "prepare_output_and_logger", "training"):
+        code = _CPU(R.train_functions[name]).replace("torch.cuda.Event(enable_timing = True)", "Quiet()")
+        exec(compile(code, os.path.join(REF, "train.py"), "exec"), ns)
+    opt = R.OptimizationParams(ArgumentParser())
+    opt.iterations, opt.pp_optimizer, opt.optim_pose = iters, True, True
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+    with tempfile.TemporaryDirectory() as td:
+        dataset = types.SimpleNamespace(source_path=scene_dir, model_path=os.path.join(td, "model"), n_views=V, images=None, eval=False,
+                                        white_background=False, resolution=2, data_device="cpu", init_scale_from_view_depth=False, sh_degree=3)
+        _random.seed(0)
+        ns["training"](dataset, opt, pipe, [], [iters], [], None, -1)
+        model = track["models"][-1]
+        assert track["uids"] == list(G["initdir_loop_view_uids"])
+        assert np.allclose(track["loss"], G["initdir_loop_losses"], rtol=1e-3, atol=0), (track["loss"], G["initdir_loop_losses"])
+        for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):
+            a, b = getattr(model, n).detach(), torch.from_numpy(G["initdir_loop_final" + (n if n.startswith("_") else "_" + n)])
+            rel = float((a - b).norm() / (b.norm() + 1e-30))
+            assert rel <= 2e-5, (n, rel)
+        assert np.allclose(np.load(os.path.join(dataset.model_path, "pose", f"ours_{iters}", "pose_optimized.npy")),
+                           G["initdir_loop_pose_optimized"], rtol=0, atol=2e-6)
+        # the reference's scene.save() wrote its PLY through the stand-in `plyfile`; OUR reader must take it (format, not shared code)
+        from instantsplat_amd.io_formats import load_gaussian_ply
+        back = load_gaussian_ply(os.path.join(dataset.model_path, "point_cloud", f"iteration_{iters}", "point_cloud.ply"))
+        for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            assert torch.equal(back[n], getattr(model, n).detach()), n

@@ -72,6 +72,10 @@ def test_fused_synced_loop_equals_autograd_loop(emu, overflow):
     ops_util.check_fused_synced_loop_equals_autograd_loop(emu, force_overflow=overflow)
 
 
+def test_commit_gate_leaves_an_overflowed_step_uncommitted(emu):
+    ops_util.check_commit_gate_leaves_an_overflowed_step_uncommitted(emu)
+
+
 def test_adam_matches_reference_trajectory(emu):
     ops_util.check_adam_golden(emu)
 

@@ -1,0 +1,109 @@
+"""GPU tier: VERDICT r3 #1(b) — a scene written to the reference's on-disk init layout (cameras.txt, images.txt, points3D.ply,
+confidence_dsp.npy, images/*.png), loaded back, trained from the directory on the MI355X, exported (point_cloud.ply,
+pose_optimized.npy) and reloaded.  The run from disk must land where the same data trains to when it never touched a file."""
+import copy
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ITERS = 200
+
+
+def _export(tmp, dev):
+    """A 3-view pointmap scene as an InstantSplat init would leave it: noisy points / colours / poses, teacher images."""
+    from instantsplat_amd import scene_io
+    from instantsplat_amd.pose_utils import get_camera_from_tensor
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training
+    sc = syn_pointmap(3, 64, 64, 256, 256, seed=5)
+    st = setup_training(sc, dev)                                   # teacher images + the student's noisy start
+    g = st.gaussians
+    w2c = [get_camera_from_tensor(p).double().cpu().numpy() for p in g.P.detach()]
+    data = dict(w2c=w2c, fovs=[(c.FoVx, c.FoVy) for c in sc.cameras], images=[x.detach().cpu() for x in st.gt_images],
+                points=g._xyz.detach().cpu(), colors=(g._features_dc.detach().cpu()[:, 0, :] * 0.28209479177387814 + 0.5).clamp(0, 1),
+                confidence=sc.confidence)
+    scene_io.write_init_scene(str(tmp), data["w2c"], data["fovs"], data["images"], data["points"], data["colors"], data["confidence"])
+    return data
+
+
+def _in_memory_scene(data, dev):
+    """The same scene as an InitScene that never went through a file: 8-bit images and colours (what PNG / PLY hold), float poses."""
+    from instantsplat_amd import scene_io
+    from instantsplat_amd.camera import Camera
+    from instantsplat_amd.scene import confidence_to_lr_modifiers
+    q8 = lambda t: (t.clamp(0, 1) * 255.0).round() / 255.0
+    infos = []
+    for v, m in enumerate(data["w2c"]):
+        infos.append(scene_io.CameraInfo(uid=v + 1, R=m[:3, :3].T.copy(), T=m[:3, 3].copy(), FovY=data["fovs"][v][1], FovX=data["fovs"][v][0],
+                                         image=None, image_path="", image_name=f"{v:04d}", width=256, height=256))
+    rng = random.Random(0)
+    order = list(range(len(infos)))
+    rng.shuffle(order)                                              # the loader's seeded shuffle, same stream
+    cams = []
+    for uid, v in enumerate(order):
+        c = Camera(uid, torch.from_numpy(scene_io.get_world2view2(infos[v].R, infos[v].T)), infos[v].FovX, infos[v].FovY, 256, 256,
+                   image=q8(data["images"][v]).float(), device=dev, colmap_id=v + 1, image_name=infos[v].image_name)
+        cams.append(c)
+    return scene_io.InitScene(source_path="", n_views=3, cameras=cams, test_cameras=[], cameras_extent=float(scene_io.get_nerfpp_norm(infos)["radius"]),
+                              points=data["points"].clone(), colors=q8(data["colors"]).float(),
+                              confidence_lr=confidence_to_lr_modifiers(data["confidence"].to(dev)), rng=rng)
+
+
+def test_scene_trains_from_the_init_directory_and_exports(gpu, tmp_path):
+    from instantsplat_amd import io_formats as iof
+    from instantsplat_amd import scene_io
+    from instantsplat_amd.gaussian_renderer import render
+    from instantsplat_amd.pose_utils import get_tensor_from_camera
+    from instantsplat_amd.scene import GaussianModel
+    from instantsplat_amd.train import psnr, training
+    src, out = tmp_path / "scene", tmp_path / "model"
+    data = _export(src, gpu)
+    assert sorted(os.listdir(src / "sparse_3" / "0")) == ["cameras.txt", "confidence_dsp.npy", "images.txt", "points3D.ply"]
+    # ---- 50 iterations, where a training run still reproduces itself: from disk vs the same data without files, within 0.1 dB
+    # (measured on MI355X, profiles/r04_rerun_psnr_spread_200_iterations.txt: four in-memory runs 44.312 .. 44.323 dB, three runs
+    # from disk 44.332 .. 44.351 — the order of float atomics differs from run to run, and Adam amplifies it as training goes on)
+    a50 = training(str(src), gpu, iterations=50, n_views=3)
+    b50 = training(_in_memory_scene(data, gpu), gpu, iterations=50)
+    print("50 iterations: PSNR from disk %.3f -> %.3f dB, in memory %.3f -> %.3f dB" % (a50["psnr_before"], a50["psnr_after"], b50["psnr_before"], b50["psnr_after"]))
+    assert abs(a50["psnr_before"] - b50["psnr_before"]) <= 0.02 and abs(a50["psnr_after"] - b50["psnr_after"]) <= 0.1
+    # ---- 200 iterations from disk, with the reference's outputs ...
+    a = training(str(src), gpu, iterations=ITERS, n_views=3, model_path=str(out), saving_iterations=[ITERS])
+    # ---- ... against the same data without files.  By now two runs of the SAME in-memory scene are 0.6 dB apart (48.27 .. 48.90
+    # over four runs, same file): the comparison is bounded by that spread, which the test measures itself
+    b, b2 = (training(_in_memory_scene(data, gpu), gpu, iterations=ITERS) for _ in range(2))
+    spread = abs(b["psnr_after"] - b2["psnr_after"])
+    print("200 iterations: PSNR from disk %.3f -> %.3f dB, in memory %.3f -> %.3f / %.3f dB" % (a["psnr_before"], a["psnr_after"], b["psnr_before"],
+                                                                                               b["psnr_after"], b2["psnr_after"]))
+    assert abs(a["psnr_before"] - b["psnr_before"]) <= 0.02 and a["psnr_after"] > a["psnr_before"] + 3.0
+    assert abs(a["psnr_after"] - 0.5 * (b["psnr_after"] + b2["psnr_after"])) <= max(1.0, 2.0 * spread), (a["psnr_after"], b["psnr_after"], b2["psnr_after"])
+    sa, sb = a["state"], b["state"]
+    assert [c.colmap_id for c in sa.cameras] == [c.colmap_id for c in sb.cameras]
+    assert sa.gaussians.spatial_lr_scale == pytest.approx(sb.gaussians.spatial_lr_scale, rel=1e-6)
+    # ---- what training wrote, reloaded
+    for f in ("cfg_args", "input.ply", "cameras.json", f"point_cloud/iteration_{ITERS}/point_cloud.ply", f"pose/ours_{ITERS}/pose_org.npy",
+              f"pose/ours_{ITERS}/pose_optimized.npy"):
+        assert (out / f).exists(), f
+    g2 = GaussianModel(3)
+    g2.load_ply(str(out / "point_cloud" / f"iteration_{ITERS}" / "point_cloud.ply"), device=gpu)
+    g2.active_sh_degree = sa.gaussians.active_sh_degree
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(g2, n).detach(), getattr(sa.gaussians, n).detach()), n
+    poses = np.load(out / "pose" / f"ours_{ITERS}" / "pose_optimized.npy")            # [V,4,4] by COLMAP id
+    vals_exact, vals_file = [], []
+    with torch.no_grad():
+        for cam in sa.cameras:
+            gt = sa.gt_images[cam.uid]
+            p_file = get_tensor_from_camera(torch.from_numpy(poses[cam.colmap_id - 1])).to(gpu)
+            assert torch.allclose(get_tensor_from_camera(torch.from_numpy(poses[cam.colmap_id - 1]))[4:], sa.gaussians.P[cam.uid, 4:].cpu(), atol=1e-5)
+            for p, acc in ((sa.gaussians.get_RT(cam.uid), vals_exact), (p_file, vals_file)):
+                img = render(cam, g2, sa.pipe, sa.background, camera_pose=p)["render"].clamp(0, 1)
+                acc.append(float(psnr(img, gt).mean()))
+    print("PSNR of the reloaded model: with the in-memory poses %.3f dB, with pose_optimized.npy %.3f dB" % (np.mean(vals_exact), np.mean(vals_file)))
+    assert abs(np.mean(vals_exact) - a["psnr_after"]) <= 0.01
+    # pose_optimized.npy stores rotation MATRICES: the unit quaternion comes back, the trained pose's |q| (which scales the
+    # covariances) does not — same loss of information as in the reference's render.py
+    assert abs(np.mean(vals_file) - a["psnr_after"]) <= 1.0
