@@ -5,11 +5,16 @@ A step = ONE full training iteration of reference train.py:140-211 on the HIP pa
 LR schedule, random view, render (pose transform + rasterizer forward), fused L1+SSIM loss, backward
 (SSIM bwd, rasterizer bwd, autograd glue), loss.item(), PerPointAdam step over all 7 parameter groups.
 
-`value` is the loop the metric describes: every iteration ends with the reference's blocking read-back of the loss
-(train.py:188) — here on the one-call step (instantsplat_amd.train.train_iteration(fused_step=True)).  Next to it, measured
-in the same run: the same step driven without that read-back (RunAhead: identical results, the loss EMA is evaluated every
-10 iterations) and the reference-shaped loop on the drop-in operators (autograd, both of the reference's read-backs).
-The timed region is repeated in blocks of --steps iterations until it covers >= 0.25 s; `value` is the median block.
+`value` is the loop `north_star` names: the reference's train.py loop shape on the drop-in operators — `render()` /
+`GaussianRasterizer` / `fused_ssim` / `PerPointAdam` through the compiled binding, autograd, and BOTH of the reference's blocking
+host read-backs per iteration (the operator's instance count, `loss.item()` at train.py:188).  Measured next to it under the same
+protocol and reported as siblings (`loops`): the same iteration behind one library call with the loss read back every iteration
+(`one_call_synced`) and without that read-back (`one_call_run_ahead`: identical results, the loss EMA is evaluated every 10).
+
+Timed region: each loop runs on a fresh state fast-forwarded (untimed) to iteration 200 of training, W warm-up iterations, then
+blocks of exactly --steps iterations, each bracketed by barrier + device synchronize, MAX over ranks; the blocks cover iterations
+200 .. 1000 whatever --steps is (40 blocks at the driver's --steps 20), `value` / `ms_per_step` are the MEDIAN block.  Nothing is
+instrumented inside it: kernel durations for `roofline` come from HIP events in a separate, untimed pass over the same stretch.
 
 Workload (BASELINE.json configs[2], "C3"): 3-view sparse scene, 196,608 Gaussians (one per pixel of three
 256x256 pointmaps), 512x512 images, joint pose + Gaussian optimisation with the per-point optimiser.
@@ -28,8 +33,6 @@ import time
 
 import torch
 import torch.distributed as dist
-
-PROF_EVERY = 8   # HIP events around every 8th launch of the timed kernels (see the timed region)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -110,36 +113,52 @@ def main():
     from instantsplat_amd.gaussian_renderer import render
     from instantsplat_amd.synthetic import syn_pointmap
     from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
-    from instantsplat_amd.train import RunAhead, evaluate_psnr, setup_training, train_iteration
+    from instantsplat_amd.train import RunAhead, evaluate_psnr, release_trainer, setup_training, train_iteration
 
     L = _lib.lib()
     V, Wm, res = 3, args.pointmap, args.res
     scene = syn_pointmap(V, Wm, Wm, res, res, seed=rank)
     # (the reference skips the optimiser on an run's LAST iteration, train.py:209: no timed iteration may be that one)
     opt = OptimizationParams(iterations=10 ** 9, pp_optimizer=True, optim_pose=True)
-    st = setup_training(scene, dev, opt=opt)
-    P = st.gaussians.get_xyz.shape[0]
-    st.gaussians.active_sh_degree = args.sh_degree
-    # The line is quoted on the regime of the reference's first 1000 iterations (SH degree 0, train.py:149-150 raises it every
-    # 1000).  Warm-up + repeated blocks + the sibling loops run more than 1000 iterations of the SAME state in total, so the degree
-    # is pinned for the whole measurement (--sh-degree picks another one): without this the later blocks and both sibling loops
-    # silently ran at degree 1 (Adam over f_rest, SH backward: +25 us per iteration).
-    st.gaussians.oneupSHdegree = lambda: None
+    # Every loop is measured on the SAME stretch of training: iterations PIN_ITER .. 1000 of the run from seed `rank` (the state
+    # drifts while a scene trains — instance counts grow, kernels with them: +13 % over the 800 iterations of round 3's timed
+    # region — so a sample's position in training must not depend on how fast the box is).  A fresh state is set up for each loop
+    # and fast-forwarded, untimed, with the run-ahead driver.
+    PIN_ITER = 0 if emulated else 200
+
+    def fresh_state(fast_forward=True):
+        st_ = setup_training(scene, dev, opt=opt)
+        st_.gaussians.active_sh_degree = args.sh_degree
+        # The line is quoted on the regime of the reference's first 1000 iterations (SH degree 0, train.py:149-150 raises it every
+        # 1000); warm-up + blocks cross iteration 1000 of the same state, so the degree is pinned (--sh-degree picks another one).
+        st_.gaussians.oneupSHdegree = lambda: None
+        if fast_forward and PIN_ITER:
+            ra_ = RunAhead(st_, window=10)
+            for _ in range(PIN_ITER):
+                ra_.step()
+            ra_.flush()
+            if ra_.trainer is not None:
+                ra_.trainer.close()
+            BinningPolicy.reset("exact")
+        return st_
+
+    st0 = fresh_state(fast_forward=False)
+    P = st0.gaussians.get_xyz.shape[0]
     if args.sh_degree:
         args.cpu_iters = 0   # the CPU trainer restates the degree-0 schedule only
 
-    # ---- CPU baseline state is cloned BEFORE the GPU run changes the parameters
+    # ---- CPU baseline state: the run's initial state, cloned before any GPU training
     cpu_trainer = None
     if rank == 0 and world == 1 and args.cpu_iters > 0:
         from oracle.train_ref import CpuTrainer
-        g = st.gaussians
+        g = st0.gaussians
         g.update_learning_rate(1)
         lrs = {grp["name"]: grp["lr"] for grp in g.optimizer.param_groups}
         params = dict(xyz=g._xyz, f_dc=g._features_dc, f_rest=g._features_rest, opacity=g._opacity, scaling=g._scaling,
                       rotation=g._rotation, pose=g.P)
-        cpu_trainer = CpuTrainer(params, st.cameras, st.gt_images, g.per_point_lr, lrs)
-
-    psnr_before = evaluate_psnr(st)
+        cpu_trainer = CpuTrainer(params, st0.cameras, st0.gt_images, g.per_point_lr, lrs)
+    psnr_before = evaluate_psnr(st0)
+    del st0
 
     def dev_sync():
         if dev.type == "cuda":
@@ -158,111 +177,129 @@ def main():
             return float(t.item())
         return x
 
-    own_seconds = []
-
     def timed_block(step, n, finish=lambda: None):
-        """n iterations bracketed by barrier + device synchronize on both sides; seconds, MAX over ranks"""
+        """n iterations bracketed by barrier + device synchronize on both sides; (seconds MAX over ranks, this rank's own seconds)"""
         sync()
         t0 = time.perf_counter()
         for _ in range(n):
             step()
         finish()
         dev_sync()
-        own_seconds.append(time.perf_counter() - t0)   # this rank's own clock, before it waits for the others
+        own = time.perf_counter() - t0   # this rank's own clock, before it waits for the others
         sync()
-        return reduce_max(time.perf_counter() - t0)
+        return reduce_max(time.perf_counter() - t0), own
 
-    synced_step = lambda: train_iteration(st, fused_step=True)   # one-call step + the reference's per-iteration loss read-back
+    # the contract's K steps are one block; the blocks cover iterations PIN_ITER + W .. ~1000 whatever K is (the driver's
+    # --steps 20 gives 40 blocks of 6 ms), and the MEDIAN block is reported.  The count is a function of K alone.
+    n_blocks = 1 if emulated else max(1, min(40, -(-(1000 - PIN_ITER) // args.steps)))
 
+    def measure(make_step):
+        """One loop under the contract's protocol on a fresh, fast-forwarded state.  make_step(state) -> (step, finish, close)."""
+        st_ = fresh_state()
+        step, finish, close = make_step(st_)
+        for _ in range(args.warmup):
+            step()
+        finish()
+        blocks, own = [], []
+        for _ in range(n_blocks):
+            b, o = timed_block(step, args.steps, finish)
+            blocks.append(b)
+            own.append(o)
+        close()
+        BinningPolicy.reset("exact")
+        med = sorted(blocks)[len(blocks) // 2]
+        return {"iters_per_sec": world * args.steps / med, "ms_per_step": 1e3 * med / args.steps, "timed_blocks": len(blocks),
+                "block_seconds": blocks, "timed_seconds": sum(blocks), "first_timed_iteration": PIN_ITER + args.warmup + 1,
+                "iters_per_sec_own_clock": args.steps / sorted(own)[len(own) // 2]}, st_
+
+    def dropin_loop(st_):      # the reference's loop on the drop-in operators: autograd, loss.item(), optimizer.step(), zero_grad
+        return (lambda: train_iteration(st_)), (lambda: None), (lambda: None)
+
+    def one_call_synced(st_):  # the same iteration behind ONE library call, loss read back every iteration
+        return (lambda: train_iteration(st_, fused_step=True)), (lambda: None), (lambda: release_trainer(st_))
+
+    def one_call_run_ahead(st_):   # ... without the per-iteration read-back (identical results: tests/ops_util.py::check_run_ahead_equals_sync_loop)
+        ra_ = RunAhead(st_, window=10)
+
+        def close():
+            if ra_.trainer is not None:
+                ra_.trainer.close()
+                ra_.trainer = None
+            replays.append(ra_.replays)
+        return ra_.step, ra_.flush, close
+
+    replays = []
     # ---- N > 1: what one rank does ALONE on this box (the others wait at the barrier), so that the line carries its own
-    # N = 1 reference for the scaling efficiency — same process, same scene, same clocks
+    # N = 1 reference for the scaling efficiency — same process, same scene, same loop, same stretch of training
     solo_its = None
     if world > 1:
+        st_solo = fresh_state()
         for _ in range(args.warmup):
-            synced_step()
+            train_iteration(st_solo)
         sync()
         if rank == 0:
             dev_sync()
             ts = time.perf_counter()
             for _ in range(args.steps):
-                synced_step()
+                train_iteration(st_solo)
             dev_sync()
             solo_its = args.steps / (time.perf_counter() - ts)
         sync()
+        del st_solo
 
-    for _ in range(args.warmup):
-        synced_step()
-    sync()
-    # live kernel timing: HIP events around every PROF_EVERY-th launch of the two composite kernels on the launch stream (an event
-    # pair costs ~3.5 us of stream time: around every launch it would add 14 us to a 311 us iteration)
-    prof_every = PROF_EVERY if args.steps >= 10 * PROF_EVERY else max(1, args.steps // 10)   # at least ~10 timed launches per block
-    L.mi355gs_profile_set_period(prof_every)
+    # ---- the timed region.  NO instrumentation runs inside it (round 3 sampled kernel events there: ~1 % of ms_per_step).
+    headline, st = measure(dropin_loop)
+    synced, _ = measure(one_call_synced)
+    run_ahead, _ = measure(one_call_run_ahead)
+    elapsed = headline["ms_per_step"] * 1e-3 * args.steps
+    value = headline["iters_per_sec"]
+    psnr_after = evaluate_psnr(st)
+
+    # ---- kernel durations for the roofline: an UNTIMED pass over the same stretch of training (fresh state, iterations
+    # PIN_ITER .. PIN_ITER + 300 of the one-call step), HIP events on the launch stream around every launch of the two composite kernels
+    stp = fresh_state()
+    n_prof = 3 if emulated else 300
+    for _ in range(5 if not emulated else 1):
+        train_iteration(stp, fused_step=True)
+    dev_sync()
+    L.mi355gs_profile_set_period(1)
     L.mi355gs_profile_begin()
-    blocks = [timed_block(synced_step, args.steps)]
-    # the contract's K steps are one block; short blocks (the driver runs --steps 20: a 6 ms sample) are repeated until the
-    # timed region covers >= 0.25 s, and the MEDIAN block is reported.  Every rank derives the same count from the reduced time.
-    n_blocks = 1 if emulated else max(1, min(40, int(0.25 / max(blocks[0], 1e-6)) + 1))
-    for _ in range(n_blocks - 1):
-        blocks.append(timed_block(synced_step, args.steps))
-    elapsed = sorted(blocks)[len(blocks) // 2]
-    own_its = args.steps / sorted(own_seconds[:len(blocks)])[len(blocks) // 2]
+    for _ in range(n_prof):
+        train_iteration(stp, fused_step=True)
+    dev_sync()
     tot_ms, n = ctypes.c_double(), ctypes.c_int()
     kern = {}
     for kind, name in ((0, "composite_fwd"), (1, "composite_bwd")):
         _lib.check(L.mi355gs_profile_read(kind, ctypes.byref(tot_ms), ctypes.byref(n)), "profile_read")
         kern[name] = (tot_ms.value / max(n.value, 1), n.value)
     L.mi355gs_profile_end()
-    L.mi355gs_profile_set_period(1)
-    if getattr(st, "_trainer", None) is not None:   # one handle at a time writes the parameters (include/mi355gs.h)
-        st._trainer.close()
-        st._trainer = None
-
-    # ---- the same step without the per-iteration read-back: identical arithmetic and results (tests/ops_util.py::
-    # check_run_ahead_equals_sync_loop), losses kept in a device ring, instance buffers sized from verified counts
-    n_side = min(args.steps, 100)
-    ra = RunAhead(st, window=10)
-    for _ in range(30 if not emulated else 1):
-        ra.step()
-    ra.flush()
-    median3 = lambda f: sorted(f() for _ in range(1 if emulated else 3))[0 if emulated else 1]   # (a block can contain a one-off: a
-    # trainer rebuilt for a grown scene, an allocator refill — the median of three blocks is the rate of the loop)
-    run_ahead_its = world * n_side / median3(lambda: timed_block(ra.step, n_side, finish=ra.flush))
-    if ra.trainer is not None:
-        ra.trainer.close()
-        ra.trainer = None
+    release_trainer(stp)
     BinningPolicy.reset("exact")
-
-    # ---- the reference-shaped loop on the drop-in operators (autograd path, both of the reference's read-backs)
-    for _ in range(20 if not emulated else 1):   # (caching allocator, per-view count hints and the optimizer's fast path settle)
-        train_iteration(st)
-    autograd_loop_its = world * n_side / median3(lambda: timed_block(lambda: train_iteration(st), n_side))
-    sync_loop_its = world * args.steps / elapsed
 
     # ---- rasterize ms/frame (reference render.py:172-186 methodology, with an explicit synchronize)
     with torch.no_grad():
-        cam = st.cameras[0]
+        cam = stp.cameras[0]
         for _ in range(5 if not emulated else 1):
-            render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
+            render(cam, stp.gaussians, stp.pipe, stp.background, camera_pose=stp.gaussians.get_RT(cam.uid))
         dev_sync()
         tr = time.perf_counter()
         nfr = 50 if not emulated else 1
         for _ in range(nfr):
-            render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
+            render(cam, stp.gaussians, stp.pipe, stp.background, camera_pose=stp.gaussians.get_RT(cam.uid))
         dev_sync()
         raster_ms = 1e3 * (time.perf_counter() - tr) / nfr
 
-    # ---- instance statistics of the trained scene (algorithmic bytes of the composite kernels)
+    # ---- instance statistics of the state the kernels were timed on (algorithmic bytes of the composite kernels)
     keep_last_frame(True)
     Rs, Reffs = [], []
     with torch.no_grad():
-        for cam in st.cameras:
-            render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
+        for cam in stp.cameras:
+            render(cam, stp.gaussians, stp.pipe, stp.background, camera_pose=stp.gaussians.get_RT(cam.uid))
             r, reff = last_frame_stats()
             Rs.append(r)
             Reffs.append(reff)
     keep_last_frame(False)
     R_eff = sum(Reffs) / len(Reffs)
-    psnr_after = evaluate_psnr(st)
 
     # ---- final metric reduction: the only collective on the path (SURVEY.md 8e)
     red = torch.tensor([psnr_after, 1.0, float(args.steps), elapsed], dtype=torch.float64, device=red_dev)
@@ -270,7 +307,6 @@ def main():
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
     mean_psnr = float(red[0] / red[1])
 
-    value = world * args.steps / elapsed
     bwd_ms, bwd_n = kern["composite_bwd"]
     fwd_ms, fwd_n = kern["composite_fwd"]
     # K7 = 40 B x R_eff + 20 B x W*H read + 72 B x R_eff (nine-float read-modify-write per instance)
@@ -283,23 +319,24 @@ def main():
     # reductions over one backward per view; the per-part issue cycles are those of the shipped binary's instruction mix
     # (tools/isa_cost.py) at the per-class costs measured on MI355X by tools/ubench/valu_rate.hip (plain fp32 2 cycles per wave64
     # instruction, packed / DPP / compare / select / min-max 4, transcendental and v_permlane*_swap 8).
-    compute = None
+    compute, fwd_compute = None, None
     if not emulated:
-        ctr = torch.zeros(8, dtype=torch.int64, device=dev)
+        ctr = torch.zeros(16, dtype=torch.int64, device=dev)
         _lib.check(L.mi355gs_profile_work_counters(_lib.ptr(ctr)), "profile_work_counters")
         try:
             for _ in range(V):
-                train_iteration(st, fused_step=True)
+                train_iteration(stp, fused_step=True)
             dev_sync()
         finally:
             _lib.check(L.mi355gs_profile_work_counters(None), "profile_work_counters")
+            release_trainer(stp)
         steps_c, quads, quads_valid, lanes, reduced, waves = [float(x) / V for x in ctr.tolist()[:6]]
         # per-part costs of the SHIPPED binary: read off the compiler's output of composite.hip at build time
         # (instantsplat_amd/csrc/Makefile -> lib/bwd_issue_model.json, tools/isa_cost.py --bwd-model); the values below are that
         # table for the round-3 tree and only stand in if the file is missing.  tools/validate_issue_model.py checks the
         # instruction total against SQ_INSTS_VALU on fixed frames (profiles/r03_issue_model_vs_SQ_INSTS_VALU.txt).
-        CYC = {"step": 40.0, "quad": 26.5, "quad_valid": 58.0, "reduce": 52.0, "init": 17.0, "wave": 1406.0}   # VALU issue cycles per part
-        INS = {"step": 17.0, "quad": 7.25, "quad_valid": 24.0, "reduce": 22.0, "init": 8.5, "wave": 463.0}    # VALU wave-instructions per part
+        CYC = {"step": 30.0, "quad": 26.5, "quad_valid": 58.0, "reduce": 52.0, "init": 17.0, "wave": 480.0}   # VALU issue cycles per part
+        INS = {"step": 15.0, "quad": 7.25, "quad_valid": 24.0, "reduce": 22.0, "init": 8.5, "wave": 159.0}    # VALU wave-instructions per part
         model_src = "built-in table (lib/bwd_issue_model.json missing)"
         try:
             with open(os.path.join(ROOT, "instantsplat_amd", "lib", "bwd_issue_model.json")) as fh:
@@ -324,12 +361,47 @@ def main():
                    "issue_frac_at_2.4GHz": (cyc / n_simd) / (bwd_s * clock) if bwd_s > 0 else None,
                    "lane_ops_per_s": ins * 64.0 / bwd_s if bwd_s > 0 else None, "lane_ops_peak_per_s": n_simd * 32.0 * clock,
                    "cycles_per_part": CYC, "instructions_per_part": INS, "per_part_table": model_src,
+                   "half_empty_exec_issues_at_full_cost": "profiles/r04_ubench_exec_half_issue_cycles.txt (a wave64 VALU instruction "
+                                                          "costs the same issue cycles with EXEC_HI = 0: idle lanes cannot be skipped)",
                    "note": "issue_frac assumes the 2.4 GHz maximum clock (the chip runs 2.0-2.3 GHz under this load, so the true "
                            "fraction is higher); lane_ops counts 64 lanes per VALU wave-instruction against 1024 SIMDs x 32 lanes/clk"}
+
+        # ---- the same for the forward (counters [8..13] of the same launches; per-part table lib/fwd_issue_model.json: a walk step of
+        # two hits, a 64-record group with its cull, the per-wave prologue / epilogue)
+        groups, hits, fsteps, fvalid, fblended, fwaves = [float(x) / V for x in ctr.tolist()[8:14]]
+        FCYC, FINS, fsrc = {"step": 148.0, "group": 232.0, "wave": 366.0}, {"step": 46.0, "group": 77.0, "wave": 100.0}, "built-in table (lib/fwd_issue_model.json missing)"
+        try:
+            with open(os.path.join(ROOT, "instantsplat_amd", "lib", "fwd_issue_model.json")) as fh:
+                ftab = json.load(fh)
+            FCYC, FINS, fsrc = ftab["CYC"], ftab["INS"], "instantsplat_amd/lib/fwd_issue_model.json (" + ftab["source"] + ")"
+        except (OSError, KeyError, ValueError):
+            pass
+        fcyc = fsteps * FCYC["step"] + groups * FCYC["group"] + fwaves * FCYC["wave"]
+        fins = fsteps * FINS["step"] + groups * FINS["group"] + fwaves * FINS["wave"]
+        fwd_s = kern["composite_fwd"][0] * 1e-3
+        fwd_compute = {"kernel": "k_composite_fwd", "bound": "valu-issue", "groups_per_launch": groups, "hits_per_launch": hits,
+                       "walk_steps_per_launch": fsteps, "hits_per_walk_step": hits / fsteps if fsteps else None,
+                       "valid_pixel_gaussian_pairs": fvalid, "blended_pixel_gaussian_pairs": fblended, "quadrant_waves": fwaves,
+                       "useful_lane_frac": fvalid / (64.0 * hits) if hits else None,
+                       "valu_issue_cycles_per_launch_model": fcyc, "valu_wave_instructions_per_launch_model": fins,
+                       "issue_cycles_per_hit": fcyc / hits if hits else None,
+                       "issue_frac_at_2.4GHz": (fcyc / n_simd) / (fwd_s * clock) if fwd_s > 0 else None,
+                       "cycles_per_part": FCYC, "instructions_per_part": FINS, "per_part_table": fsrc,
+                       "note": "a 512^2 frame is ONE resident round of 4096 quadrant waves (four per SIMD) that nothing rebalances: the kernel "
+                               "lasts as long as its busiest SIMD, so the average issue fraction understates how busy the critical SIMDs are "
+                               "(DESIGN.md 4.2: average wave resident for 0.79 of the kernel)"}
 
     # ---- the metric as BASELINE.json words it: "1k iters" of full training on C3 (configs[2]), both loops, wall clock
     long_runs = None
     fps = None
+    legs_skipped = []
+    if emulated:
+        legs_skipped.append("emulated kernels: no issue model, no long runs, no FPS loop")
+    if world > 1:
+        legs_skipped += ["cpu_baseline (rank 0 at N = 1 only)", "iters_per_sec_1k and fps_reference_method (N = 1 only: they are "
+                         "single-scene wall-clock legs outside the timed region)"]
+    elif not args.long_run:
+        legs_skipped.append("iters_per_sec_1k and fps_reference_method (--no-long-run)")
     if not emulated and args.long_run and world == 1:
         from instantsplat_amd.pose_tracking import measure_fps
         from instantsplat_amd.train import training
@@ -360,7 +432,7 @@ def main():
     traffic, traffic_src, fwd_traffic = None, None, None
     try:  # HBM-side bytes per launch: rocprofv3 --pmc passes of this command, collected separately (counters cannot run inside a
         # timed bench) and committed under profiles/; the newest round present is used and named
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 fr, wr = pmc_rows(f"{rnd}_pmc_c3_FETCH_SIZE.csv"), pmc_rows(f"{rnd}_pmc_c3_WRITE_SIZE.csv")
                 f_, w_ = fr["k_composite_bwd"], wr["k_composite_bwd"]
@@ -377,7 +449,7 @@ def main():
 
     valu = None
     try:  # SQ counter pass of the same command (separate run)
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 row = pmc_rows(f"{rnd}_pmc_c3_SQ_counters.csv")["k_composite_bwd"]
             except (OSError, KeyError):
@@ -410,7 +482,10 @@ def main():
         import socket
         mine = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "gpu": device_identity(dev), "cpus": len(cpus),
                 "first_cpu": cpus[0] if cpus else None,
-                "iters_per_sec_median_block_own_clock": own_its, "psnr_after": psnr_after}
+                "iters_per_sec_median_block_own_clock": headline["iters_per_sec_own_clock"],            # the headline (drop-in) loop
+                "ms_per_step_dropin_own_clock": 1e3 / headline["iters_per_sec_own_clock"],
+                "iters_per_sec_one_call_synced_own_clock": synced["iters_per_sec_own_clock"],
+                "iters_per_sec_one_call_run_ahead_own_clock": run_ahead["iters_per_sec_own_clock"], "psnr_after": psnr_after}
         reports = gather_rank_reports(mine)
         if not emulated:
             assert_one_rank_per_device(reports, torch.cuda.device_count())
@@ -437,27 +512,41 @@ def main():
                                    f"), one scene per GPU", "views": V, "gaussians": P, "width": res, "height": res,
                        "parallelism": f"scene-per-gpu x{world}"},
             "rasterize_ms_per_frame": raster_ms,
-            "loop": "one-call step (mi355gs_trainer_step) with the reference's per-iteration blocking loss read-back (train.py:188)",
-            "timed_blocks": len(blocks), "block_seconds": blocks, "timed_seconds": sum(blocks),
-            "iters_per_sec_with_per_iteration_loss_readback": sync_loop_its,
-            "iters_per_sec_run_ahead": run_ahead_its, "run_ahead_window_replays": ra.replays,
-            "iters_per_sec_dropin_reference_loop": autograd_loop_its, "iters_per_sec_autograd_path": autograd_loop_its,
+            "value_path": "drop-in reference loop",
+            "loop": "the reference's train.py loop shape on the drop-in operators (render() / GaussianRasterizer / fused_ssim / PerPointAdam "
+                    "through the compiled binding): autograd, the operator's blocking instance-count read-back and the blocking "
+                    "loss.item() read-back (train.py:188) every iteration — the loop north_star names",
+            "timed_blocks": headline["timed_blocks"], "block_seconds": headline["block_seconds"], "timed_seconds": headline["timed_seconds"],
+            "timed_iterations": f"{headline['first_timed_iteration']} .. {headline['first_timed_iteration'] + n_blocks * args.steps - 1} of training "
+                                f"from seed {rank} (every loop on a fresh state fast-forwarded to iteration {PIN_ITER}); no instrumentation inside",
+            "loops": {"dropin_reference_loop": headline,
+                      "one_call_synced": dict(synced, what="mi355gs_trainer_step: the whole iteration behind one library call, loss and instance "
+                                                           "count read back every iteration (device-side commit gate, host half of the next "
+                                                           "iteration overlapped)"),
+                      "one_call_run_ahead": dict(run_ahead, what="the same step without the per-iteration read-back (identical results; EMA "
+                                                                 "evaluated every 10 iterations)", window_replays=sum(replays))},
+            "iters_per_sec_dropin_reference_loop": headline["iters_per_sec"], "iters_per_sec_autograd_path": headline["iters_per_sec"],
+            "iters_per_sec_with_per_iteration_loss_readback": synced["iters_per_sec"], "iters_per_sec_one_call_synced": synced["iters_per_sec"],
+            "iters_per_sec_run_ahead": run_ahead["iters_per_sec"], "run_ahead_window_replays": sum(replays),
             "binding": _lib.BINDING,
-            "multi_gpu": multi,
+            "multi_gpu": multi, "legs_skipped": legs_skipped,
             "psnr_before": psnr_before, "psnr_after_mean": mean_psnr,
             "iters_per_sec_1k": long_runs, "fps_reference_method": fps,
-            "roofline": {"kernel": "k_composite_bwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": bwd_ms,
-                         "launches": bwd_n, "timed_every": prof_every, "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs),
+            "roofline": {"kernel": "k_composite_bwd", "bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_hbm": achieved / HBM_PEAK_GBS, "frac_issue": (compute or {}).get("issue_frac_at_2.4GHz"),
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": bwd_ms,
+                         "launches": bwd_n, "timed_every": 1, "timed_where": f"untimed pass, iterations {PIN_ITER + 6} .. {PIN_ITER + 5 + n_prof} of the one-call step",
+                         "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs),
                          "pmc_sq": valu, "compute": compute,
-                         "note": "the kernel is VALU-issue-bound, not HBM-bound (roofline.compute: counters of this run x measured issue "
-                                 "costs): the HBM fraction is reported as the contract asks.  traffic > algorithmic bytes: the backward runs in "
-                                 "64-instance units (DESIGN.md 4.2b) that re-read a 16 B/pixel boundary record and 32 B/pixel of pixel state "
-                                 "per unit, L2 / Infinity-Cache resident at this size; units grow to 512 instances on large frames",
+                         "note": "achieved / peak / frac are the HBM roofline the contract asks for (algorithmic bytes / kernel time / 8 TB/s); "
+                                 "the kernel is bound by VALU issue, not by HBM: frac_issue = modelled VALU issue cycles per SIMD / the kernel's "
+                                 "cycles at 2.4 GHz (roofline.compute: work counters of this run x per-part costs of the shipped binary).  "
+                                 "traffic > algorithmic bytes: the backward runs in 64-instance units (DESIGN.md 4.2b) that re-read a 16 B/pixel "
+                                 "boundary record and 32 B/pixel of pixel state per unit, L2 / Infinity-Cache resident at this size",
                          "composite_fwd": {"avg_kernel_ms": fwd_ms, "launches": fwd_n, "algorithmic_bytes_per_launch": fwd_bytes,
                                            "achieved": fwd_bytes / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0,
                                            "frac": (fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fwd_ms > 0 else 0.0,
-                                           "traffic": fwd_traffic,
+                                           "traffic": fwd_traffic, "compute": fwd_compute,
                                            "note": "traffic above the algorithmic bytes: the forward leaves a 16 B/pixel boundary record per "
                                                    "64-instance unit of every tile for the segmented backward (DESIGN.md 4.2b)"}},
             "cpu_baseline": cpu_baseline,

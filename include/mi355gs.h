@@ -137,10 +137,12 @@ int mi355gs_profile_begin(void);
 /* Time only every `every`-th launch of a kind (default 1: all).  An event pair costs ~3.5 us of stream time, which matters when
  * the timed kernels are part of a measured loop.  Returns the previous period; every <= 0 only queries. */
 int mi355gs_profile_set_period(int every);
-/* While `counters` (device uint64[8], zeroed by the caller) is non-null, every composite-backward launch runs its counting
- * instantiation and ADDS: [0] (Gaussian, tile) steps, [1] quadrant bodies evaluated, [2] of those with at least one valid
- * pixel, [3] valid (pixel, Gaussian) pairs, [4] steps that ended in a reduction + atomics, [5] waves that did work.
- * null switches back to the shipped kernel (which has no counters).  Process-wide, measurement only. */
+/* While `counters` (device uint64[16], zeroed by the caller) is non-null, every composite launch runs its counting
+ * instantiation and ADDS — backward: [0] (Gaussian, tile) steps, [1] quadrant bodies evaluated, [2] of those with at least one
+ * valid pixel, [3] valid (pixel, Gaussian) pairs, [4] steps that ended in a reduction + atomics, [5] waves that did work;
+ * forward: [8] staged 64-record groups (one cull each), [9] (Gaussian, quadrant) hits, [10] walk steps (two hits each),
+ * [11] (pixel, Gaussian) pairs that pass the alpha tests, [12] of those blended (not the stopping one), [13] quadrant waves.
+ * null switches back to the shipped kernels (which have no counters).  Process-wide, measurement only. */
 int mi355gs_profile_work_counters(void* counters);
 int mi355gs_profile_read(int kind, double* total_ms, int* launches);
 int mi355gs_profile_end(void);

@@ -16,7 +16,7 @@ int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, co
                       const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             float*, float*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint4*, float4*, uint32_t,
-                            const uint32_t*, unsigned long long*, uint32_t, uint32_t*);
+                            const uint32_t*, unsigned long long*, uint32_t, uint32_t*, unsigned long long*);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint4*,
                             const float4*, const uint32_t*, uint32_t, bool, const unsigned long long*, uint32_t, const uint32_t*,
@@ -28,7 +28,7 @@ namespace {
 constexpr int PROF_KINDS = 2, PROF_MAX = 8192;
 struct ProfState {
   bool on = false;
-  unsigned long long* work_counters = nullptr;   // device uint64[8] or null (mi355gs_profile_work_counters)
+  unsigned long long* work_counters = nullptr;   // device uint64[16] or null (mi355gs_profile_work_counters)
   hipEvent_t ev[PROF_KINDS][PROF_MAX][2];
   int created[PROF_KINDS] = {0, 0};
   int used[PROF_KINDS] = {0, 0};
@@ -150,7 +150,7 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
                             (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.seg_first), (const uint32_t*)(t + tl.part_first),
                             (uint4*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, (const uint32_t*)(t + tl.meta),
-                            (unsigned long long*)(b + bl.hitmask), bl.max_chunks, (uint32_t*)(t + tl.qmax));
+                            (unsigned long long*)(b + bl.hitmask), bl.max_chunks, (uint32_t*)(t + tl.qmax), g_prof.work_counters);
   }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;

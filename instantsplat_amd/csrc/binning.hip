@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int SCAN_THREADS = 1024;
+constexpr size_t SCAN_STAGE_MAX_BYTES = 48 * 1024;   // dynamic LDS of the staged tile scan (next to ~9 KiB static): 12288 tiles
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_SMALL_CAP = GS_SORT_SMALL_CAP;  // small kernel: <= 8 keys per thread, 16 KiB LDS, ~40 VGPRs -> 8 workgroups per CU
 constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64 KiB LDS
@@ -24,16 +25,32 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 // (count and start may alias: every thread reads an element before it overwrites it)
 // With `order` set it also writes order[] = tile indices by descending count (counting sort over 1024 count buckets — exact
 // order inside a bucket is irrelevant for load balance): the per-tile kernels launch their heaviest tiles first.
+// STAGED (frames with more tiles than threads: 1080p has 8160): thread t owns `per` CONSECUTIVE tiles, so its reads of count[]
+// are `per` words apart from its neighbour's — every pass over the counts (sum, maximum, histogram, order, units, starts) was a
+// loop of strided, dependent global loads in a kernel that is one workgroup's latency chain (30.2 us at 8160 tiles).  The counts
+// are instead fetched ONCE, coalesced and all loads in flight together, into LDS in the owner-major transposed layout
+// [k][thread] (element k of thread t at k * SCAN_THREADS + t: conflict-free for every later pass), and the passes read LDS:
+// 23.7 us (profiles/r04_c4_1M_1080p_kernel_stats.csv).
+template <bool STAGED>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
                                                                uint32_t* __restrict__ seg_first, uint32_t* __restrict__ part_first,
                                                                uint32_t min_units) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / GS_WAVE];
+  HIP_DYNAMIC_SHARED(uint32_t, s_stage)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
   const int lo = tid * per, hi = min(T, lo + per);
+  if constexpr (STAGED) {
+    for (int e = tid; e < T; e += SCAN_THREADS) s_stage[(e % per) * SCAN_THREADS + e / per] = count[e];
+    __syncthreads();
+  }
+  auto cnt = [&](int i) -> uint32_t {   // the count of tile i, lo <= i < hi (one of this thread's own)
+    if constexpr (STAGED) return s_stage[(i - lo) * SCAN_THREADS + tid];
+    else return count[i];
+  };
   uint32_t local = 0;
-  for (int i = lo; i < hi; ++i) local += count[i];
+  for (int i = lo; i < hi; ++i) local += cnt(i);
   // wave inclusive scan (DPP: this single-workgroup kernel is a chain of latencies, and a __shfl_up step is an LDS round trip)
   const uint32_t incl = gs_wave_scan_incl_u32(local);
   if (lane == 63) wave_tot[wave] = incl;
@@ -50,7 +67,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     __shared__ uint32_t hist[SCAN_THREADS];
     __shared__ uint32_t s_max;
     uint32_t mx = 0;
-    for (int i = lo; i < hi; ++i) mx = max(mx, count[i]);
+    for (int i = lo; i < hi; ++i) mx = max(mx, cnt(i));
     mx = gs_wave_max_u32(mx);
     hist[tid] = 0u;
     if (tid == 0) s_max = 0u;
@@ -58,8 +75,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     if (lane == 0) atomicMax(&s_max, mx);
     __syncthreads();
     const uint32_t cmax = max(s_max, 1u);
-    auto bucket = [&](uint32_t c) { return (uint32_t)(SCAN_THREADS - 1) - (uint32_t)(((uint64_t)c * (SCAN_THREADS - 1)) / cmax); };
-    for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(count[i])], 1u);
+    // (bucket boundaries need not be exact, only the same in both passes and monotone in the count: a float multiply instead of
+    // a 64-bit division per tile and pass — a hundred-odd instructions each on this latency chain)
+    const float bscale = (float)(SCAN_THREADS - 1) / (float)cmax;
+    auto bucket = [&](uint32_t c) { return (uint32_t)(SCAN_THREADS - 1) - min((uint32_t)(SCAN_THREADS - 1), (uint32_t)((float)c * bscale)); };
+    for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(cnt(i))], 1u);
     __syncthreads();
     // exclusive scan of the 1024 bucket sizes (one per thread)
     const uint32_t h = hist[tid];
@@ -73,7 +93,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
       if (w < wave) hoff += hist_wave[w];
     hist[tid] = hoff + hi_ - h;
     __syncthreads();
-    for (int i = lo; i < hi; ++i) order[atomicAdd(&hist[bucket(count[i])], 1u)] = (uint32_t)i;
+    for (int i = lo; i < hi; ++i) order[atomicAdd(&hist[bucket(cnt(i))], 1u)] = (uint32_t)i;
     __syncthreads();
   }
   if (seg_first) {
@@ -84,7 +104,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     // ... and, in the same pass, the prefix of "this tile's last unit is a short one" (part_first): the backward launches
     // the full-length units first and the short ones last, where they shorten the tail of the kernel (composite.hip)
     uint32_t lseg = 0, lpart = 0;
-    for (int i = lo; i < hi; ++i) { lseg += (count[i] + seg_len - 1) / seg_len; lpart += (count[i] % seg_len) != 0u; }
+    for (int i = lo; i < hi; ++i) { lseg += (cnt(i) + seg_len - 1) / seg_len; lpart += (cnt(i) % seg_len) != 0u; }
     const uint32_t iseg = gs_wave_scan_incl_u32(lseg), ipart = gs_wave_scan_incl_u32(lpart);
     __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
     __shared__ uint32_t part_wave[SCAN_THREADS / GS_WAVE];
@@ -99,15 +119,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     uint32_t srun = soff + iseg - lseg, prun = poff + ipart - lpart;
     for (int i = lo; i < hi; ++i) {
       seg_first[i] = srun; part_first[i] = prun;
-      srun += (count[i] + seg_len - 1) / seg_len;
-      prun += (count[i] % seg_len) != 0u;
+      srun += (cnt(i) + seg_len - 1) / seg_len;
+      prun += (cnt(i) % seg_len) != 0u;
     }
     if (tid == 0) { part_first[T] = ptot; meta[3] = ptot; }
     if (tid == 0) { seg_first[T] = stot; meta[1] = stot; meta[2] = chunks; }
   }
   uint32_t run = wave_off + incl - local;
   for (int i = lo; i < hi; ++i) {
-    const uint32_t c = count[i];
+    const uint32_t c = cnt(i);
     start[i] = run;
     run += c;
   }
@@ -571,8 +591,14 @@ void gs_pin_min_units(int v) { g_min_units_pinned = v; }
 
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
                          uint32_t* meta, uint32_t* seg_first, uint32_t* part_first) {
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order, meta, seg_first,
-                     part_first, (uint32_t)gs_min_units());
+  // more tiles than threads and the counts fit the workgroup's dynamic LDS: the staged form (see the kernel)
+  const size_t stage_bytes = (size_t)((T + SCAN_THREADS - 1) / SCAN_THREADS) * SCAN_THREADS * 4;   // [per][SCAN_THREADS] words
+  if (T > SCAN_THREADS && stage_bytes <= SCAN_STAGE_MAX_BYTES)
+    hipLaunchKernelGGL(k_scan_tiles<true>, dim3(1), dim3(SCAN_THREADS), stage_bytes, stream, T, count, start, num_rendered, order, meta,
+                       seg_first, part_first, (uint32_t)gs_min_units());
+  else
+    hipLaunchKernelGGL(k_scan_tiles<false>, dim3(1), dim3(SCAN_THREADS), 0, stream, T, count, start, num_rendered, order, meta, seg_first,
+                       part_first, (uint32_t)gs_min_units());
   return 0;
 }
 
@@ -580,7 +606,7 @@ int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint3
 int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t* out, uint32_t* block_sums, int32_t* total) {
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
+  hipLaunchKernelGGL(k_scan_tiles<false>, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
                      (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);  // in place
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;

@@ -138,7 +138,10 @@ constexpr int FWD_GROUP = GS_FWD_GROUP;   // hits per walk step (A/B build switc
 #ifndef GS_FWD_TILES
 #define GS_FWD_TILES 0   // 0: by the frame's tile count (gs_launch_composite_fwd); 1, 2, 4: forced (A/B builds)
 #endif
-template <int FWD_TILES>
+// COUNT: the measurement instantiation (mi355gs_profile_work_counters, like the backward's): the same kernel also adds up, per
+// wave, its staged groups, hits, walk steps and the lanes of a hit that hold a blendable (pixel, Gaussian) pair — the inputs of
+// the forward's VALU-issue model in bench.py (counters[8 ..]).  The shipped launches use COUNT = false: no counters exist.
+template <int FWD_TILES, bool COUNT = false>
 __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ list, const GsRec* __restrict__ recs,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
@@ -147,7 +150,9 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
                                                         const uint32_t* __restrict__ part_first, uint4* __restrict__ unit_tile,
                                                         float4* __restrict__ bstate, uint32_t max_units,
                                                         const uint32_t* __restrict__ meta, unsigned long long* __restrict__ hitmask,
-                                                        uint32_t max_chunks, uint32_t* __restrict__ qmax) {
+                                                        uint32_t max_chunks, uint32_t* __restrict__ qmax,
+                                                        unsigned long long* __restrict__ counters) {
+  [[maybe_unused]] unsigned long long c_groups = 0, c_hits = 0, c_steps = 0, c_valid = 0, c_blended = 0;
   // The wave's staged group: 64 records of three float4 each, record-major (48 B apiece), at an address the SCALAR unit knows —
   // the wave index is read into an SGPR and the walk's record index is scalar already, so a hit's three broadcast reads take
   // ONE address register filled by a v_mov from an SGPR plus immediate offsets.  (Three separate arrays indexed through the
@@ -237,7 +242,9 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
     pr_hits += __popcll(mask); pr_groups += 1;
     const unsigned long long pr_k0 = GS_PROBE_CLOCK();
 #endif
+    if constexpr (COUNT) { c_groups += 1; c_hits += __popcll(mask); }
     while (mask) {
+      if constexpr (COUNT) c_steps += 1;
       int idx[FWD_GROUP];
       bool live[FWD_GROUP];
 #pragma unroll
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
         // a skipped Gaussian is a transparent one (and so is the padding of a short group)
         valid[u] = live[u] && power2 <= 0.0f && alpha >= ALPHA_MIN;
         al[u] = valid[u] ? alpha : 0.0f;
+        if constexpr (COUNT) c_valid += __popcll(__ballot(valid[u]));
       }
 #pragma unroll
       for (int u = 0; u < FWD_GROUP; ++u) {
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
         // (carrying this position in the staged record's unused depth slot — one broadcast read wider, no scalar-to-vector move
         // per hit — measured slower: 75.5 -> 78.1 us at C3; three or four hits per walk step: 78.2 / 81.7 us)
         last = (valid[u] && !stop) ? (base - start) + (uint32_t)idx[u] + 1u : last;
+        if constexpr (COUNT) c_blended += __popcll(__ballot(valid[u] && !stop));
         Tr = stop ? -fabsf(Tr) : test_T;
       }
     }
@@ -300,6 +309,12 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
     out_color[pix] = C0 + Tfin * bg[0];
     out_color[plane + pix] = C1 + Tfin * bg[1];
     out_color[2 * plane + pix] = C2 + Tfin * bg[2];
+  }
+  if constexpr (COUNT) {
+    if (lane == 0 && counters) {
+      atomicAdd(counters + 8, c_groups); atomicAdd(counters + 9, c_hits); atomicAdd(counters + 10, c_steps);
+      atomicAdd(counters + 11, c_valid); atomicAdd(counters + 12, c_blended); atomicAdd(counters + 13, 1ull);
+    }
   }
   GS_PROBE_STORE((uint32_t)tile * 4u + (uint32_t)wave, pr_t0, GS_PROBE_CLOCK(), pr_hits, 0ull, pr_groups, (unsigned long long)(end - start),
                  (unsigned long long)gs_physical_cu(), pr_walk);
@@ -671,7 +686,7 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
                             uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, const uint32_t* part_first,
                             uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta, unsigned long long* hitmask,
-                            uint32_t max_chunks, uint32_t* qmax) {
+                            uint32_t max_chunks, uint32_t* qmax, unsigned long long* counters) {
   // equal-weight workgroups of 4 (2) tiles while the whole frame is one resident round of at most one (two) workgroups per CU
   // (the count belongs to the device the launch goes to — the process's current one — not to whichever device was current
   // the first time: a process that drives two different GPUs gets each one's own; a device attribute read is host-only and cheap,
@@ -686,10 +701,11 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
     cus_of[dev] = cus = n;
   }
   const int per_wg = GS_FWD_TILES ? GS_FWD_TILES : (T <= 4 * cus ? 4 : (T <= 4 * cus * 2 ? 2 : 1));
-#define GS_FWD(N)                                                                                                                   \
-  hipLaunchKernelGGL((k_composite_fwd<N>), dim3((T + N - 1) / N), dim3(256 * N), 0, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, \
-                     out_color, final_T, n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax)
-  if (per_wg == 4) GS_FWD(4); else if (per_wg == 2) GS_FWD(2); else GS_FWD(1);
+#define GS_FWD(N, CNT)                                                                                                              \
+  hipLaunchKernelGGL((k_composite_fwd<N, CNT>), dim3((T + N - 1) / N), dim3(256 * N), 0, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, \
+                     out_color, final_T, n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax, counters)
+  if (counters) { if (per_wg == 4) GS_FWD(4, true); else if (per_wg == 2) GS_FWD(2, true); else GS_FWD(1, true); }
+  else { if (per_wg == 4) GS_FWD(4, false); else if (per_wg == 2) GS_FWD(2, false); else GS_FWD(1, false); }
 #undef GS_FWD
   return 0;
 }

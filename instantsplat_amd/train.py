@@ -51,6 +51,7 @@ class TrainState:
     last_loss: Optional[torch.Tensor] = None
     _trainer: object = None
     _loss_slot: Optional[torch.Tensor] = None
+    _prepared: object = None   # (saved host state, arguments) of the NEXT iteration's host half, see _fused_synced_iteration
 
 
 def setup_training_from_init(scene, device, opt: OptimizationParams | None = None, pipe: PipelineParams | None = None,
@@ -160,15 +161,51 @@ def _optimizer_step(st: TrainState):
             st.gaussians.optimizer.zero_grad(set_to_none=True)
 
 
+def _host_state(st: TrainState, tr):
+    """Everything the host half of an iteration (FusedTrainer.prepare) changes"""
+    return (st.iteration, list(st.viewpoint_stack), st.rng.getstate(), st.gaussians.active_sh_degree,
+            [st.gaussians.optimizer.state[p]["step"] for p in tr.params], [g["lr"] for g in st.gaussians.optimizer.param_groups])
+
+
+def _restore_host_state(st: TrainState, tr, saved):
+    st.iteration, st.viewpoint_stack, st.gaussians.active_sh_degree = saved[0], list(saved[1]), saved[3]
+    st.rng.setstate(saved[2])
+    for p, s0 in zip(tr.params, saved[4]):
+        st.gaussians.optimizer.state[p]["step"] = s0
+    for g, lr in zip(st.gaussians.optimizer.param_groups, saved[5]):
+        g["lr"] = lr
+
+
+def cancel_prepared(st: TrainState):
+    """The synced one-call loop runs the host half of iteration t + 1 while the device works on iteration t.  Whoever takes
+    the state elsewhere (the autograd path, RunAhead, a checkpoint, a test reading st.iteration) first takes that half back."""
+    pre = getattr(st, "_prepared", None)
+    if pre is not None:
+        st._prepared = None
+        _restore_host_state(st, st._trainer, pre[0])
+
+
+def release_trainer(st: TrainState):
+    """Leave the synced one-call loop: take back the prepared half iteration and close the handle (one handle at a time writes
+    the parameters, include/mi355gs.h)."""
+    cancel_prepared(st)
+    if getattr(st, "_trainer", None) is not None:
+        st._trainer.close()
+        st._trainer = None
+
+
 def _fused_synced_iteration(st: TrainState):
     """The reference's loop shape — loss read back on the host every iteration — on the one-call fused step: the WHOLE
     iteration is enqueued (forward, backward, optimizer), loss and instance count come back in ONE read-back.  The optimizer
     launch carries a device-side commit gate (it writes nothing when the frame's instance count exceeded the buffers,
-    csrc/trainer.hip), so the host does not have to see the count before the update is enqueued — the GPU never idles waiting
-    for the host between backward and Adam — and an iteration that did overflow is simply redone on the exact-sizing
-    autograd path: parameters and moments are still the ones it started from."""
+    csrc/trainer.hip), so the host does not have to see the count before the update is enqueued, and an iteration that did
+    overflow is simply redone on the exact-sizing autograd path: parameters and moments are still the ones it started from.
+    While the device works on iteration t the host runs the host half of iteration t + 1 (LR schedule, view sampling, step
+    counts, argument marshalling: FusedTrainer.prepare) — results cannot depend on when that happens, the blocking read-back of
+    every iteration stays (train.py:188), and `cancel_prepared` takes the half iteration back when the loop is left."""
     tr = getattr(st, "_trainer", None)
     if tr is None:
+        st._prepared = None
         with torch.no_grad():
             for cam in st.cameras:  # exact instance counts of every view size the fixed buffers
                 with binning_hint(("train", cam.uid)):
@@ -180,24 +217,30 @@ def _fused_synced_iteration(st: TrainState):
         # could hide an overflow of a few instances): the iteration's read-back is a wait for the stream, not a copy
         st._host_words = torch.zeros(2, dtype=torch.int32, pin_memory=(tr.dev.type == "cuda"))
         st._loss_slot = st._host_words[0:1].view(torch.float32)
-    saved = (st.iteration, list(st.viewpoint_stack), st.rng.getstate(), st.gaussians.active_sh_degree,
-             [st.gaussians.optimizer.state[p]["step"] for p in tr.params], [g["lr"] for g in st.gaussians.optimizer.param_groups])
-    cam = tr.step(st._loss_slot, defer_optimizer=False, verify_async=False, count_out=st._host_words[1:2])
+    pre = getattr(st, "_prepared", None)
+    if pre is None:
+        saved = _host_state(st, tr)
+        args = tr.prepare()
+    else:
+        saved, args = pre
+        st._prepared = None
+    cam = tr.launch(args, st._loss_slot, st._host_words[1:2])
+    nxt = None
+    if args["it"] < st.opt.iterations:        # (the run's last iteration has no successor)
+        nxt_saved = _host_state(st, tr)
+        nxt = (nxt_saved, tr.prepare())       # host half of the next iteration, under the device's work on this one
     if tr.dev.type == "cuda":
         torch.cuda.current_stream(tr.dev).synchronize()
     loss, r = float(st._loss_slot[0]), int(st._host_words[1])
     BinningPolicy.known[("train", cam.uid)] = int(r)
     if r > tr.capacity:   # dropped instances (the device left the update out): redo exactly, and grow the buffers for the next iterations
-        st.iteration, st.viewpoint_stack, st.gaussians.active_sh_degree = saved[0], saved[1], saved[3]
-        st.rng.setstate(saved[2])
-        for p, s0 in zip(tr.params, saved[4]):
-            st.gaussians.optimizer.state[p]["step"] = s0
-        for g, lr in zip(st.gaussians.optimizer.param_groups, saved[5]):
-            g["lr"] = lr
+        _restore_host_state(st, tr, saved)
         tr.close()
         st._trainer = None
         return None
+    st._prepared = nxt
     if r * 1.2 + 1024 > tr.capacity:
+        cancel_prepared(st)
         tr.close()
         st._trainer = None
     return loss
@@ -211,6 +254,7 @@ def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = T
         if out is not None:
             st.last_loss = out
             return out
+    cancel_prepared(st)
     loss = _forward_backward_step(st, fused_loss)
     out = loss.item() if sync_loss else loss
     _optimizer_step(st)
@@ -305,13 +349,11 @@ class FusedTrainer:
 
     COUNT_RING = 256
 
-    def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True, record_event: bool = True,
-             count_out: torch.Tensor | None = None):
-        """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1]).
-        defer_optimizer: stop after backward; `apply_optimizer()` then commits the update (or the caller discards it).
-        record_event=False: the caller synchronises with the stream itself before it polls the counts (RunAhead's read-back of
-        the loss ring does), so no event is recorded behind the step.
-        count_out (with verify_async=False): where the step's instance count goes instead of the handle's device word."""
+    def prepare(self):
+        """Host half of an iteration (reference train.py:140-157 + the optimizer's bookkeeping): advances the iteration counter,
+        the LR schedule, the SH degree, the view sampling and the optimizer's step counts, and returns the ready-made arguments
+        of the library call.  Nothing is enqueued: `launch()` does that — possibly later, while the host half of the NEXT
+        iteration overlaps it (see _fused_synced_iteration)."""
         st = self.st
         st.iteration += 1
         it, g, opt = st.iteration, st.gaussians, st.opt
@@ -330,6 +372,28 @@ class FusedTrainer:
             steps.append(max(s["step"], 1))
         b1, b2 = grp[0]["betas"]
         F7, I7 = ctypes.c_float * 7, ctypes.c_int32 * 7
+        return dict(it=it, cam=cam, bg=bg, do_opt=do_opt, sh=int(g.active_sh_degree), lr=F7(*[float(x["lr"]) for x in grp]), steps=I7(*steps),
+                    b1=float(b1), b2=float(b2), eps=float(grp[0]["eps"]), lam=float(opt.lambda_dssim))
+
+    def launch(self, a, loss_slot: torch.Tensor, count_out: torch.Tensor, defer_optimizer: bool = False):
+        cam = a["cam"]
+        with _lib.on_device(self.dev):
+            _lib.check(_lib.lib().mi355gs_trainer_step(
+                ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), a["sh"], _lib.ptr(self.st.gt_images[cam.uid]),
+                _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(a["bg"]),
+                a["lr"], a["steps"], a["b1"], a["b2"], a["eps"], a["lam"],
+                1 if (a["do_opt"] and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(count_out)), "trainer_step")
+        self._pending_opt = (a["lr"], a["steps"], a["b1"], a["b2"], a["eps"]) if a["do_opt"] else None
+        return cam
+
+    def step(self, loss_slot: torch.Tensor, defer_optimizer: bool = False, verify_async: bool = True, record_event: bool = True,
+             count_out: torch.Tensor | None = None):
+        """One iteration of reference train.py:140-211; the loss lands in `loss_slot` (device float[1]).
+        defer_optimizer: stop after backward; `apply_optimizer()` then commits the update (or the caller discards it).
+        record_event=False: the caller synchronises with the stream itself before it polls the counts (RunAhead's read-back of
+        the loss ring does), so no event is recorded behind the step.
+        count_out (with verify_async=False): where the step's instance count goes instead of the handle's device word."""
+        a = self.prepare()
         if verify_async:
             if len(BinningPolicy.pending) >= self.COUNT_RING:
                 raise RuntimeError("more unverified frames than count slots: call BinningPolicy.poll() at least every "
@@ -339,19 +403,12 @@ class FusedTrainer:
             count_out = self._count_ring[k:k + 1]
         elif count_out is None:
             count_out = self.num_rendered
-        with _lib.on_device(self.dev):
-            _lib.check(_lib.lib().mi355gs_trainer_step(
-                ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), int(cam.uid), int(g.active_sh_degree),
-                _lib.ptr(st.gt_images[cam.uid]),
-                _lib.ptr(cam.projection_matrix), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), _lib.ptr(bg),
-                F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"]), float(opt.lambda_dssim),
-                1 if (do_opt and not defer_optimizer) else 0, _lib.ptr(loss_slot), _lib.ptr(count_out)), "trainer_step")
-        self._pending_opt = (F7(*[float(x["lr"]) for x in grp]), I7(*steps), float(b1), float(b2), float(grp[0]["eps"])) if do_opt else None
+        cam = self.launch(a, loss_slot, count_out, defer_optimizer)
         if not verify_async:
             return cam
         # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy): the count is in its
         # pinned slot once the event recorded behind the step has completed
-        with binning_hint(("train", cam.uid), tag=it):
+        with binning_hint(("train", cam.uid), tag=a["it"]):
             BinningPolicy.defer(count_out, self.capacity, self.dev, event=record_event)
         return cam
 
@@ -380,6 +437,7 @@ class RunAhead:
     def __init__(self, st: TrainState, window: int = 10, fused_loss: bool = True, fused_step: bool = True):
         self.st, self.window, self.fused = st, window, fused_loss
         self.fused_step, self.trainer = fused_step, None
+        cancel_prepared(st)
         dev = st.background.device
         self.ring = torch.zeros(window, dtype=torch.float32, device=dev)
         self.ema = 0.0
@@ -569,12 +627,14 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
                 print(f"[iter {i + 1}] loss {last:.6f}")
         it = i + 1
         if it in saving or it in checkpoints:
+            cancel_prepared(st)
             if ra is not None:
                 ra.flush()   # the window up to here is verified (and replayed if a frame overflowed) before anything is written
             if it in saving:
                 _save_outputs(st, it, model_path, colmap_ids)
             if it in checkpoints:
                 torch.save((st.gaussians.capture(), it), os.path.join(model_path, f"chkpnt{it}.pth"))
+    cancel_prepared(st)
     if ra is not None:
         ra.flush()
         last = st.last_loss

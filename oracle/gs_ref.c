@@ -9,6 +9,15 @@
  * SURVEY.md Appendix A.1-A.5 and is cross-checked against oracle/raster_torch.py (autograd, fp64)
  * in tests/test_oracle.py.  No golden output of the CUDA operator exists: "parity unpinned".
  *
+ * One point where the published operator may differ and that cannot be settled here: dL/dscale under scale_modifier != 1.
+ * This file (and the HIP kernel, which agrees with it: tests/edge_cases.py::check_scale_modifier_and_init_opacity at mod = 1.7)
+ * returns the true derivative, d/dscale of Sigma(mod * scale) = mod x the derivative with respect to the modified scale
+ * (the `c->mod *` factor at the `gs[k] =` line below; SURVEY.md A.4-5 describes upstream that way).  Two independent
+ * recollections of upstream's computeCov3D backward (`dL_dscale->x = glm::dot(Rt[0], dL_dMt[0])`, with `s = mod * scale` formed
+ * earlier) have NO such factor, i.e. upstream would return dL/d(mod * scale).  At mod = 1 — the only value the reference ever
+ * trains with (gaussian_renderer/__init__.py:29, scaling_modifier=1.0; viewers change it for rendering only) — the two are the
+ * same number; for mod != 1 the gradient with respect to scales is UNPINNED in both directions.
+ *
  * Compiled twice (oracle/Makefile): -DGSREF_DOUBLE=0 -> symbols *_f32, =1 -> *_f64.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library.
  */

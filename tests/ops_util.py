@@ -558,6 +558,55 @@ def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=Fa
         BinningPolicy.reset("exact")
 
 
+def check_synced_one_call_loop_can_be_left_and_reentered(dev, Wm=12, W=32):
+    """The synced one-call loop runs the host half of iteration t + 1 under the device's work on iteration t.  Leaving it —
+    for the autograd path, for RunAhead, for a look at the state — must take that half back: interleaving the three loops gives
+    the trajectory of the plain reference-shaped loop, and st.iteration / the optimizer's step counts read right in between."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import RunAhead, cancel_prepared, release_trainer, setup_training, train_iteration
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=23)
+    mk = lambda: generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=14, pp_optimizer=True, optim_pose=True)))
+    cuda = torch.device(dev).type == "cuda"
+    try:
+        BinningPolicy.reset("exact")
+        a = mk()
+        for _ in range(14):
+            train_iteration(a)
+        b = mk()
+        for _ in range(3):
+            train_iteration(b, fused_step=True)
+        assert b._prepared is not None and b.iteration == 4            # the next iteration's host half has run ...
+        cancel_prepared(b)
+        assert b._prepared is None and b.iteration == 3                # ... and is taken back
+        assert [b.gaussians.optimizer.state[p]["step"] for p in b._trainer.params] == [3] * 7
+        train_iteration(b)                                             # autograd path (it cancels by itself)
+        train_iteration(b, fused_step=True)
+        train_iteration(b, fused_step=True)
+        assert b.iteration == 7
+        train_iteration(b)
+        assert b.iteration == 7
+        release_trainer(b)
+        ra = RunAhead(b, window=3)
+        for _ in range(3):
+            ra.step()
+        ra.flush()
+        if ra.trainer is not None:
+            ra.trainer.close()
+        BinningPolicy.reset("exact")
+        assert b.iteration == 10
+        for _ in range(4):                                             # ... to the run's last iteration: no half iteration is left over
+            train_iteration(b, fused_step=True)
+        assert b.iteration == 14 and b._prepared is None
+        assert [b.gaussians.optimizer.state[p]["step"] for p in b._trainer.params] == [13] * 7   # train.py:209: the last step is skipped
+        release_trainer(b)
+        for n in TRAIN_TENSORS:
+            bound("leave_and_reenter/param" + n, rel_l2(getattr(b.gaussians, n), getattr(a.gaussians, n)), 1e-3 if cuda else 1e-5)
+    finally:
+        BinningPolicy.reset("exact")
+
+
 def check_commit_gate_leaves_an_overflowed_step_uncommitted(dev, Wm=12, W=32):
     """mi355gs_trainer_step(do_optimizer_step = 1) enqueues the optimizer before the host has seen the frame's instance count:
     the Adam launch itself must write NOTHING — parameters, both moments — when the count exceeded the capacity of the instance
@@ -1073,7 +1122,8 @@ def check_trainer_keeps_its_unit_length_knob(dev, Wm=14, W=48, H=32):
                 L.mi355gs_tune_min_units(old)    # the handle must not notice
             losses += [train_iteration(st, fused_step=True) for _ in range(4)]
             res[change] = (losses, {n: getattr(st.gaussians, n).detach().cpu().clone() for n in names})
-            st._trainer.close()
+            from instantsplat_amd.train import release_trainer
+            release_trainer(st)
             BinningPolicy.reset("exact")
         for a_, b_ in zip(res[False][0], res[True][0]):
             bound("trainer_knob/loss", abs(a_ - b_) / max(abs(a_), 1e-6), 1e-3 if cuda else 0.0)

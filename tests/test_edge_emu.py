@@ -218,3 +218,12 @@ def test_pending_frames_are_verified_with_their_own_count(emu):
 
 def test_speculative_stage2_overflow_is_rerendered(emu):
     edge_cases.check_speculative_stage2_overflow_is_rerendered(emu)
+
+
+def test_more_tiles_than_scan_threads(emu):
+    """A frame with more tiles than the tile scan has threads (1140 > 1024, two tiles per thread with the last threads short):
+    the staged form of k_scan_tiles — counts fetched once into LDS, every pass reads them there.  Image, radii and every gradient
+    against the C oracle, and the per-tile lists exactly."""
+    from tests.util import assert_raster_parity, run_blob_case
+    assert_raster_parity(run_blob_case(emu, 700, 608, 480, 1, scale_mean=0.08))
+    edge_cases.check_tile_lists_against_oracle(emu, 500, W=608, H=480)

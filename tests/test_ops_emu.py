@@ -72,6 +72,10 @@ def test_fused_synced_loop_equals_autograd_loop(emu, overflow):
     ops_util.check_fused_synced_loop_equals_autograd_loop(emu, force_overflow=overflow)
 
 
+def test_synced_one_call_loop_can_be_left_and_reentered(emu):
+    ops_util.check_synced_one_call_loop_can_be_left_and_reentered(emu)
+
+
 def test_commit_gate_leaves_an_overflowed_step_uncommitted(emu):
     ops_util.check_commit_gate_leaves_an_overflowed_step_uncommitted(emu)
 

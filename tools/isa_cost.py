@@ -87,7 +87,60 @@ def bwd_model(path):
     print(json.dumps(out))
 
 
+def fwd_model(path):
+    """Per-part costs of the forward composite kernel (k_composite_fwd<4, false>: the instantiation a 512^2 frame runs), from its
+    loop structure: "step" = the walk loop's body (the one block that holds the v_exp_f32 of its two hits and branches back to
+    itself), "group" = the rest of the loop over 64-record groups that contains it (staging stores, the four-quadrant-free cull of
+    this wave's quadrant, prefetch, boundary store, loop control; priced as if every conditional part ran, which it does for all
+    but the last group of a tile), "wave" = everything outside (prologue: unit table, first gather; epilogue: remaining boundary
+    records, quadrant maximum, pixel stores)."""
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "k_composite_fwdILi4ELb0" in l and ":" in l and not l.startswith("\t"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    blocks, cur, lab = [], [], "entry"
+    for l in lines[start:end + 1]:
+        t = l.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            blocks.append((lab, cur)); cur, lab = [], m.group(1)
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        cur.append(t)
+        if t.split()[0].startswith("s_cbranch") or t.split()[0] == "s_branch":
+            blocks.append((lab, cur)); cur, lab = [], lab + "'"
+    blocks.append((lab, cur))
+    index = {}
+    for i, (lb, _) in enumerate(blocks):
+        index.setdefault(lb, i)
+    walk = next(i for i, (lb, b) in enumerate(blocks) if any(t.startswith("v_exp_f32") for t in b) and b and b[-1].split()[-1] == lb)
+    # the group loop: the widest backward branch around the walk block (the walk's own re-entry loop sits inside it)
+    best = None
+    for i, (lb, b) in enumerate(blocks):
+        if i <= walk or not b or not b[-1].split()[0].startswith(("s_branch", "s_cbranch")):
+            continue
+        tgt = index.get(b[-1].split()[-1])
+        if tgt is not None and tgt < walk and (best is None or i - tgt > best[1] - best[0]):
+            best = (tgt, i)
+    g0, g1 = best
+    parts = {k: [0, 0] for k in ("step", "group", "wave")}
+    for i, (lb, b) in enumerate(blocks):
+        v = [t for t in b if t.startswith("v_")]
+        k = "step" if i == walk else ("group" if g0 <= i <= g1 else "wave")
+        parts[k][0] += len(v); parts[k][1] += sum(cost(t.split()[0], t)[0] for t in v)
+    import json
+    print(json.dumps({"INS": {k: parts[k][0] for k in parts}, "CYC": {k: parts[k][1] for k in parts}, "hits_per_step": 2,
+                      "source": "hipcc -S of instantsplat_amd/csrc/composite.hip, k_composite_fwd<4, false>; tools/isa_cost.py --fwd-model"}))
+
+
 def main():
+    if sys.argv[1] == "--fwd-model":
+        try:
+            return fwd_model(sys.argv[2])
+        except (StopIteration, ValueError, ZeroDivisionError, IndexError, OSError, TypeError) as e:
+            sys.stderr.write("isa_cost.py --fwd-model: the walk / group loops were not recognised in %s (%s: %s); no table written\n"
+                             % (sys.argv[2], type(e).__name__, e))
+            sys.exit(3)
     if sys.argv[1] == "--bwd-model":
         try:   # pattern matching on compiler output: a different LLVM or a variant build may not have these blocks
             return bwd_model(sys.argv[2])

@@ -40,7 +40,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 for _ in range(N):
     for cam in st.cameras:
         fwd_bwd(cam)
-ctr = torch.zeros(8, dtype=torch.int64, device=dev)
+ctr = torch.zeros(16, dtype=torch.int64, device=dev)
 _lib.check(L.mi355gs_profile_work_counters(_lib.ptr(ctr)), "work_counters")
 for cam in st.cameras:
     fwd_bwd(cam)
@@ -52,6 +52,13 @@ INS, CYC = tab["INS"], tab["CYC"]
 inits = max(steps - quads_valid / 4.0, 0.0)
 ins = steps * INS["step"] + quads * INS["quad"] + quads_valid * INS["quad_valid"] + reduced * INS["reduce"] + inits * INS["init"] + waves * INS["wave"]
 cyc = steps * CYC["step"] + quads * CYC["quad"] + quads_valid * CYC["quad_valid"] + reduced * CYC["reduce"] + inits * CYC["init"] + waves * CYC["wave"]
+groups, hits, fsteps, fvalid, fblended, fwaves = [float(x) / len(st.cameras) for x in ctr.tolist()[8:14]]
+ftab = json.load(open(os.path.join(ROOT, "instantsplat_amd", "lib", "fwd_issue_model.json")))
+print(json.dumps({"kernel": "k_composite_fwd<4, false>", "frames": "C3 after 200 iterations, frozen; mean over the 3 views", "groups": groups, "hits": hits,
+                  "walk_steps": fsteps, "valid_pairs": fvalid, "quadrant_waves": fwaves, "useful_lane_frac": fvalid / (64.0 * hits),
+                  "model_valu_wave_instructions_per_launch": fsteps * ftab["INS"]["step"] + groups * ftab["INS"]["group"] + fwaves * ftab["INS"]["wave"],
+                  "model_valu_issue_cycles_per_launch": fsteps * ftab["CYC"]["step"] + groups * ftab["CYC"]["group"] + fwaves * ftab["CYC"]["wave"],
+                  "compare_with": "mean_SQ_INSTS_VALU of `k_composite_fwd<4; false>` in the PMC csv of this command"}))
 print(json.dumps({"frames": "C3 after 200 iterations, frozen; mean over the 3 views", "steps": steps, "quadrant_bodies": quads,
                   "quadrant_bodies_with_valid_lanes": quads_valid, "reductions": reduced, "waves_with_work": waves,
                   "model_valu_wave_instructions_per_launch": ins, "model_valu_issue_cycles_per_launch": cyc,
