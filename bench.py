@@ -321,6 +321,8 @@ def main():
     # instruction, packed / DPP / compare / select / min-max 4, transcendental and v_permlane*_swap 8).
     compute, fwd_compute = None, None
     if not emulated:
+        train_iteration(stp, fused_step=True)   # (re-creates the trainer handle: its exact-count renders are not the step's launches)
+        dev_sync()
         ctr = torch.zeros(16, dtype=torch.int64, device=dev)
         _lib.check(L.mi355gs_profile_work_counters(_lib.ptr(ctr)), "profile_work_counters")
         try:

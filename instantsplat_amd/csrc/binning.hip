@@ -99,12 +99,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
   if (seg_first) {
     // Backward units (common.h): the unit length of this frame from its true instance count, then the first unit of every tile
     // = exclusive scan of ceil(count / unit length) (same two-level scan as below)
-    const uint32_t chunks = 1u << gs_unit_level_for((long long)total, (long long)min_units);
+    const uint32_t level = (uint32_t)gs_unit_level_for((long long)total, (long long)min_units);
+    const uint32_t chunks = 1u << level;
     const uint32_t seg_len = chunks * GS_SEG;
+    // seg_len is a power of two: units and "short last unit" by shift and mask (four 32-bit divisions per tile otherwise, on a
+    // kernel that is one workgroup's latency chain)
+    static_assert((GS_SEG & (GS_SEG - 1)) == 0, "GS_SEG must be a power of two");
+    const uint32_t seg_shift = level + (uint32_t)__builtin_ctz(GS_SEG), seg_mask = seg_len - 1u;
+    auto units_of = [&](uint32_t c) { return (c + seg_mask) >> seg_shift; };
+    auto short_of = [&](uint32_t c) { return (uint32_t)((c & seg_mask) != 0u); };
     // ... and, in the same pass, the prefix of "this tile's last unit is a short one" (part_first): the backward launches
     // the full-length units first and the short ones last, where they shorten the tail of the kernel (composite.hip)
     uint32_t lseg = 0, lpart = 0;
-    for (int i = lo; i < hi; ++i) { lseg += (cnt(i) + seg_len - 1) / seg_len; lpart += (cnt(i) % seg_len) != 0u; }
+    for (int i = lo; i < hi; ++i) { lseg += units_of(cnt(i)); lpart += short_of(cnt(i)); }
     const uint32_t iseg = gs_wave_scan_incl_u32(lseg), ipart = gs_wave_scan_incl_u32(lpart);
     __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
     __shared__ uint32_t part_wave[SCAN_THREADS / GS_WAVE];
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     uint32_t srun = soff + iseg - lseg, prun = poff + ipart - lpart;
     for (int i = lo; i < hi; ++i) {
       seg_first[i] = srun; part_first[i] = prun;
-      srun += (cnt(i) + seg_len - 1) / seg_len;
-      prun += (cnt(i) % seg_len) != 0u;
+      srun += units_of(cnt(i));
+      prun += short_of(cnt(i));
     }
     if (tid == 0) { part_first[T] = ptot; meta[3] = ptot; }
     if (tid == 0) { seg_first[T] = stot; meta[1] = stot; meta[2] = chunks; }
@@ -202,16 +209,23 @@ constexpr int BIN_PER_THREAD = BIN_CHUNK / 256;
 // preloaded), or -1 on the wide path where another thread's Gaussian is walked.  own[j] = rectangle of Gaussian
 // lo + tid + 256 j, preloaded by the caller ((0,0,0,0) past the end): the kernels that use this run in one resident round,
 // every workgroup in the same phase, and a load issued inside the loop is a round trip to L2/HBM nobody covers.
+// The queue holds the rectangle next to the index: at 1080p with a million Gaussians a third of them are "wide" (3 x 3 tiles
+// and up), a workgroup's 16 rows then take ~10 queue rounds each, and a round that began with a dependent global load of the
+// rectangle (plus two integer divisions per instance) made count and scatter latency chains (25 / 77 us at C4).
 template <class F>
 __device__ __forceinline__ void for_each_instance(int lo, int hi, const uint2 (&own)[BIN_PER_THREAD], const uint2* __restrict__ rects,
-                                                  uint32_t* s_wide, uint32_t* s_nwide, F&& f) {
+                                                  uint32_t* s_wide, uint2* s_wide_rect, uint32_t* s_nwide, F&& f) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int j = 0; j < BIN_PER_THREAD; ++j) {
     const int i = lo + tid + 256 * j;
     int x0, y0, x1, y1;
     if (i >= hi || !unpack_rect(own[j], x0, y0, x1, y1)) continue;
-    if ((x1 - x0) * (y1 - y0) > BIN_WIDE) { s_wide[atomicAdd(s_nwide, 1u)] = (uint32_t)i; continue; }
+    if ((x1 - x0) * (y1 - y0) > BIN_WIDE) {
+      const uint32_t slot = atomicAdd(s_nwide, 1u);
+      s_wide[slot] = (uint32_t)i; s_wide_rect[slot] = own[j];
+      continue;
+    }
     for (int y = y0; y < y1; ++y)
       for (int x = x0; x < x1; ++x) f(i, j, x, y);
   }
@@ -220,9 +234,16 @@ __device__ __forceinline__ void for_each_instance(int lo, int hi, const uint2 (&
   for (int q = tid >> 4; q < nwide; q += 16) {  // one 16-lane row per queued Gaussian
     const int i = (int)s_wide[q];
     int x0, y0, x1, y1;
-    unpack_rect(rects[i], x0, y0, x1, y1);
+    unpack_rect(s_wide_rect[q], x0, y0, x1, y1);
     const int w = x1 - x0, n = w * (y1 - y0);
-    for (int j = tid & 15; j < n; j += 16) f(i, -1, x0 + j % w, y0 + j / w);
+    // row-major walk without a division per instance: (column, row) of position j advance by (16 mod w, 16 div w) per step
+    const int dq = 16 / w, dr = 16 - dq * w;
+    int j = tid & 15, row = j / w, col = j - row * w;
+    for (; j < n; j += 16) {
+      f(i, -1, x0 + col, y0 + row);
+      col += dr; row += dq;
+      if (col >= w) { col -= w; row += 1; }
+    }
   }
 }
 
@@ -230,6 +251,7 @@ __global__ __launch_bounds__(256) void k_count_tiles_lds(int P, int T, int gx, c
                                                           uint32_t* __restrict__ tile_count) {
   HIP_DYNAMIC_SHARED(uint32_t, s_bins)
   __shared__ uint32_t s_wide[BIN_CHUNK];
+  __shared__ uint2 s_wide_rect[BIN_CHUNK];
   __shared__ uint32_t s_nwide;
   const int tid = threadIdx.x;
   const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(256) void k_count_tiles_lds(int P, int T, int gx, c
   for (int t = tid; t < T; t += 256) s_bins[t] = 0;
   if (tid == 0) s_nwide = 0;
   __syncthreads();
-  for_each_instance(lo, hi, own, rects, s_wide, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
+  for_each_instance(lo, hi, own, rects, s_wide, s_wide_rect, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
   __syncthreads();
   for (int t = tid; t < T; t += 256) {
     const uint32_t c = s_bins[t];
@@ -252,6 +274,7 @@ __global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const
                                                       uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, uint32_t capacity) {
   HIP_DYNAMIC_SHARED(uint32_t, s_bins)
   __shared__ uint32_t s_wide[BIN_CHUNK];
+  __shared__ uint2 s_wide_rect[BIN_CHUNK];
   __shared__ uint32_t s_nwide;
   const int tid = threadIdx.x;
   const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const
   for (int t = tid; t < T; t += 256) s_bins[t] = 0;
   if (tid == 0) s_nwide = 0;
   __syncthreads();
-  for_each_instance(lo, hi, own, rects, s_wide, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
+  for_each_instance(lo, hi, own, rects, s_wide, s_wide_rect, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
   __syncthreads();
   // Private counts -> first slot of this workgroup's range in each touched tile.  Four returning atomics per thread are in
   // flight before the first result is consumed (one at a time they were four dependent trips to the L2).
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const
   }
   if (tid == 0) s_nwide = 0;
   __syncthreads();
-  for_each_instance(lo, hi, own, rects, s_wide, &s_nwide, [&](int i, int j, int x, int y) {
+  for_each_instance(lo, hi, own, rects, s_wide, s_wide_rect, &s_nwide, [&](int i, int j, int x, int y) {
     const uint32_t depth = j == 0 ? own_depth[0] : (j == 1 ? own_depth[BIN_PER_THREAD - 1] : __float_as_uint(recs[i].q2.w));
     const uint64_t key = ((uint64_t)depth << 32) | (uint32_t)i;
     const uint32_t pos = atomicAdd(&s_bins[y * gx + x], 1u);

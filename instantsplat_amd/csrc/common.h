@@ -53,7 +53,7 @@ constexpr int GS_UNIT_LEVELS = 4;
 // pick the kernel instantiation and to size buffers): lengthen the units while at least `min_units` of them remain.
 __host__ __device__ inline int gs_unit_level_for(long long instances, long long min_units) {
   int level = 0;
-  while (level + 1 < GS_UNIT_LEVELS && instances / ((long long)(2 * 64) << level) >= min_units) ++level;
+  while (level + 1 < GS_UNIT_LEVELS && (instances >> (7 + level)) >= min_units) ++level;   // instances / (2 * 64 << level), instances >= 0
   return level;
 }
 int gs_min_units();               // binning.hip: the mi355gs_tune_min_units knob (or the value a trainer handle pinned for its calls)

@@ -22,9 +22,9 @@ So the assertions are relative to what the fp32 oracle itself achieves against f
   * image: every value within 5e-3 of fp64; fraction of values off by more than 1e-4 at most FACTOR x the fp32 oracle's (floor 2e-4);
   * per-Gaussian gradient tensors: relative L2 against fp64 at most FACTOR x the fp32 oracle's (floor 1e-3), also with the 64
     worst Gaussians set aside (floor 1e-4).  FACTOR = 4 for the deterministic cases (blob-200k, and C3 / C4 at iteration 0: the
-    inputs are fixed, the result repeats exactly up to float-atomic order) and 8 for the trained states (which pairs flip is
-    luck there: the trained state itself differs from run to run; measured ratios over 30 repeated runs are 0.6 .. 2.3, with
-    ONE run of the 40-iteration case above 4).  Every measured ratio is printed (pytest -s) and recorded (GS_CALIBRATE=1).  A
+    inputs are fixed, the result repeats exactly up to float-atomic order); for the trained states (which pairs flip is luck
+    there: the trained state itself differs from run to run) 8 on whole tensors and 5 on the outlier-free statistics, from
+    the distribution over 30 repeated runs committed as profiles/r04_trained_state_ratio_distribution.txt (see the constants).  Every measured ratio is printed (pytest -s) and recorded (GS_CALIBRATE=1).  A
     wrong kernel is off by orders of magnitude, not by 4x;
   * pose gradients (sums over all Gaussians), loss: plain relative bounds.
 """
@@ -37,7 +37,13 @@ from tests.ops_util import bound
 pytestmark = pytest.mark.gpu
 OUTLIERS = 64
 FACTOR_FIXED_INPUTS = 4.0   # device error allowed, in units of the fp32 oracle's own error against fp64 (see the module docstring)
+# Trained states, from the distribution over 30 repeated runs of the C3 case and 6 of the C4 case on the round-4 tree
+# (profiles/r04_trained_state_ratio_distribution.txt, tools/trained_state_ratios.py; worst tensor and view of each run):
+#   whole gradient tensors      median 1.37, 90th percentile 1.9, max 5.75 (ONE run above 2.7: a single pair on a threshold)  -> 8
+#   without the 64 worst rows   median 1.39, 90th percentile 1.9, max 2.64                                                    -> 5
+#   image values off by > 1e-4  median 1.17, 90th percentile 1.8, max 2.39                                                    -> 5
 FACTOR_TRAINED_STATE = 8.0
+FACTOR_TRAINED_STATE_ROBUST = 5.0   # (~2x the largest of 30 runs: a red GPU tier on a rare run teaches nothing)
 
 
 def _grad_errors(a, b):
@@ -52,7 +58,13 @@ def _grad_errors(a, b):
     return full, float(keep.sum().sqrt()) / n
 
 
+def _robust(factor):
+    """the limit for the outlier-free statistics (image fraction, gradients without the 64 worst Gaussians)"""
+    return FACTOR_TRAINED_STATE_ROBUST if factor == FACTOR_TRAINED_STATE else factor
+
+
 def _check_image(pre, dut, c32, c64, factor):
+    factor = _robust(factor)
     d = (dut.detach().double().cpu() - c64).abs()
     d_ref = (c32.detach().double() - c64).abs()
     bound(pre + "image_max", float(d.max()), 5e-3)
@@ -68,7 +80,7 @@ def _check_grad(pre, k, dut, c32, c64, factor):
     print("%-46s device %.2e  fp32 oracle %.2e  ratio %.2f | without the %d worst: %.2e / %.2e  ratio %.2f (limit %g)" % (
         pre + "grad_" + k, full, full_ref, full / max(full_ref, 1e-30), OUTLIERS, robust, robust_ref, robust / max(robust_ref, 1e-30), factor))
     bound(pre + "grad_%s[fp32 oracle: %.1e]" % (k, full_ref), full, max(factor * full_ref, 1e-3))
-    bound(pre + "grad_%s_without_%d_worst[fp32 oracle: %.1e]" % (k, OUTLIERS, robust_ref), robust, max(factor * robust_ref, 1e-4))
+    bound(pre + "grad_%s_without_%d_worst[fp32 oracle: %.1e]" % (k, OUTLIERS, robust_ref), robust, max(_robust(factor) * robust_ref, 1e-4))
 
 
 @pytest.mark.parametrize("deg", [0, 3])
