@@ -270,7 +270,11 @@ int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float
  *   The handle is the only writer of the parameter and moment tensors while it is alive (it remembers across steps that
  *   a tensor without gradients has an all-zero first moment and then skips it; create a new handle after changing them).
  *   capacity: instance capacity of the binning buffers; *num_rendered (device-writable, see above) receives the true count of every
- *   step — a step with num_rendered > capacity dropped instances and must be discarded by the caller.
+ *   step — a step with num_rendered > capacity dropped instances and must be discarded by the caller.  With
+ *   do_optimizer_step = 1 the optimizer launch of such a step discards ITSELF: it reads the count and the capacity on the
+ *   device and writes no parameter and no moment when the count is larger (commit gate), so the whole iteration can be enqueued
+ *   before the host has seen the count and an overflowed one is simply repeated with larger buffers; its loss_out / gradients are
+ *   those of the truncated frame.  (mi355gs_trainer_optimizer_step, below, is the caller's own decision and is not gated.)
  *   lr[7], step[7] (1-based Adam step of each group): host arrays.  loss_out: device float[1].
  * ---------------------------------------------------------------------------------------------- */
 size_t mi355gs_trainer_workspace_bytes(int P, int W, int H, int V, int64_t capacity);
