@@ -215,6 +215,9 @@ def main():
     def dropin_loop(st_):      # the reference's loop on the drop-in operators: autograd, loss.item(), optimizer.step(), zero_grad
         return (lambda: train_iteration(st_)), (lambda: None), (lambda: None)
 
+    def dropin_loop_reference_loss(st_):   # ... with the loss formed exactly as train.py:171-176 does: torch l1_loss + fused_ssim + scalar arithmetic
+        return (lambda: train_iteration(st_, fused_loss=False)), (lambda: None), (lambda: None)
+
     def one_call_synced(st_):  # the same iteration behind ONE library call, loss read back every iteration
         return (lambda: train_iteration(st_, fused_step=True)), (lambda: None), (lambda: release_trainer(st_))
 
@@ -249,6 +252,7 @@ def main():
 
     # ---- the timed region.  NO instrumentation runs inside it (round 3 sampled kernel events there: ~1 % of ms_per_step).
     headline, st = measure(dropin_loop)
+    strict, _ = measure(dropin_loop_reference_loss)
     synced, _ = measure(one_call_synced)
     run_ahead, _ = measure(one_call_run_ahead)
     elapsed = headline["ms_per_step"] * 1e-3 * args.steps
@@ -522,12 +526,17 @@ def main():
             "timed_iterations": f"{headline['first_timed_iteration']} .. {headline['first_timed_iteration'] + n_blocks * args.steps - 1} of training "
                                 f"from seed {rank} (every loop on a fresh state fast-forwarded to iteration {PIN_ITER}); no instrumentation inside",
             "loops": {"dropin_reference_loop": headline,
+                      "dropin_reference_loop_torch_l1": dict(strict, what="the same loop with the loss formed exactly as train.py:171-176 writes it: "
+                                                                          "torch's own l1_loss (abs / mean), the drop-in fused_ssim, scalar arithmetic in "
+                                                                          "eager PyTorch — the headline takes (1-l)*L1 + l*(1-SSIM) as one node, "
+                                                                          "instantsplat_amd.fused_ssim.fused_l1_ssim_loss"),
                       "one_call_synced": dict(synced, what="mi355gs_trainer_step: the whole iteration behind one library call, loss and instance "
                                                            "count read back every iteration (device-side commit gate, host half of the next "
                                                            "iteration overlapped)"),
                       "one_call_run_ahead": dict(run_ahead, what="the same step without the per-iteration read-back (identical results; EMA "
                                                                  "evaluated every 10 iterations)", window_replays=sum(replays))},
             "iters_per_sec_dropin_reference_loop": headline["iters_per_sec"], "iters_per_sec_autograd_path": headline["iters_per_sec"],
+            "iters_per_sec_dropin_reference_loop_torch_l1": strict["iters_per_sec"],
             "iters_per_sec_with_per_iteration_loss_readback": synced["iters_per_sec"], "iters_per_sec_one_call_synced": synced["iters_per_sec"],
             "iters_per_sec_run_ahead": run_ahead["iters_per_sec"], "run_ahead_window_replays": sum(replays),
             "binding": _lib.BINDING,

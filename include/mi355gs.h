@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 6
+#define MI355GS_ABI_VERSION 7
 
 /* error codes */
 #define MI355GS_OK 0
@@ -74,14 +74,19 @@ size_t mi355gs_raster_binning_bytes(int64_t num_instances, int W, int H);
  *   viewmatrix[16], projmatrix[16]: row-vector convention, i.e. the transposed matrices the
  *     reference stores (scene/cameras.py:54-55) in flat memory; campos[3]
  *   radii[P] (int32, output); num_rendered: one int32 the device can write — device memory, or pinned host memory mapped into
- *   the device's address space, in which case the count reaches the host without a copy — receives the instance count R */
+ *   the device's address space, in which case the count reaches the host without a copy — receives the instance count R
+ *   visible (ABI v7, may be null): uint8[P] (a torch.bool tensor's memory), 1 where radii > 0 — the `visibility_filter` the
+ *   reference's render() computes with an elementwise kernel behind the operator (gaussian_renderer/__init__.py:142)
+ *   grad_scratch (ABI v7, may be null): the mi355gs_raster_grad_scratch_bytes(P) buffer this frame's backward will be given,
+ *   if the caller holds it already.  The projection kernel then clears it on its way (the per-tile counters are always
+ *   cleared that way: no memset is enqueued in front of a frame), and the backward is told so: grad_scratch_is_clear = 1 */
 int mi355gs_raster_forward_preprocess(
     void* stream, int P, int D, int M, int W, int H,
     const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tanfovx, float tanfovy, int prefiltered,
-    int32_t* radii, void* geom, void* tiles, int32_t* num_rendered, int debug);
+    int32_t* radii, void* geom, void* tiles, int32_t* num_rendered, uint8_t* visible, void* grad_scratch, int debug);
 
 /* Stage 2: scatter instances to their tiles, sort every tile's list front-to-back
  * (depth, then Gaussian index), alpha-composite.  capacity = instances `binning` was sized for.
@@ -96,7 +101,9 @@ int mi355gs_raster_forward_render(
  *   dL_dscales[P,3] dL_drotations[P,4] or dL_dcov3D[P,6]
  *   geom/tiles/binning/capacity/radii/out_color: exactly what the forward of this frame used and produced
  *   grad_scratch: mi355gs_raster_grad_scratch_bytes(P) bytes (per-Gaussian accumulators; the last 256 bytes, from
- *   mi355gs_raster_grad_gate_offset(P) on, are the eight gate flags mi355gs_posed_backward leaves for the optimizer) */
+ *   mi355gs_raster_grad_gate_offset(P) on, are the eight gate flags mi355gs_posed_backward leaves for the optimizer)
+ *   grad_scratch_is_clear (ABI v7): 1 = this frame's forward was given grad_scratch and nothing has written to it since
+ *   (the backward then enqueues no memset); 0 = the backward clears it itself.  A second backward of the same frame passes 0. */
 size_t mi355gs_raster_grad_scratch_bytes(int P);
 size_t mi355gs_raster_grad_gate_offset(int P);
 int mi355gs_raster_backward(
@@ -108,7 +115,7 @@ int mi355gs_raster_backward(
     const void* geom, void* tiles, const void* binning, int64_t capacity, const int32_t* radii,
     const float* out_color, const float* dL_dpix, void* grad_scratch,
     float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities,
-    float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int debug);
+    float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int grad_scratch_is_clear, int debug);
 
 /* Visibility test only — replaces diff_gaussian_rasterization._C.mark_visible
  * (GaussianRasterizer.markVisible; not called by the reference's scripts). present[P] uint8. */
@@ -202,11 +209,19 @@ int mi355gs_adam_step(void* stream, int64_t n, int row, float* param, const floa
  * gate[gate_index[t]] > 0 (device float[8] / host int32[ntensors], entries 0..7; `scratch` may then be null) and the
  * pass over all gradients is not launched.  mi355gs_posed_backward leaves such flags behind its gradient records
  * (group order xyz, f_dc, f_rest, opacity, scaling, rotation, pose); the caller vouches that grads[t] is exactly the
- * tensor that call wrote. */
+ * tensor that call wrote.
+ * live / seq (ABI v7, live may be null): a memory of gated-off tensors ACROSS calls, owned by the caller — device uint32[16],
+ * zeroed once, handed to every step of the same tensor list together with a sequence number that differs from call to call
+ * and is never 0.  A tensor whose gradient is all zero keeps its moments and takes the parameter step p - s * (m / denom),
+ * which is the identity wherever the first moment is zero; a call that scanned such a tensor completely without meeting a
+ * non-zero first moment says so in `live`, and later calls skip the tensor without reading anything (f_rest before the SH
+ * degree is raised: 4 B per element per step otherwise).  Any update of the tensor resets its entry.  The caller must zero
+ * `live` again if anything but these calls writes the moments. */
 int mi355gs_adam_multi_step(void* stream, int ntensors, const int64_t* numel, const int32_t* row, float* const* params,
                             const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                             const float* const* per_point_lr, const float* lr, float beta1, float beta2, float eps,
-                            const int32_t* step, float* scratch, const float* gate, const int32_t* gate_index);
+                            const int32_t* step, float* scratch, const float* gate, const int32_t* gate_index,
+                            uint32_t* live, uint32_t seq);
 
 /* ------------------------------------------------------------------------------------------------
  * InstantSplat camera-frame transform fused with the Gaussian activations
@@ -237,7 +252,8 @@ int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* ro
  *   log_scales[P,3], rotation[P,4] raw (w,x,y,z), pose[7] = (qw,qx,qy,qz,tx,ty,tz), all on the device.
  *   view_identity[16] / origin[3]: device constants (identity matrix, zeros) — InstantSplat hands the operator an
  *   identity view and a camera at the origin (reference :55-59); kept as arguments because the library owns no memory.
- *   Stage 2 of the forward is mi355gs_raster_forward_render, unchanged.
+ *   Stage 2 of the forward is mi355gs_raster_forward_render, unchanged.  visible / grad_scratch / grad_scratch_is_clear: as for
+ *   mi355gs_raster_forward_preprocess / _backward.
  *   backward: pose_scratch = device float[16 * ((P + 255) / 256) + 32]; d_f_rest may be null while D == 0 (the reference's
  *   gradient for it is all zero then); d_* receive dL/d(raw parameter), d_pose[7] dL/dpose.
  *   Also written: PerPointAdam's whole-tensor gate flags for these gradients, float[8] at grad_scratch +
@@ -248,14 +264,15 @@ int mi355gs_posed_forward_preprocess(void* stream, int P, int D, int W, int H, c
                                      const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,
                                      const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
                                      const float* origin, float tanfovx, float tanfovy, int32_t* radii, void* geom, void* tiles,
-                                     int32_t* num_rendered, int debug);
+                                     int32_t* num_rendered, uint8_t* visible, void* grad_scratch, int debug);
 int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float* bg, const float* xyz, const float* f_dc,
                            const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,
                            const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
                            const float* origin, float tanfovx, float tanfovy, const void* geom, void* tiles, const void* binning,
                            int64_t capacity, const int32_t* radii, const float* out_color, const float* dL_dpix,
                            void* grad_scratch, float* pose_scratch, float* d_xyz, float* d_means2D, float* d_f_dc, float* d_f_rest,
-                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int debug);
+                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int grad_scratch_is_clear,
+                           int debug);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole train iteration in one call

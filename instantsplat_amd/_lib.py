@@ -27,11 +27,11 @@ _SIGNATURES = {
     "mi355gs_raster_grad_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_raster_grad_gate_offset": (c_size_t, [c_int]),
     "mi355gs_raster_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P,
-                                                  _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, c_int]),
+                                                  _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_forward_render": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
                                         _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                        c_int]),
+                                        c_int, c_int]),
     "mi355gs_raster_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),
     "mi355gs_tune_min_units": (c_int, [c_int]),
@@ -47,13 +47,14 @@ _SIGNATURES = {
     "mi355gs_knn_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_knn_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "mi355gs_adam_step": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int]),
-    "mi355gs_adam_multi_step": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P]),
+    "mi355gs_adam_multi_step": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P, _P,
+                                        ctypes.c_uint32]),
     "mi355gs_pose_forward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_pose_backward": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_posed_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
-                                                 c_float, c_float, _P, _P, _P, _P, c_int]),
+                                                 c_float, c_float, _P, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_posed_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_float,
-                                       c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
+                                       c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int]),
     "mi355gs_trainer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
     "mi355gs_trainer_create": (c_void_p, [c_int, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_trainer_step": (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
@@ -65,7 +66,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 6   # include/mi355gs.h MI355GS_ABI_VERSION the signatures above were written for
+ABI_VERSION = 7   # include/mi355gs.h MI355GS_ABI_VERSION the signatures above were written for
 
 
 def _bind(path: str):

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float
 extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_t* numel, const int32_t* row, float* const* params,
                                        const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                                        const float* const* per_point_lr, const float* lr, float beta1, float beta2, float eps,
-                                       const int32_t* step, float* scratch, const float* gate, const int32_t* gate_index) {
+                                       const int32_t* step, float* scratch, const float* gate, const int32_t* gate_index,
+                                       uint32_t* live, uint32_t seq) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (ntensors < 0 || ntensors > MT_MAX || (gate && !gate_index)) return MI355GS_EINVAL;
@@ -226,6 +227,8 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
   if (!gate && g_fused.gate == scratch) {
     a.live = g_fused.adam_live; a.seq = g_fused.adam_seq;
     a.commit_count = g_fused.commit_count; a.commit_capacity = g_fused.commit_capacity;
+  } else if (live && seq != 0u) {
+    a.live = live; a.seq = seq;   // the caller's own memory of gated-off tensors (include/mi355gs.h)
   }
   if (gate && any_ungated) {
     // small leftovers (the pose table: 7 V floats) are gated inside the update kernel, by the one workgroup that owns them

@@ -5,7 +5,8 @@
 
 // launchers implemented next to their kernels
 int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*,
-                             const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*);
+                             const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*, uint8_t*,
+                             const GsPrologue&);
 int gs_launch_count_tiles(hipStream_t, int, int, int, const uint2*, uint32_t*);
 int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, int, int,
                              const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
@@ -100,7 +101,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
                                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
                                       const float* viewmatrix, const float* projmatrix, const float* campos, float tanfovx,
                                       float tanfovy, int prefiltered, int32_t* radii, void* geom, void* tiles,
-                                      int32_t* num_rendered, int debug) {
+                                      int32_t* num_rendered, uint8_t* visible, void* grad_scratch, int debug) {
   (void)prefiltered;  // as in the reference operator it only affects an internal consistency check
   hipStream_t stream = (hipStream_t)stream_;
   if (P < 0 || W <= 0 || H <= 0 || W > 65535 * GS_TILE || H > 65535 * GS_TILE || D < 0 || D > 3) return MI355GS_EINVAL;
@@ -114,11 +115,22 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   const TilesLayout tl(W, H);
   char* g = (char*)geom;
   char* t = (char*)tiles;
-  // count + cursor are adjacent
-  if (!g_fused.skip_memsets && hipMemsetAsync(t + tl.count, 0, tl.start - tl.count, stream) != hipSuccess) return MI355GS_ELAUNCH;
+  // The frame's accumulators are cleared by the projection kernel on its way (the one-call step hands over its own list): the
+  // per-tile count + cursor words (adjacent), and — if the caller already holds the buffer its backward will use — the moment
+  // records with the gate flags behind them.  No Gaussians, no kernel: memsets then.
+  GsPrologue pro = g_fused.prologue;
+  if (!g_fused.skip_memsets) {
+    pro = GsPrologue();
+    pro.tile_counters = (uint32_t*)(t + tl.count); pro.n_counters = (int)((tl.start - tl.count) / 4);
+    if (grad_scratch) { pro.grad_records = (float4*)grad_scratch; pro.n_vec = mi355gs_raster_grad_gate_offset(P) / 16 + 2; }
+    if (P <= 0) {
+      if (hipMemsetAsync(t + tl.count, 0, tl.start - tl.count, stream) != hipSuccess) return MI355GS_ELAUNCH;
+      if (grad_scratch && hipMemsetAsync(grad_scratch, 0, mi355gs_raster_grad_gate_offset(P) + 32, stream) != hipSuccess) return MI355GS_ELAUNCH;
+    }
+  }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
   gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
-                           (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped));
+                           (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped), visible, pro);
   GS_CHECK_LAUNCH("preprocess_fwd");
   gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
   GS_CHECK_LAUNCH("count_tiles");
@@ -163,7 +175,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                             void* tiles, const void* binning, int64_t capacity, const int32_t* radii, const float* out_color,
                             const float* dL_dpix, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                             float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                            int debug) {
+                            int grad_scratch_is_clear, int debug) {
   (void)opacities; (void)colors_precomp;
   hipStream_t stream = (hipStream_t)stream_;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return MI355GS_EINVAL;
@@ -187,7 +199,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   GsGrad* grads = (GsGrad*)grad_scratch;
   // (with gate_tail the eight gate flags behind the records are cleared by the same memset)
   const size_t clear_bytes = g_fused.gate_tail ? mi355gs_raster_grad_gate_offset(P) + 8 * sizeof(float) : (size_t)P * sizeof(GsGrad);
-  if (!g_fused.skip_memsets && hipMemsetAsync(grads, 0, clear_bytes, stream) != hipSuccess) return MI355GS_ELAUNCH;
+  if (!g_fused.skip_memsets && !grad_scratch_is_clear && hipMemsetAsync(grads, 0, clear_bytes, stream) != hipSuccess) return MI355GS_ELAUNCH;
   if (cap > 0) {
     {
       ProfScope prof(1, stream);

@@ -110,19 +110,26 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, CamParams cp,
     int32_t* __restrict__ radii, GsRec* __restrict__ recs, float* __restrict__ cov3Ds, uint2* __restrict__ rects,
-    uint8_t* __restrict__ clamped, GsPosed posed, GsPrologue pro) {
+    uint8_t* __restrict__ clamped, uint8_t* __restrict__ visible, GsPosed posed, GsPrologue pro) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (POSED && pro.grad_records) {
+  // The frame's accumulators are cleared by its first kernel — this one — instead of memsets in front of it (a 2-4 us launch
+  // and a dependent-dispatch boundary each): the per-tile counters always; the backward's moment records (and the gate flags
+  // behind them) when the caller handed them over already; the one-call step's pose / optimizer scratch.
+  {
     const size_t gid = (size_t)i, stride = (size_t)gridDim.x * blockDim.x;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t k = gid; k < pro.n_vec; k += stride) pro.grad_records[k] = z;
-    for (size_t k = gid; k < (size_t)pro.n_counters; k += stride) pro.tile_counters[k] = 0u;
-    if (gid < (size_t)pro.n_pose) pro.g_poses[gid] = 0.f;
-    if (gid < 32) pro.pose_scratch[gid] = 0.f;
-    if (gid < 8) pro.adam_scratch[gid] = 0.f;
+    if (pro.grad_records) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (size_t k = gid; k < pro.n_vec; k += stride) pro.grad_records[k] = z;
+    }
+    if (pro.tile_counters)
+      for (size_t k = gid; k < (size_t)pro.n_counters; k += stride) pro.tile_counters[k] = 0u;
+    if (pro.g_poses && gid < (size_t)pro.n_pose) pro.g_poses[gid] = 0.f;
+    if (pro.pose_scratch && gid < 32) pro.pose_scratch[gid] = 0.f;
+    if (pro.adam_scratch && gid < 8) pro.adam_scratch[gid] = 0.f;
   }
   if (i >= P) return;
   radii[i] = 0;
+  if (visible) visible[i] = 0;
   rects[i] = make_uint2(0u, 0u);
   const float* view = cp.view;
   const float* proj = cp.proj;
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   }
 
   radii[i] = (int)radius;
+  if (visible) visible[i] = 1;   // the reference's `visibility_filter` (radii > 0; radius >= 1 here) without a compare kernel behind the operator
   clamped[i] = clamp_bits;
   // Tiles this Gaussian is binned to: the reference's 3-sigma rect, intersected with the tiles the
   // alpha >= 1/255 box can reach.  Dropped tiles hold no pixel that would pass the alpha test, so the
@@ -539,14 +547,13 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
                              const float* colors_precomp, const float* opacities, const float* scales,
                              const float* rotations, const float* cov3D_precomp, const CamParams& cp, int32_t* radii,
-                             GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped) {
+                             GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped, uint8_t* visible, const GsPrologue& pro) {
   if (P <= 0) return 0;
   const bool posed = g_fused.posed.pose != nullptr;
   const GsPosed pa = posed ? g_fused.posed : GsPosed();
-  const GsPrologue pro = posed ? g_fused.prologue : GsPrologue();
 #define GS_FWD(POSED, DEG)                                                                                                              \
   hipLaunchKernelGGL((k_preprocess_fwd<POSED, DEG>), dim3((P + 255) / 256), dim3(256), 0, stream, P, M, means3D, shs, shs_rest,         \
-                     colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, pa, pro)
+                     colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, visible, pa, pro)
   const int deg = shs ? D : 0;  // one instantiation per active SH degree: coefficient arrays stay in registers
   if (posed) { if (deg == 0) GS_FWD(true, 0); else if (deg == 1) GS_FWD(true, 1); else if (deg == 2) GS_FWD(true, 2); else GS_FWD(true, 3); }
   else { if (deg == 0) GS_FWD(false, 0); else if (deg == 1) GS_FWD(false, 1); else if (deg == 2) GS_FWD(false, 2); else GS_FWD(false, 3); }

@@ -90,7 +90,7 @@ int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t*
     g_fused.commit_count = (const uint32_t*)(t->tiles + tl.start) + tl.T;   // tile_start[T]: the frame's instance count
     g_fused.commit_capacity = (unsigned long long)t->capacity;
   }
-  return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch, nullptr, nullptr);
+  return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch, nullptr, nullptr, nullptr, 0u);
 }
 
 __global__ void k_trainer_consts(float* consts) {
@@ -109,13 +109,13 @@ int mi355gs_posed_forward_preprocess(void* stream, int P, int D, int W, int H, c
                                      const float* f_rest, const float* opacity_logit, const float* log_scales, float scale_modifier,
                                      const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
                                      const float* origin, float tanfovx, float tanfovy, int32_t* radii, void* geom, void* tiles,
-                                     int32_t* num_rendered, int debug) {
+                                     int32_t* num_rendered, uint8_t* visible, void* grad_scratch, int debug) {
   if (!pose || D < 0 || D > 3 || (D > 0 && !f_rest)) return MI355GS_EINVAL;
   struct Scope { ~Scope() { g_fused = GsFusedStepHooks(); } } scope;
   g_fused.posed.pose = pose;
   return mi355gs_raster_forward_preprocess(stream, P, D, D == 0 ? 1 : 16, W, H, xyz, f_dc, D == 0 ? nullptr : f_rest, nullptr,
                                            opacity_logit, log_scales, scale_modifier, rotation, nullptr, view_identity, projmatrix,
-                                           origin, tanfovx, tanfovy, 0, radii, geom, tiles, num_rendered, debug);
+                                           origin, tanfovx, tanfovy, 0, radii, geom, tiles, num_rendered, visible, grad_scratch, debug);
 }
 
 int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const float* bg, const float* xyz, const float* f_dc,
@@ -124,7 +124,8 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
                            const float* origin, float tanfovx, float tanfovy, const void* geom, void* tiles, const void* binning,
                            int64_t capacity, const int32_t* radii, const float* out_color, const float* dL_dpix,
                            void* grad_scratch, float* pose_scratch, float* d_xyz, float* d_means2D, float* d_f_dc, float* d_f_rest,
-                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int debug) {
+                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int grad_scratch_is_clear,
+                           int debug) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!pose || !pose_scratch || !d_pose || D < 0 || D > 3 || (D > 0 && (!f_rest || !d_f_rest))) return MI355GS_EINVAL;
   if (P <= 0) return hipMemsetAsync(d_pose, 0, 7 * sizeof(float), stream) == hipSuccess ? MI355GS_OK : MI355GS_ELAUNCH;
@@ -142,7 +143,8 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
     rc = mi355gs_raster_backward(stream, P, D, D == 0 ? 1 : 16, W, H, bg, xyz, f_dc, D == 0 ? nullptr : f_rest, nullptr, opacity_logit,
                                  log_scales, scale_modifier, rotation, nullptr, view_identity, projmatrix, origin, tanfovx, tanfovy,
                                  geom, tiles, binning, capacity, radii, out_color, dL_dpix, grad_scratch, d_xyz, d_means2D, d_f_dc,
-                                 D == 0 ? nullptr : d_f_rest, nullptr, d_opacity_logit, d_log_scales, d_rotation, nullptr, debug);
+                                 D == 0 ? nullptr : d_f_rest, nullptr, d_opacity_logit, d_log_scales, d_rotation, nullptr,
+                                 grad_scratch_is_clear, debug);
   }
   if (rc) return rc;
   gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, gate + 6, nullptr, 0, 0.0, 0.f, nullptr);
@@ -234,7 +236,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   float* g_rest = D == 0 ? nullptr : t->g_frest;
   if ((rc = mi355gs_raster_forward_preprocess(stream, P, D, M, W, H, t->xyz, t->f_dc, rest, nullptr, t->opacity, t->scaling, 1.0f,
                                               t->rotation, nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, 0, t->radii,
-                                              t->geom, t->tiles, num_rendered_out, 0)))
+                                              t->geom, t->tiles, num_rendered_out, nullptr, nullptr, 0)))
     return rc;
   if ((rc = mi355gs_raster_forward_render(stream, P, W, H, t->capacity, bg, t->geom, t->tiles, t->binning, t->image, 0))) return rc;
   // ---- loss and its gradient in one launch (the SSIM partial-derivative maps never leave LDS); the loss VALUE, which only
@@ -244,7 +246,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   if ((rc = mi355gs_raster_backward(stream, P, D, M, W, H, bg, t->xyz, t->f_dc, rest, nullptr, t->opacity, t->scaling, 1.0f, t->rotation,
                                     nullptr, view_m, projmatrix, campos, tanfovx, tanfovy, t->geom, t->tiles, t->binning,
                                     t->capacity, t->radii, t->image, t->dL_dimg, t->grad_scratch, t->g_xyz, t->g_means2D, t->g_fdc,
-                                    g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0)))
+                                    g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0, 0)))
     return rc;
   gs_launch_pose_finish_partials(stream, pose, t->pose_partial, (P + 255) / 256, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6,
                                  (const float*)t->ssim_scratch, gs_loss_fused_nblocks(3, H, W), 1.0 / (3.0 * H * W), lambda_dssim, loss_out);

@@ -17,6 +17,7 @@
 
 #include <chrono>
 #include <optional>
+#include <map>
 #include <mutex>
 
 #include "../../include/mi355gs.h"
@@ -153,6 +154,44 @@ struct GateRecord {
 std::mutex g_gate_mutex;
 GateRecord g_gates;
 
+// Does a backward of this call exist at all?  (The forward then owns the backward's accumulator buffer already and lets the
+// projection kernel clear it on its way: no memset in front of the backward's first kernel.)
+template <class... T> bool any_requires_grad(const T&... t) {
+  if (!at::GradMode::is_enabled()) return false;
+  bool any = false;
+  ((any = any || (t.defined() && t.requires_grad())), ...);
+  return any;
+}
+
+// The all-zero gradient of `f_rest` below its SH degree (what the reference's cat(f_dc, f_rest) backward produces: 35 MB of
+// zeros per iteration at C3, filled by a kernel every backward).  ONE persistent zero buffer per (device, shape) is handed
+// to autograd instead, as a fresh alias each time: AccumulateGrad takes it over without a copy (use count 1, dense), the
+// optimizer reads zeros, zero_grad(set_to_none=True) drops the alias.  Aliases share the buffer's version counter, so any
+// in-place operation on such a `.grad` (accumulation over two backward passes, clipping, zero_grad(set_to_none=False), an
+// all-reduce) is seen here as a changed version and the buffer is zeroed again before its next use.  Writes BEHIND the
+// version counter (`.grad.data`, raw pointers) are the caller's to declare: mi355gs shared_zero_grad(false)
+// (instantsplat_amd.optim.PerPointAdam.use_backward_gates = False switches it off together with the gate shortcut).
+struct ZeroGrad { Tensor buf; uint32_t version = 0; };
+std::mutex g_zero_mutex;
+std::map<std::string, ZeroGrad> g_zero_pool;
+bool g_share_zero_grad = true;
+Tensor zero_grad_like(const Tensor& like) {
+  if (!g_share_zero_grad) return at::zeros_like(like);
+  std::ostringstream key;
+  key << like.device() << ":" << like.sizes();
+  std::lock_guard<std::mutex> lock(g_zero_mutex);
+  if (g_zero_pool.size() > 8 && !g_zero_pool.count(key.str())) g_zero_pool.clear();   // (shapes come and go: a handful of scenes at most)
+  ZeroGrad& z = g_zero_pool[key.str()];
+  if (!z.buf.defined()) {
+    z.buf = at::zeros_like(like, like.options().requires_grad(false), at::MemoryFormat::Contiguous);
+    z.version = z.buf._version();
+  } else if (z.buf._version() != z.version) {
+    z.buf.zero_();
+    z.version = z.buf._version();
+  }
+  return z.buf.detach();
+}
+
 // ------------------------------------------------------------------------------------------------
 // render()'s differentiable body: raw GaussianModel tensors + the 7-vector camera pose in, image out
 // (reference gaussian_renderer/__init__.py:81-135; the Python twin is instantsplat_amd/fused.py::_RenderPosed)
@@ -174,14 +213,20 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     const int P = (int)xyz.size(0);
     const DeviceScope dev(xyz);
     Tensor radii = at::empty({P}, xyz.options().dtype(at::kInt));
+    Tensor visible = at::empty({P}, xyz.options().dtype(at::kBool));   // radii > 0, written by the projection kernel
     Tensor color = at::empty({3, H, W}, xyz.options());
     Tensor geom = empty_bytes(g_abi.geom_bytes(P), xyz), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), xyz);
+    // a backward will follow: its accumulator buffer is allocated now and cleared by the projection kernel on its way
+    Tensor scratch;
+    if (any_requires_grad(xyz_, rot_, scaling_, opl_, f_dc_, f_rest_, pose_, means2D)) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
     int32_t* count = count_slot.data_ptr<int32_t>();  // pinned host memory the tile-scan kernel stores into (a CPU word under emulation)
     auto preprocess = [&]() {
       *reinterpret_cast<volatile int32_t*>(count) = -1;   // "not written yet" for wait_for_count
       check(g_abi.posed_forward_preprocess(dev.stream, P, (int)D, (int)W, (int)H, fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling),
                                            (float)scale_modifier, fp(rot), fp(pose), fp(view), fp(proj), fp(origin), (float)tanfovx,
-                                           (float)tanfovy, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count, 0),
+                                           (float)tanfovy, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count,
+                                           P > 0 ? reinterpret_cast<uint8_t*>(visible.data_ptr<bool>()) : nullptr,
+                                           scratch.defined() ? scratch.data_ptr() : nullptr, 0),
             "posed_forward_preprocess");
     };
     Tensor binning;
@@ -219,9 +264,13 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     }
     ctx->saved_data["dims"] = std::vector<int64_t>{P, D, W, H, R};
     ctx->saved_data["scalars"] = std::vector<double>{tanfovx, tanfovy, scale_modifier};
-    ctx->save_for_backward({xyz, rot, scaling, opl, f_dc, f_rest, pose, radii, geom, tiles, binning, bg, view, proj, origin, color});
-    ctx->mark_non_differentiable({radii});
-    return {color, radii};
+    ctx->saved_data["scratch_is_clear"] = scratch.defined();
+    ctx->save_for_backward({xyz, rot, scaling, opl, f_dc, f_rest, pose, radii, geom, tiles, binning, bg, view, proj, origin, color,
+                            scratch.defined() ? scratch : Tensor()});
+    ctx->mark_non_differentiable({radii, visible});
+    // (no zero tensors for the gradients of `radii` / `visible`: autograd otherwise fills one of each per backward — two launches)
+    ctx->set_materialize_grads(false);
+    return {color, radii, visible};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
@@ -234,21 +283,27 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     const auto sc = ctx->saved_data["scalars"].toDoubleVector();
     const int P = (int)dims[0], D = (int)dims[1], W = (int)dims[2], H = (int)dims[3];
     const int64_t R = dims[4];
+    if (!grad_out[0].defined()) return variable_list(21);   // the image took no part in the loss: no gradient flows back
     const Tensor g = f32c(grad_out[0], "grad_color", xyz);
     const DeviceScope dev(xyz);
     Tensor d_xyz = at::empty_like(xyz), d_rot = at::empty_like(rot), d_scaling = at::empty_like(scaling), d_opl = at::empty_like(opl),
            d_fdc = at::empty_like(f_dc), d_m2d = at::empty_like(xyz);
     // below its SH degree f_rest gets the all-zero gradient cat(f_dc, f_rest) would give it (the optimizer then takes
     // PerPointAdam's zero-gradient step on it, as in the reference)
-    Tensor d_frest = D == 0 ? at::zeros_like(f_rest) : at::empty_like(f_rest);
+    Tensor d_frest = D == 0 ? zero_grad_like(f_rest) : at::empty_like(f_rest);
     Tensor d_pose = at::empty({7}, xyz.options());
-    Tensor scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
+    // the accumulator buffer the forward allocated and had cleared — once: a second backward of the same frame (retain_graph)
+    // finds it used and lets the library clear it
+    Tensor scratch = saved.size() > 16 ? saved[16] : Tensor();
+    int scratch_is_clear = (scratch.defined() && ctx->saved_data["scratch_is_clear"].toBool()) ? 1 : 0;
+    ctx->saved_data["scratch_is_clear"] = false;
+    if (!scratch.defined()) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
     Tensor pose_scratch = at::empty({16 * (((int64_t)P + 255) / 256) + 32}, xyz.options());
     check(g_abi.posed_backward(dev.stream, P, D, W, H, fp(bg), fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling), (float)sc[2], fp(rot),
                                fp(pose), fp(view), fp(proj), fp(origin), (float)sc[0], (float)sc[1], geom.data_ptr(), tiles.data_ptr(),
                                binning.data_ptr(), R, radii.data_ptr<int32_t>(), fp(color), fp(g), scratch.data_ptr(), fp(pose_scratch),
                                fp(d_xyz), fp(d_m2d), fp(d_fdc), D ? fp(d_frest) : nullptr, fp(d_opl), fp(d_scaling), fp(d_rot), fp(d_pose),
-                               0),
+                               scratch_is_clear, 0),
           "posed_backward");
     {
       std::lock_guard<std::mutex> lock(g_gate_mutex);
@@ -308,12 +363,20 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     Tensor radii = at::empty({P}, means3D.options().dtype(at::kInt));
     Tensor color = at::empty({3, H, W}, means3D.options());
     Tensor geom = empty_bytes(g_abi.geom_bytes(P), means3D), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), means3D);
+    Tensor scratch;   // see RenderPosedFn::forward
+    {
+      const Tensor none;
+      auto val = [&](const OptTensor& t) -> const Tensor& { return t.has_value() ? *t : none; };
+      if (any_requires_grad(means3D_, means2D, opac_, val(sh_), val(colors_), val(scales_), val(rot_), val(cov_), val(sh_rest_)))
+        scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
+    }
     int32_t* count = count_slot.data_ptr<int32_t>();
     auto preprocess = [&]() {
       *reinterpret_cast<volatile int32_t*>(count) = -1;
       check(g_abi.forward_preprocess(dev.stream, P, (int)D, M, (int)W, (int)H, fp(means3D), fp(sh), fp(sh_rest), fp(colors), fp(opac), fp(scales),
                                      (float)scale_modifier, fp(rot), fp(cov), fp(view), fp(proj), fp(campos), (float)tanfovx, (float)tanfovy,
-                                     prefiltered ? 1 : 0, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count, 0),
+                                     prefiltered ? 1 : 0, radii.data_ptr<int32_t>(), geom.data_ptr(), tiles.data_ptr(), count, nullptr,
+                                     scratch.defined() ? scratch.data_ptr() : nullptr, 0),
             "raster_forward_preprocess");
     };
     Tensor binning;
@@ -341,12 +404,16 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     ctx->saved_data["dims"] = std::vector<int64_t>{P, D, M, W, H, R};
     ctx->saved_data["scalars"] = std::vector<double>{tanfovx, tanfovy, scale_modifier};
     ctx->saved_data["opacity_shape"] = opac_.sizes().vec();
-    ctx->save_for_backward({means3D, sh, colors, opac, scales, rot, cov, sh_rest, radii, geom, tiles, binning, bg, view, proj, campos, color});
+    ctx->saved_data["scratch_is_clear"] = scratch.defined();
+    ctx->save_for_backward({means3D, sh, colors, opac, scales, rot, cov, sh_rest, radii, geom, tiles, binning, bg, view, proj, campos, color,
+                            scratch.defined() ? scratch : Tensor()});
     ctx->mark_non_differentiable({radii});
+    ctx->set_materialize_grads(false);
     return {color, radii};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    if (!grad_out[0].defined()) return variable_list(23);
     const auto saved = ctx->get_saved_variables();
     const Tensor &means3D = saved[0], &sh = saved[1], &colors = saved[2], &opac = saved[3], &scales = saved[4], &rot = saved[5], &cov = saved[6],
                  &sh_rest = saved[7], &radii = saved[8], &geom = saved[9], &tiles = saved[10], &binning = saved[11], &bg = saved[12],
@@ -363,11 +430,14 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     if (sh.defined()) d_sh = at::empty({P, sh_rest.defined() ? 1 : M, 3}, o);
     if (sh_rest.defined()) d_shr = at::empty({P, M - 1, 3}, o);
     if (cov.defined()) d_cov = at::empty({P, 6}, o); else { d_scales = at::empty({P, 3}, o); d_rot = at::empty({P, 4}, o); }
-    Tensor scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
+    Tensor scratch = saved.size() > 17 ? saved[17] : Tensor();
+    const int scratch_is_clear = (scratch.defined() && ctx->saved_data["scratch_is_clear"].toBool()) ? 1 : 0;
+    ctx->saved_data["scratch_is_clear"] = false;
+    if (!scratch.defined()) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
     check(g_abi.raster_backward(dev.stream, P, D, M, W, H, fp(bg), fp(means3D), fp(sh), fp(sh_rest), fp(colors), fp(opac), fp(scales), (float)sc[2],
                                 fp(rot), fp(cov), fp(view), fp(proj), fp(campos), (float)sc[0], (float)sc[1], geom.data_ptr(), tiles.data_ptr(),
                                 binning.data_ptr(), R, radii.data_ptr<int32_t>(), fp(color), fp(g), scratch.data_ptr(), fp(d_means3D), fp(d_means2D),
-                                fp(d_sh), fp(d_shr), fp(d_col), fp(d_opac), fp(d_scales), fp(d_rot), fp(d_cov), 0),
+                                fp(d_sh), fp(d_shr), fp(d_col), fp(d_opac), fp(d_scales), fp(d_rot), fp(d_cov), scratch_is_clear, 0),
           "raster_backward");
     Tensor none;
     const auto shape = ctx->saved_data["opacity_shape"].toIntVector();
@@ -405,12 +475,14 @@ struct L1SsimLossFn : public torch::autograd::Function<L1SsimLossFn> {
           "l1_ssim_loss_fused");
     ctx->save_for_backward({grad});
     ctx->mark_non_differentiable({out});
+    ctx->set_materialize_grads(false);
     return {loss, out};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
     HostClock clock(&g_host_us[3]);
-    const auto saved = ctx->get_saved_variables();
     Tensor none;
+    if (!grad_out[0].defined()) return {none, none, none};
+    const auto saved = ctx->get_saved_variables();
     return {saved[0] * grad_out[0], none, none};
   }
 };
@@ -469,6 +541,12 @@ struct AdamPlan {
   double beta1, beta2, eps;
   int64_t last_used_gates = 0;   // diagnostics: tensors of the last step that took a gate flag of the posed backward
   std::string last_gate_note;    // diagnostics: why a tensor of the last step did not qualify
+  // the library's memory of gated-off tensors across this plan's steps (include/mi355gs.h, mi355gs_adam_multi_step `live`):
+  // f_rest below its SH degree is skipped without reading its first moment again.  These steps are the only writers of the
+  // moments the library knows of; a torch operation on a moment tensor shows in its version counter and resets the memory.
+  Tensor live;
+  uint32_t seq = 0;
+  std::vector<int64_t> moment_version;
 
   AdamPlan(std::vector<Tensor> p, std::vector<Tensor> m, std::vector<Tensor> v, std::vector<c10::optional<Tensor>> pp, double b1, double b2,
            double e)
@@ -540,8 +618,19 @@ struct AdamPlan {
     Tensor scratch;
     if (n_flagged < (int64_t)n) scratch = at::empty({8}, params[0].options());
     last_used_gates = n_flagged;
+    bool moments_touched = !live.defined();
+    if (moment_version.size() != 2 * n) moment_version.assign(2 * n, -1);
+    for (size_t t = 0; t < n; ++t) {
+      const int64_t v0 = (int64_t)exp_avg[t]._version(), v1 = (int64_t)exp_avg_sq[t]._version();
+      moments_touched = moments_touched || v0 != moment_version[2 * t] || v1 != moment_version[2 * t + 1];
+      moment_version[2 * t] = v0; moment_version[2 * t + 1] = v1;
+    }
+    if (!live.defined()) live = at::zeros({16}, params[0].options().dtype(at::kInt));
+    else if (moments_touched) live.zero_();
+    if (++seq == 0u) seq = 1u;
     check(g_abi.adam_multi_step(dev.stream, (int)n, nm, rw, pp, gg, mm, vv, ll, lrs, (float)beta1, (float)beta2, (float)eps, st,
-                                scratch.defined() ? scratch.data_ptr<float>() : nullptr, gated ? rec.gate : nullptr, gated ? gidx : nullptr),
+                                scratch.defined() ? scratch.data_ptr<float>() : nullptr, gated ? rec.gate : nullptr, gated ? gidx : nullptr,
+                                reinterpret_cast<uint32_t*>(live.data_ptr<int32_t>()), seq),
           "adam_multi_step");
   }
 };
@@ -561,6 +650,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     return v;
   }, "accumulated host microseconds: render fwd (incl. the count wait), render bwd, loss fwd, loss bwd, adam step, count wait");
   m.def("forget_gates", []() { std::lock_guard<std::mutex> lock(g_gate_mutex); g_gates = GateRecord(); });
+  m.def("shared_zero_grad", [](bool on) {
+    std::lock_guard<std::mutex> lock(g_zero_mutex);
+    const bool old = g_share_zero_grad;
+    g_share_zero_grad = on;
+    if (!on) g_zero_pool.clear();
+    return old;
+  }, "f_rest's all-zero gradient below its SH degree: true (default) = aliases of one persistent zero buffer, false = a fresh zeros tensor per backward");
   py::class_<AdamPlan>(m, "AdamPlan")
       .def(py::init<std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, std::vector<c10::optional<Tensor>>, double, double, double>())
       .def("step", &AdamPlan::step)

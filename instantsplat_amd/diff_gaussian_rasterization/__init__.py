@@ -313,7 +313,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 stream, P, D, M, W, H, _lib.ptr(means3D), _lib.ptr(sh_), _lib.ptr(shr_), _lib.ptr(col_), _lib.ptr(opac), _lib.ptr(sc_),
                 float(s.scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos),
                 float(s.tanfovx), float(s.tanfovy), int(bool(s.prefiltered)), _lib.ptr(radii), _lib.ptr(geom),
-                _lib.ptr(tiles), _lib.ptr(num_rendered), debug), "raster_forward_preprocess")
+                _lib.ptr(tiles), _lib.ptr(num_rendered), None, None, debug), "raster_forward_preprocess")
             return size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug)
 
         if s.debug:
@@ -371,7 +371,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.ptr(campos), float(s.tanfovx), float(s.tanfovy), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(binning),
                 int(ctx.num_rendered), _lib.ptr(radii), _lib.ptr(color), _lib.ptr(g), _lib.ptr(scratch), _lib.ptr(dL_dmeans3D),
                 _lib.ptr(dL_dmeans2D), _lib.ptr(dL_dsh), _lib.ptr(dL_dshr), _lib.ptr(dL_dcol), _lib.ptr(dL_dopac), _lib.ptr(dL_dscales),
-                _lib.ptr(dL_drot), _lib.ptr(dL_dcov), 1 if s.debug else 0), "raster_backward")
+                _lib.ptr(dL_drot), _lib.ptr(dL_dcov), 0, 1 if s.debug else 0), "raster_backward")
 
         if s.debug:
             try:

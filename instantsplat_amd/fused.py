@@ -94,8 +94,8 @@ class _RenderPosed(torch.autograd.Function):
             _lib.check(L.mi355gs_posed_forward_preprocess(
                 stream, P, D, W, H, _lib.ptr(xyz), _lib.ptr(f_dc), _lib.ptr(f_rest), _lib.ptr(opl), _lib.ptr(scaling),
                 float(s.scale_modifier), _lib.ptr(rot), _lib.ptr(pose), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(origin),
-                float(s.tanfovx), float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(num_rendered), debug),
-                "posed_forward_preprocess")
+                float(s.tanfovx), float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(num_rendered), None, None,
+                debug), "posed_forward_preprocess")
             R, binning = dgr.size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug)
         if dgr._KEEP_LAST_FRAME:
             dgr._LAST_FRAME.update(tiles=tiles, W=W, H=H)
@@ -127,7 +127,7 @@ class _RenderPosed(torch.autograd.Function):
                 _lib.ptr(origin), float(s.tanfovx), float(s.tanfovy), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(binning),
                 int(ctx.capacity), _lib.ptr(radii), _lib.ptr(color), _lib.ptr(g), _lib.ptr(scratch), _lib.ptr(pose_scratch),
                 _lib.ptr(d_xyz), _lib.ptr(d_m2d), _lib.ptr(d_fdc), _lib.ptr(d_frest) if D else None, _lib.ptr(d_opl),
-                _lib.ptr(d_scaling), _lib.ptr(d_rot), _lib.ptr(d_pose), 1 if s.debug else 0), "posed_backward")
+                _lib.ptr(d_scaling), _lib.ptr(d_rot), _lib.ptr(d_pose), 0, 1 if s.debug else 0), "posed_backward")
         return d_xyz, d_rot, d_scaling, d_opl, d_fdc, d_frest, d_pose, d_m2d, None
 
 
@@ -135,7 +135,8 @@ _LAST_COUNT = {}   # (P, W, H, hint key) -> instance count of the last frame lik
 
 
 def render_posed_compiled(ext, pc, pose, means2D, bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree):
-    """The compiled node (csrc_torch/binding.cpp) with the BinningPolicy bookkeeping of `size_and_render` around it."""
+    """The compiled node (csrc_torch/binding.cpp) with the BinningPolicy bookkeeping of `size_and_render` around it.
+    -> [image, radii, visible]: `visible` = radii > 0 as a bool tensor the projection kernel wrote (no compare kernel)."""
     policy = dgr.BinningPolicy
     xyz = pc._xyz
     dev = xyz.device
@@ -143,22 +144,22 @@ def render_posed_compiled(ext, pc, pose, means2D, bg, view, proj, origin, H, W, 
     cap = policy.deferred_capacity()
     key = policy.current_key
     if cap is not None:
-        color, radii = ext.render_posed(xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
-                                        bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree, cap, 0, slot)
+        out = ext.render_posed(xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
+                               bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree, cap, 0, slot)
         policy.defer(slot, cap, dev)
-        return color, radii
+        return out
     # exact mode: the reference operator's blocking count read-back; the count of the previous frame like this one lets the
     # node enqueue stage 2 before the count of THIS frame has arrived (see RenderPosedFn::forward)
     ck = (xyz.shape[0], W, H, key)
-    color, radii = ext.render_posed(xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
-                                    bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree, -1, _LAST_COUNT.get(ck, 0), slot)
+    out = ext.render_posed(xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
+                           bg, view, proj, origin, H, W, tanfovx, tanfovy, scale_modifier, degree, -1, _LAST_COUNT.get(ck, 0), slot)
     r = dgr.read_count(slot)
     if len(_LAST_COUNT) > 256:
         _LAST_COUNT.clear()
     _LAST_COUNT[ck] = r
     if key is not None:
         policy.known[key] = r
-    return color, radii
+    return out
 
 
 def render_posed(pc, pose, means2D, settings):
@@ -173,7 +174,7 @@ def render_posed(pc, pose, means2D, settings):
         return _RenderPosed.apply(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
                                   settings)
     return render_posed_compiled(ext, pc, pose, means2D, s.bg, s.viewmatrix, s.projmatrix, s.campos, int(s.image_height),
-                                 int(s.image_width), float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), int(s.sh_degree))
+                                 int(s.image_width), float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), int(s.sh_degree))[:2]
 
 
 def sh_features(pc):

@@ -92,10 +92,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             tans = viewpoint_camera.__dict__.get("_gs_tanfov")
             if tans is None or tans[0] != fx or tans[1] != fy:
                 tans = viewpoint_camera.__dict__["_gs_tanfov"] = (fx, fy, math.tan(fx * 0.5), math.tan(fy * 0.5))
-            image, radii = render_posed_compiled(ext, pc, camera_pose, screenspace_points, bg_color, view_identity, projmatrix, origin,
-                                                 int(viewpoint_camera.image_height), int(viewpoint_camera.image_width), tans[2], tans[3],
-                                                 float(scaling_modifier), int(pc.active_sh_degree))
-            return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+            image, radii, visible = render_posed_compiled(ext, pc, camera_pose, screenspace_points, bg_color, view_identity, projmatrix,
+                                                          origin, int(viewpoint_camera.image_height), int(viewpoint_camera.image_width),
+                                                          tans[2], tans[3], float(scaling_modifier), int(pc.active_sh_degree))
+            # (`visible` is the reference's `radii > 0`, written by the projection kernel: no elementwise launch behind the node)
+            return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii}
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,

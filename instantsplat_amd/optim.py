@@ -43,7 +43,9 @@ class PerPointAdam(Optimizer):
     # on the device instead of a pass over the gradient.  `_version()` sees every in-place torch op on the tensor itself; it does
     # NOT see writes through `.grad.data` / `.detach()` views made before the backward, or raw-pointer kernels.  Code that edits
     # gradients that way sets `use_backward_gates = False` (class or instance): every step then sums the squared gradients itself,
-    # exactly like the reference's `grad.norm() > 0` (one more ~20 us launch per step).
+    # exactly like the reference's `grad.norm() > 0` (one more ~20 us launch per step), and the render backward goes back to a
+    # fresh zero tensor for `f_rest`'s gradient below its SH degree instead of aliases of one persistent zero buffer
+    # (csrc_torch/binding.cpp::zero_grad_like: same contract — in-place torch ops on such a `.grad` are seen and handled).
     use_backward_gates = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
@@ -190,6 +192,7 @@ class PerPointAdam(Optimizer):
             steps.append(st["step"])
         if not self.use_backward_gates:
             fast[0].forget_gates()
+            fast[0].shared_zero_grad(False)   # gradients are edited behind the version counter: no shared zero buffer either
         plan.step(grads, lrs, steps)
         return True
 
@@ -240,6 +243,7 @@ class PerPointAdam(Optimizer):
                     b["compiled_ext"] = ext
                 if not self.use_backward_gates:
                     ext.forget_gates()
+                    ext.shared_zero_grad(False)
                 plan.step([p.grad for p in b["params"]], [group["lr"] for group in b["groups"]], [s_["step"] for s_ in b["states"]])
                 if len(batches) == 1 and len(live) == sum(len(g["params"]) for g in self.param_groups):
                     # every parameter of the optimizer took part, in one batch: remember the line-up for _step_fast
@@ -265,5 +269,5 @@ class PerPointAdam(Optimizer):
                 _lib.check(L.mi355gs_adam_multi_step(
                     _lib.stream_ptr(dev), b["n"], b["numel"], b["row"], b["p"], b["PTR"](*ptrs), b["m"], b["v"],
                     b["pplr"], b["F32"](*[group["lr"] for group in b["groups"]]), b1, b2, eps,
-                    b["I32"](*[s_["step"] for s_ in b["states"]]), scratch.data_ptr(), None, None), "adam_multi_step")
+                    b["I32"](*[s_["step"] for s_ in b["states"]]), scratch.data_ptr(), None, None, None, 0), "adam_multi_step")
         return loss

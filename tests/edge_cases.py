@@ -182,7 +182,7 @@ def check_tile_lists_sorted(dev, n):
     nr = torch.zeros(1, dtype=torch.int32, device=dev)
     p, stream = _lib.ptr, _lib.stream_ptr(dev)
     _lib.check(L.mi355gs_raster_forward_preprocess(stream, n, 0, 0, W, H, p(means), None, None, p(col), p(opac), p(scales), 1.0, p(q), None,
-                                                   p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles), p(nr), 0), "preprocess")
+                                                   p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles), p(nr), None, None, 0), "preprocess")
     R = int(nr.item())
     binning = torch.zeros(L.mi355gs_raster_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
     img, bg = torch.zeros(3, H, W, device=dev), torch.zeros(3, device=dev)
@@ -238,7 +238,7 @@ def check_backward_launch_order(dev, n=3000, min_units=None):
         nr = torch.zeros(1, dtype=torch.int32, device=dev)
         p, stream = _lib.ptr, _lib.stream_ptr(dev)
         _lib.check(L.mi355gs_raster_forward_preprocess(stream, n, 0, 0, W, H, p(means), None, None, p(col), p(opac), p(scales), 1.0, p(q), None,
-                                                       p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles), p(nr), 0), "preprocess")
+                                                       p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles), p(nr), None, None, 0), "preprocess")
         R = int(nr.item())
         binning = torch.zeros(L.mi355gs_raster_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         img, bg = torch.zeros(3, H, W, device=dev), torch.zeros(3, device=dev)
@@ -357,7 +357,7 @@ def check_tile_lists_against_oracle(dev, n, W=80, H=48, seed=5):
     p, stream = _lib.ptr, _lib.stream_ptr(dev)
     _lib.check(L.mi355gs_raster_forward_preprocess(stream, n, 0, 0, W, H, p(d_means), None, None, p(d_col), p(d_opac), p(d_scales), 1.0,
                                                    p(d_q), None, p(view), p(proj), p(campos), tanx, tany, 0, p(radii), p(geom), p(tiles),
-                                                   p(nr), 0), "preprocess")
+                                                   p(nr), None, None, 0), "preprocess")
     R = int(nr.item())
     binning = torch.zeros(L.mi355gs_raster_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
     img, bg = torch.zeros(3, H, W, device=dev), torch.zeros(3, device=dev)

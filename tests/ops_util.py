@@ -455,19 +455,27 @@ def check_gated_off_tensor_keeps_moving(dev, Wm=10, W=24):
     cuda = torch.device(dev).type == "cuda"
     try:
         res = {}
-        for fused in (False, True):
-            st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=500, pp_optimizer=True, optim_pose=True)))
-            ra = RunAhead(st, window=2, fused_step=fused)
-            g = st.gaussians
-            track = []
-            for degree in (0, 0, 0, 1, 1, 0, 0, 0):
-                g.active_sh_degree = degree
-                ra.step()
-                ra.flush()
-                track.append(g._features_rest.detach().cpu().clone())
-            stt = g.optimizer.state[g._features_rest]
-            res[fused] = (track, stt["exp_avg"].detach().cpu().clone(), stt["exp_avg_sq"].detach().cpu().clone())
-            BinningPolicy.reset("exact")
+        # False: autograd path through the compiled binding (AdamPlan keeps the library's `live` memory since ABI v7), True: the
+        # one-call step (the trainer handle's `live`), "ctypes": autograd path through the ctypes binding, which passes NO memory —
+        # every step reads the first moment again: the independent reference of the other two
+        for fused in (False, True, "ctypes"):
+            with _with_binding("ctypes" if fused == "ctypes" else "compiled"):
+                st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=500, pp_optimizer=True, optim_pose=True)))
+                ra = RunAhead(st, window=2, fused_step=(fused is True))
+                g = st.gaussians
+                track = []
+                for degree in (0, 0, 0, 1, 1, 0, 0, 0):
+                    g.active_sh_degree = degree
+                    ra.step()
+                    ra.flush()
+                    track.append(g._features_rest.detach().cpu().clone())
+                stt = g.optimizer.state[g._features_rest]
+                res[fused] = (track, stt["exp_avg"].detach().cpu().clone(), stt["exp_avg_sq"].detach().cpu().clone())
+                BinningPolicy.reset("exact")
+        for k in range(8):
+            a_, b_ = res[False][0][k], res["ctypes"][0][k]
+            bound("gated_off/f_rest_track_compiled_vs_ctypes", float((a_ - b_).norm()) / float(b_.norm() + 1e-12) if float(b_.norm()) > 0 else float(a_.norm()),
+                  2e-4 if cuda else 0.0)
         for fused in (False, True):
             track = res[fused][0]
             assert float(track[2].abs().max()) == 0                       # untouched while never updated
@@ -555,6 +563,74 @@ def check_fused_synced_loop_equals_autograd_loop(dev, iters=5, force_overflow=Fa
             bound("synced_one_call_vs_autograd/param" + n, rel_l2(getattr(b.gaussians, n), getattr(a.gaussians, n)), 1e-3 if cuda else 1e-5)   # MI355X: <= 5.3e-5
     finally:
         BinningPolicy.slack, BinningPolicy.pad = 1.5, 16384
+        BinningPolicy.reset("exact")
+
+
+def check_dropin_node_housekeeping(dev, Wm=10, W=32, H=24):
+    """What ABI v7 moved into the render node's own kernels, on the drop-in path (compiled binding):
+      * `visibility_filter` is written by the projection kernel (no `radii > 0` launch): bool, equal to radii > 0;
+      * the backward's accumulator buffer is allocated by the forward and cleared by the projection kernel — a SECOND backward of the
+        same frame (retain_graph) must clear it itself and return the same gradients;
+      * below its SH degree `f_rest.grad` is an alias of one persistent zero buffer: it must read as zeros, survive being modified in
+        place (the next backward hands out zeros again), accumulate over two backward passes, and a no-grad render must not
+        allocate anything for a backward."""
+    from instantsplat_amd import _lib
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.fused_ssim import fused_l1_ssim_loss
+    from instantsplat_amd.gaussian_renderer import render
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training
+    sc = syn_pointmap(2, Wm, Wm, W, H, seed=9)
+    cuda = torch.device(dev).type == "cuda"
+    try:
+        with _with_binding("compiled"):
+            st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+            g, cam = st.gaussians, st.cameras[0]
+            names = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation", "P")
+            pkg = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+            vis = pkg["visibility_filter"]
+            assert vis.dtype == torch.bool and vis.shape == pkg["radii"].shape and torch.equal(vis, pkg["radii"] > 0) and bool(vis.any())
+            with torch.no_grad():
+                pkg0 = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+            assert torch.equal(pkg0["visibility_filter"], vis) and pkg0["render"].grad_fn is None
+            loss, _ = fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), 0.2)
+            loss.backward(retain_graph=True)
+            first = {n: getattr(g, n).grad.clone() for n in names}
+            fr = g._features_rest.grad
+            assert fr is not None and float(fr.abs().max()) == 0.0
+            for n in names + ("_features_rest",):
+                getattr(g, n).grad = None
+            loss.backward()                                         # the same frame again: the accumulators were used once already
+            for n in names:
+                bound("dropin_housekeeping/second_backward" + n, rel_l2(getattr(g, n).grad, first[n]), 2e-4 if cuda else 0.0)
+            # ---- the shared zero gradient
+            g._features_rest.grad.add_(1.0)                          # an in-place edit the version counter sees
+            for n in names + ("_features_rest",):
+                getattr(g, n).grad = None
+            pkg = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+            fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), 0.2)[0].backward()
+            assert float(g._features_rest.grad.abs().max()) == 0.0   # zeros again, not the polluted buffer
+            pkg = render(st.cameras[1], g, st.pipe, st.background, camera_pose=g.get_RT(1))
+            fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[1].unsqueeze(0), 0.2)[0].backward()   # accumulates: zeros += zeros
+            assert float(g._features_rest.grad.abs().max()) == 0.0
+            ext = _lib.compiled()
+            was = ext.shared_zero_grad(False)
+            try:
+                for n in names + ("_features_rest",):
+                    getattr(g, n).grad = None
+                pkg = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+                fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), 0.2)[0].backward()
+                a = g._features_rest.grad
+                a.data.fill_(3.0)                                    # behind the version counter: harmless with a private tensor
+                for n in names + ("_features_rest",):
+                    getattr(g, n).grad = None
+                pkg = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+                fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), 0.2)[0].backward()
+                assert float(g._features_rest.grad.abs().max()) == 0.0
+            finally:
+                ext.shared_zero_grad(was)
+    finally:
         BinningPolicy.reset("exact")
 
 

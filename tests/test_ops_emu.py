@@ -72,6 +72,10 @@ def test_fused_synced_loop_equals_autograd_loop(emu, overflow):
     ops_util.check_fused_synced_loop_equals_autograd_loop(emu, force_overflow=overflow)
 
 
+def test_dropin_node_housekeeping(emu):
+    ops_util.check_dropin_node_housekeeping(emu)
+
+
 def test_synced_one_call_loop_can_be_left_and_reentered(emu):
     ops_util.check_synced_one_call_loop_can_be_left_and_reentered(emu)
 
@@ -149,7 +153,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.mi355gs_abi_version.restype = ctypes.c_int
-    assert lib.mi355gs_abi_version() == 6
+    assert lib.mi355gs_abi_version() == 7
 
 
 def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):

@@ -64,6 +64,10 @@ def test_fused_synced_loop_equals_autograd_loop(gpu, overflow):
     ops_util.check_fused_synced_loop_equals_autograd_loop(gpu, force_overflow=overflow, iters=12, Wm=48, W=96)
 
 
+def test_dropin_node_housekeeping(gpu):
+    ops_util.check_dropin_node_housekeeping(gpu, Wm=48, W=128, H=96)
+
+
 def test_synced_one_call_loop_can_be_left_and_reentered(gpu):
     ops_util.check_synced_one_call_loop_can_be_left_and_reentered(gpu, Wm=48, W=96)
 
