@@ -122,6 +122,12 @@ def setup_training(scene, device, opt: OptimizationParams | None = None, pipe: P
     return TrainState(student, cams, gts, bg, opt, pipe)
 
 
+def hint_key(st, cam):
+    """Key of a training view in BinningPolicy's process-wide tables: the view of THIS scene (two training states in one
+    process — two scenes, or a state and its copy — must not read each other's instance counts)."""
+    return ("train", id(st.gaussians), cam.uid)
+
+
 def _pick_camera(st: TrainState):
     """reference train.py:152-157: pop a random view from the stack, refilling it when empty."""
     if not st.viewpoint_stack:
@@ -141,7 +147,7 @@ def _forward_backward_step(st: TrainState, fused_loss: bool):
     cam = _pick_camera(st)
     pose = g.get_RT(cam.uid)
     bg = torch.rand(3, device=st.background.device) if opt.random_background else st.background
-    with binning_hint(("train", cam.uid), tag=it):
+    with binning_hint(hint_key(st, cam), tag=it):
         pkg = render(cam, g, st.pipe, bg, camera_pose=pose)
     image = pkg["render"]
     gt = st.gt_images[cam.uid]
@@ -208,9 +214,9 @@ def _fused_synced_iteration(st: TrainState):
         st._prepared = None
         with torch.no_grad():
             for cam in st.cameras:  # exact instance counts of every view size the fixed buffers
-                with binning_hint(("train", cam.uid)):
+                with binning_hint(hint_key(st, cam)):
                     render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
-        need = max(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
+        need = max(BinningPolicy.known[hint_key(st, c)] for c in st.cameras)
         tr = st._trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
         # loss and instance count are stored by the kernels that produce them straight into two words of pinned, device-mapped
         # host memory (count as int32: a float32 detour would round counts above 2^24, reachable at 1 M Gaussians / 1080p, and
@@ -232,7 +238,7 @@ def _fused_synced_iteration(st: TrainState):
     if tr.dev.type == "cuda":
         torch.cuda.current_stream(tr.dev).synchronize()
     loss, r = float(st._loss_slot[0]), int(st._host_words[1])
-    BinningPolicy.known[("train", cam.uid)] = int(r)
+    BinningPolicy.known[hint_key(st, cam)] = int(r)
     if r > tr.capacity:   # dropped instances (the device left the update out): redo exactly, and grow the buffers for the next iterations
         _restore_host_state(st, tr, saved)
         tr.close()
@@ -408,7 +414,7 @@ class FusedTrainer:
             return cam
         # asynchronous verification of the instance count (same bookkeeping as the bounded BinningPolicy): the count is in its
         # pinned slot once the event recorded behind the step has completed
-        with binning_hint(("train", cam.uid), tag=a["it"]):
+        with binning_hint(hint_key(self.st, cam), tag=a["it"]):
             BinningPolicy.defer(count_out, self.capacity, self.dev, event=record_event)
         return cam
 
@@ -453,12 +459,12 @@ class RunAhead:
         st = self.st
         with torch.no_grad():
             for cam in st.cameras:
-                if ("train", cam.uid) not in BinningPolicy.known:
+                if hint_key(st, cam) not in BinningPolicy.known:
                     mode, BinningPolicy.mode = BinningPolicy.mode, "exact"
-                    with binning_hint(("train", cam.uid)):
+                    with binning_hint(hint_key(st, cam)):
                         render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
                     BinningPolicy.mode = mode
-        need = max(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
+        need = max(BinningPolicy.known[hint_key(st, c)] for c in st.cameras)
         if self.trainer is not None:
             self.trainer.close()
         self.trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
@@ -534,7 +540,7 @@ class RunAhead:
         self.st.last_loss = losses[-1]
         self.n_in_window = 0
         if self.trainer is not None:  # grow the fixed-capacity buffers before the scene outgrows them
-            need = max(BinningPolicy.known.get(("train", c.uid), 0) for c in self.st.cameras)
+            need = max(BinningPolicy.known.get(hint_key(self.st, c), 0) for c in self.st.cameras)
             if need * 1.2 + 1024 > self.trainer.capacity:
                 self._make_trainer()
         self._snapshot()

@@ -691,7 +691,7 @@ def check_commit_gate_leaves_an_overflowed_step_uncommitted(dev, Wm=12, W=32):
     from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
     from instantsplat_amd.gaussian_renderer import render
     from instantsplat_amd.synthetic import syn_pointmap
-    from instantsplat_amd.train import FusedTrainer, binning_hint, setup_training
+    from instantsplat_amd.train import FusedTrainer, binning_hint, hint_key, setup_training
     sc = syn_pointmap(3, Wm, Wm, W, W, seed=19)
     st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
     g = st.gaussians
@@ -699,9 +699,9 @@ def check_commit_gate_leaves_an_overflowed_step_uncommitted(dev, Wm=12, W=32):
         BinningPolicy.reset("exact")
         with torch.no_grad():
             for cam in st.cameras:
-                with binning_hint(("train", cam.uid)):
+                with binning_hint(hint_key(st, cam)):
                     render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
-        need = min(BinningPolicy.known[("train", c.uid)] for c in st.cameras)
+        need = min(BinningPolicy.known[hint_key(st, c)] for c in st.cameras)
         words = torch.zeros(2, dtype=torch.int32, pin_memory=(torch.device(dev).type == "cuda"))
         loss_slot = words[0:1].view(torch.float32)
         sync = (lambda: torch.cuda.synchronize(dev)) if torch.device(dev).type == "cuda" else (lambda: None)
@@ -712,7 +712,7 @@ def check_commit_gate_leaves_an_overflowed_step_uncommitted(dev, Wm=12, W=32):
                 s_ = g.optimizer.state[getattr(g, n)]
                 out += [s_["exp_avg"].clone(), s_["exp_avg_sq"].clone()]
             return out
-        big = FusedTrainer(st, 4 * max(BinningPolicy.known[("train", c.uid)] for c in st.cameras) + 1024)
+        big = FusedTrainer(st, 4 * max(BinningPolicy.known[hint_key(st, c)] for c in st.cameras) + 1024)
         before = state()
         big.step(loss_slot, verify_async=False, count_out=words[1:2])     # fits: commits (moments become non-zero)
         sync()

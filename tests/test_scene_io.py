@@ -194,3 +194,27 @@ def test_optimizer_relays_out_a_column_major_parameter(emu):
             opt.step()
         outs.append(p.detach().clone())
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], base.t())
+
+
+def test_eval_layout_reads_poses_from_sparse_1(tmp_path):
+    """`--eval` (reference scene/dataset_readers.py:317-322,336-340): cameras and poses come from sparse_<n>/1, the points still
+    from sparse_<n>/0, and train and test camera lists are the same cameras."""
+    from instantsplat_amd.synthetic import syn_pointmap
+    sc = syn_pointmap(3, 4, 4, 24, 16, seed=8)
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.rand(3, 16, 24, generator=g) for _ in range(3)]
+    w2c = [c.world_view_transform.t().double().numpy() for c in sc.cameras]
+    fovs = [(c.FoVx, c.FoVy) for c in sc.cameras]
+    scene_io.write_init_scene(str(tmp_path), w2c, fovs, imgs, sc.points, sc.colors, sc.confidence)
+    shifted = [m.copy() for m in w2c]
+    for m in shifted:
+        m[:3, 3] += 0.25                                   # the "test" poses differ from the training ones
+    scene_io.write_init_scene(str(tmp_path), shifted, fovs, imgs, sc.points, sc.colors, None, subdir="1")
+    assert not os.path.exists(tmp_path / "sparse_3" / "1" / "points3D.ply")
+    tr = scene_io.load_init_scene(str(tmp_path), 3, device="cpu", shuffle=False)
+    ev = scene_io.load_init_scene(str(tmp_path), 3, device="cpu", shuffle=False, eval=True)
+    assert tr.test_cameras == [] and len(ev.test_cameras) == len(ev.cameras) == 3
+    for a, b, c in zip(tr.cameras, ev.cameras, ev.test_cameras):
+        assert np.allclose(b.world_view_transform.t().numpy()[:3, 3], a.world_view_transform.t().numpy()[:3, 3] + 0.25, atol=1e-6)
+        assert torch.equal(b.world_view_transform, c.world_view_transform) and torch.equal(b.original_image, a.original_image)
+    assert torch.equal(ev.points, tr.points) and ev.cameras_extent == pytest.approx(tr.cameras_extent, rel=1e-6)
