@@ -217,4 +217,5 @@ def test_eval_layout_reads_poses_from_sparse_1(tmp_path):
     for a, b, c in zip(tr.cameras, ev.cameras, ev.test_cameras):
         assert np.allclose(b.world_view_transform.t().numpy()[:3, 3], a.world_view_transform.t().numpy()[:3, 3] + 0.25, atol=1e-6)
         assert torch.equal(b.world_view_transform, c.world_view_transform) and torch.equal(b.original_image, a.original_image)
-    assert torch.equal(ev.points, tr.points) and ev.cameras_extent == pytest.approx(tr.cameras_extent, rel=1e-6)
+    assert torch.equal(ev.points, tr.points)                       # ... the points of sparse_<n>/0
+    assert ev.cameras_extent == float(scene_io.get_nerfpp_norm(ev.info.train_cameras)["radius"]) != tr.cameras_extent   # extent of the cameras read
