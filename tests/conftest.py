@@ -20,7 +20,13 @@ def emu_lib_path():
     """g++ build of the UNMODIFIED kernel sources against the SIMT emulator (tests/emu), and the compiled PyTorch binding
     (host code only; a no-op when __graft_entry__.build() has already made it) that the operators go through by default."""
     subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "instantsplat_amd", "csrc_torch", "build.py")])
+    if torch.version.hip is None:
+        # a CPU-only PyTorch wheel has no ATen/hip headers or libc10_hip to build the compiled binding against: the emulated
+        # tier then runs through the ctypes binding (same C-ABI calls), and the tests that compare the two bindings skip
+        from instantsplat_amd import _lib
+        os.environ["MI355GS_BINDING"] = _lib.BINDING = "ctypes"
+    else:
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "instantsplat_amd", "csrc_torch", "build.py")])
     return os.path.join(ROOT, "tests", "emu", "libmi355gs_emu.so")
 
 

@@ -1020,6 +1020,10 @@ def _with_binding(name):
     import contextlib
     from instantsplat_amd import _lib
 
+    if name == "compiled" and torch.version.hip is None:
+        import pytest
+        pytest.skip("the compiled binding needs a ROCm build of PyTorch (tests/conftest.py falls back to ctypes)")
+
     @contextlib.contextmanager
     def cm():
         prev, _lib.BINDING = _lib.BINDING, name
