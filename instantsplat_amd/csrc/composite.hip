@@ -353,6 +353,17 @@ constexpr bool BW_REDUCE_LDS = GS_BW_LDS != 0;
 // 15 adds, two quad_perm steps and lanes 0, 4, .., 32 hold the nine sums.  The LDS crossbar moves the data on its own pipe;
 // the VALU is left with the additions (~40 issue cycles instead of ~128 for the register-transposed form).
 constexpr int RED_PITCH = 68;
+// GS_BW_HALF: every 64-instance unit of the one-chunk instantiation is replayed by TWO waves that never meet: the BACK half of
+// the unit (instances 32..63) back to front from the unit's far boundary record, exactly as before, and the FRONT half
+// (instances 0..31) FRONT TO BACK from the near boundary record (= the previous unit's far record; T = 1, C = 0 for a tile's
+// first unit).  The forward already leaves both records (one per 64 instances): nothing changes on its side.  Front to back,
+// the colour behind Gaussian k is dL/dC . (C_out - C accumulated through k) — the same running scalar, walked the other way —
+// and the transmittance is the forward's own product T (1 - alpha), no division.  Twice the waves, half the length: the
+// backward of a 512^2 frame is ~1.84 resident rounds of 64-instance units whose last third runs below four waves per SIMD
+// (tools/probe_bwd.py), and the tail is as long as a unit.
+#ifndef GS_BW_HALF
+#define GS_BW_HALF 0
+#endif
 constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgroups give the dispatcher the finest grain (129.4 -> 128.2 us at C3 against 4)
 
 // CHUNKS: 64-instance chunks per unit (1, or 0 = the frame's own value from meta[2] for the longer units of big frames; the
@@ -385,8 +396,12 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
   // one tile and re-read the same 8 KiB of per-pixel state, so they should share an L2: inside every block of 8 * BW_XCD_RUN
   // launch positions the index is transposed, and units RUN b .. RUN b + RUN - 1 of the block all land on XCD b.
   static_assert(BW_UNITS == 1, "the XCD transposition below is written for one unit per workgroup");
-  const uint32_t pos = blockIdx.x, in_block = pos % (8u * BW_XCD_RUN);
-  const uint32_t unit = pos - in_block + (in_block & 7u) * BW_XCD_RUN + (in_block >> 3);
+  constexpr bool HALVES = GS_BW_HALF != 0 && CHUNKS == 1;
+  constexpr uint32_t PER_UNIT = HALVES ? 2u : 1u;   // launch positions per unit; the two halves of a unit are neighbours on one XCD
+  const uint32_t pos = blockIdx.x, in_block = pos % (8u * BW_XCD_RUN * PER_UNIT);
+  const uint32_t hu = pos - in_block + (in_block & 7u) * (BW_XCD_RUN * PER_UNIT) + (in_block >> 3);
+  const uint32_t unit = hu / PER_UNIT;
+  const bool fwd_dir = HALVES && (hu & 1u) == 0u;   // wave-uniform: this wave replays the unit's front half, front to back
   if (unit >= min(meta[1], max_units)) return;  // wave-uniform; no workgroup barrier below
   // The one-chunk instantiation is launched when the CAPACITY cannot need longer units; a frame that overflowed its capacity
   // may still have been laid out in longer ones (k_scan_tiles decides from the true count).  Such a frame is discarded by its
@@ -407,8 +422,9 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
   const uint32_t slot = __builtin_amdgcn_readfirstlane(entry.z);
   if (slot >= max_units) return;   // (a frame that overflowed its buffers)
   float4 brec[4];
+  const uint32_t bslot = (fwd_dir && seg > 0u) ? slot - 1u : slot;   // front half: the record at the unit's NEAR boundary
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) brec[qd] = bstate[(size_t)slot * 256 + qd * 64 + lane];
+  for (int qd = 0; qd < 4; ++qd) brec[qd] = bstate[(size_t)bslot * 256 + qd * 64 + lane];
   const int tx = (int)(where & 0xFFFFu), ty = (int)(where >> 16);
   const int tile = ty * gx + tx;
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
@@ -441,7 +457,8 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
     if (!(px < W && py < H)) { Tr[qd] = 0.f; lastq[qd] = 0; g0[qd] = g1[qd] = g2[qd] = 0.f; }   // outside the image
   }
 #undef GS_PIN4
-  if (end <= start + boff) return;
+  const uint32_t hlo = boff + ((HALVES && !fwd_dir) ? (uint32_t)GS_SEG / 2u : 0u);   // first instance this wave replays
+  if (end <= start + hlo) return;
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     behind[qd] = Tr[qd] * (bg0 * g0[qd] + bg1 * g1[qd] + bg2 * g2[qd]);  // dL/dC . (everything behind, background included)
@@ -449,8 +466,18 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
   }
   // the tile only needs instances [0, max over pixels of last)
   const uint32_t tile_max = min(max(max(wmaxq[0], wmaxq[1]), max(wmaxq[2], wmaxq[3])), end - start);
-  if (tile_max <= boff) return;  // every pixel's last contributor lies in front of this segment
-  if (boff + seg_len < tile_max) {
+  if (tile_max <= hlo) return;  // every pixel's last contributor lies in front of this segment
+  if (fwd_dir) {
+    // front to back from the near boundary: T in front of the unit, and dL/dC . (C_out - C accumulated in front of it) —
+    // everything from this unit's first instance to the background
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const bool first = seg == 0u;
+      const float c0 = first ? 0.f : brec[qd].y, c1 = first ? 0.f : brec[qd].z, c2 = first ? 0.f : brec[qd].w;
+      Tr[qd] = first ? 1.f : brec[qd].x;
+      behind[qd] = (oc0[qd] - c0) * g0[qd] + (oc1[qd] - c1) * g1[qd] + (oc2[qd] - c2) * g2[qd];
+    }
+  } else if (boff + seg_len < tile_max) {
     // not the deepest active unit of the tile: resume from the forward's record at this unit's far boundary
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -499,14 +526,25 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
           const float av = valid ? au : 0.f;
           const float al = __builtin_amdgcn_fmed3f(av, 0.0f, 0.99f);     // min(0.99, av) for av >= 0: one v_med3_f32
           const float inv_one_m = __builtin_amdgcn_rcpf(1.f - al);        // v_rcp_f32 (1 ulp) instead of two IEEE divisions
-          Tr[qd] = Tr[qd] * inv_one_m;                                    // transmittance in front of this Gaussian
           // dC/dalpha_k = c_k T_k - (sum_{j behind k} c_j alpha_j T_j + T_final bg) / (1 - alpha_k).  Contracted with
           // dL/dC first, the "colour behind" term is ONE running scalar (behind) instead of the reference's three-channel
           // accum_rec / last_color / last_alpha recursion (same quantity: accum_rec_k = sum_{j>k} c_j alpha_j T_j / T_{k+1}).
           const float cg = a2.x * g0[qd] + a2.y * g1[qd] + a2.z * g2[qd];
-          const float dL_dalpha = Tr[qd] * cg - behind[qd] * inv_one_m;
-          const float dchannel = al * Tr[qd];
-          behind[qd] += cg * dchannel;
+          float dL_dalpha, dchannel;
+          if (HALVES && fwd_dir) {
+            // front to back (wave-uniform branch): Tr is the transmittance in FRONT of this Gaussian already, `behind` still
+            // contains this Gaussian's own contribution — take it out, then step T forward with the forward's own product
+            dchannel = al * Tr[qd];
+            const float bk = behind[qd] - cg * dchannel;
+            dL_dalpha = Tr[qd] * cg - bk * inv_one_m;
+            behind[qd] = bk;
+            Tr[qd] = Tr[qd] * (1.f - al);
+          } else {
+            Tr[qd] = Tr[qd] * inv_one_m;                                  // transmittance in front of this Gaussian
+            dL_dalpha = Tr[qd] * cg - behind[qd] * inv_one_m;
+            dchannel = al * Tr[qd];
+            behind[qd] += cg * dchannel;
+          }
           // Moments of w = G * dL/dG over the Gaussian's pixels: every screen-space gradient of this Gaussian is a fixed
           // linear combination of them (coefficients = its own conic / opacity), applied once per Gaussian in
           // k_preprocess_bwd instead of once per pixel here:
@@ -622,30 +660,37 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
         mq[qd] = chunk < max_chunks ? (hm[qd] & keep) : 0ull;
       }
     }
+    if constexpr (HALVES) {
+      const unsigned long long mine = fwd_dir ? 0x00000000ffffffffull : 0xffffffff00000000ull;   // this wave's half of the unit
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) mq[qd] &= mine;
+    }
     unsigned long long many = (mq[0] | mq[1]) | (mq[2] | mq[3]);
     if (!many) continue;
+    // the next instance of the walk: the deepest remaining one back to front, the nearest one front to back (scalar)
+    auto top = [&](unsigned long long m) { return (HALVES && fwd_dir) ? (int)__builtin_ctzll(m) : 63 - __clzll((long long)m); };
     // back-to-front walk over the union mask, unrolled by two with ping-pong record registers: the next record's LDS reads
     // (wave-uniform addresses: broadcasts) are issued before the current record's math
     auto xy = [&](int i) { const float4& r = recl[i][0]; return make_float2(r.x, r.y); };   // the walk only needs the centre
-    int iA = 63 - __clzll((long long)many), iB = iA;
+    int iA = top(many), iB = iA;
     float2 A0 = xy(iA), B0 = A0;
     float4 A1 = recl[iA][1], A2 = recl[iA][2], B1 = A1, B2 = A2;
     for (;;) {
       many &= ~(1ull << iA);
       const bool moreB = many != 0;
-      if (moreB) iB = 63 - __clzll((long long)many);
+      if (moreB) iB = top(many);
       B0 = xy(iB); B1 = recl[iB][1]; B2 = recl[iB][2];
       replay_one(A0, A1, A2, iA);
       if (!moreB) break;
       many &= ~(1ull << iB);
       const bool moreA = many != 0;
-      if (moreA) iA = 63 - __clzll((long long)many);
+      if (moreA) iA = top(many);
       A0 = xy(iA); A1 = recl[iA][1]; A2 = recl[iA][2];
       replay_one(B0, B1, B2, iB);
       if (!moreA) break;
     }
   }
-  GS_PROBE_STORE(4096u + unit, pr_t0, GS_PROBE_CLOCK(), pr_steps, pr_t1 - pr_t0, (unsigned long long)tile, (unsigned long long)seg,
+  GS_PROBE_STORE(4096u + (HALVES ? hu : unit), pr_t0, GS_PROBE_CLOCK(), pr_steps, pr_t1 - pr_t0, (unsigned long long)tile, (unsigned long long)seg,
                  (unsigned long long)gs_physical_cu(), (unsigned long long)blockIdx.x);
   if constexpr (COUNT) {
     if (lane == 0 && counters) {
@@ -718,8 +763,11 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units, bool may_loop, const unsigned long long* hitmask, uint32_t max_chunks,
                             const uint32_t* qmax, unsigned long long* counters) {
-  const uint32_t blk = 8u * BW_XCD_RUN;   // whole blocks of launch positions (see the index transposition in the kernel)
-  const dim3 grid((max_units + blk - 1u) / blk * blk);
+  // whole blocks of launch positions (see the index transposition in the kernel); with GS_BW_HALF the one-chunk instantiation
+  // takes two positions per unit
+  const uint32_t per_unit = (GS_BW_HALF != 0 && !may_loop) ? 2u : 1u;
+  const uint32_t blk = 8u * BW_XCD_RUN * per_unit;
+  const dim3 grid((max_units * per_unit + blk - 1u) / blk * blk);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
 #define GS_BWD(CH, CNT)                                                                                                               \
   hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \

@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from instantsplat_amd import _lib
-PROBE = os.path.join(ROOT, "instantsplat_amd", "lib", "libmi355gs_probe.so")
+PROBE = os.environ.get("GS_PROBE_LIB") or os.path.join(ROOT, "instantsplat_amd", "lib", "libmi355gs_probe.so")
 _lib._use_library_for_testing(PROBE)
 from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
 from instantsplat_amd.fused_ssim import fused_l1_ssim_loss
