@@ -79,7 +79,7 @@ def test_scene_trains_from_the_init_directory_and_exports(gpu, tmp_path):
     print("200 iterations: PSNR from disk %.3f -> %.3f dB, in memory %.3f -> %.3f / %.3f dB" % (a["psnr_before"], a["psnr_after"], b["psnr_before"],
                                                                                                b["psnr_after"], b2["psnr_after"]))
     assert abs(a["psnr_before"] - b["psnr_before"]) <= 0.02 and a["psnr_after"] > a["psnr_before"] + 3.0
-    assert abs(a["psnr_after"] - 0.5 * (b["psnr_after"] + b2["psnr_after"])) <= max(1.0, 2.0 * spread), (a["psnr_after"], b["psnr_after"], b2["psnr_after"])
+    assert abs(a["psnr_after"] - 0.5 * (b["psnr_after"] + b2["psnr_after"])) <= max(1.5, 2.0 * spread), (a["psnr_after"], b["psnr_after"], b2["psnr_after"])
     sa, sb = a["state"], b["state"]
     assert [c.colmap_id for c in sa.cameras] == [c.colmap_id for c in sb.cameras]
     assert sa.gaussians.spatial_lr_scale == pytest.approx(sb.gaussians.spatial_lr_scale, rel=1e-6)
