@@ -59,8 +59,8 @@ def read_cameras_text(path) -> Dict[int, ColmapCamera]:
         if not s or s[0] == "#":
             continue
         e = s.split()
-        if e[1] != "PINHOLE":
-            raise ValueError("only PINHOLE cameras are supported on this path (as in the reference loader)")
+        if e[1] not in ("PINHOLE", "SIMPLE_PINHOLE"):   # what reference scene/dataset_readers.py:129-138 takes without undistorting
+            raise ValueError("only PINHOLE / SIMPLE_PINHOLE cameras are supported on this path (as in the reference loader)")
         cams[int(e[0])] = ColmapCamera(int(e[0]), e[1], int(e[2]), int(e[3]), np.array([float(v) for v in e[4:]]))
     return cams
 
@@ -101,7 +101,7 @@ def write_images_text(path, imgs: Dict[int, ColmapImage]):
 
 def camera_fovs(cam: ColmapCamera) -> Tuple[float, float]:
     """PINHOLE intrinsics -> (FoVx, FoVy) as reference scene/dataset_readers.py:129-134 (focal2fov)."""
-    fx, fy = cam.params[0], cam.params[1]
+    fx, fy = cam.params[0], (cam.params[0] if cam.model == "SIMPLE_PINHOLE" else cam.params[1])
     return 2 * math.atan(cam.width / (2 * fx)), 2 * math.atan(cam.height / (2 * fy))
 
 

@@ -14,6 +14,8 @@ What the reference does between `init_geo.py`'s output directory and the first t
   load_cam                 utils/camera_utils.py:21-54 + utils/general_utils.py:21-27 (PILtoTorch): the image at `-r <resolution>`
                            as float32 [3,H,W] in [0,1]; width / height of the camera come from the IMAGE, FoV from cameras.txt
   scale_from_view_depth    utils/graphics_utils.py:107-135 (`--init_scale_from_view_depth`, off in the reference's scripts)
+  load_cameras             scene/dataset_readers.py:75-104 (loadCameras): stored poses (pose_optimized.npy, an interpolated path) back
+                           into the cameras, as render.py:206-207,235-236 does before it renders with them
   load_init_scene          scene/__init__.py:28-101 (Scene.__init__): input.ply + cameras.json into the model directory, the
                            seeded shuffle of the training cameras (uid = position after it), cameras on the device, and the
                            per-point learning-rate multipliers of train.py:63-85,95-96
@@ -117,9 +119,12 @@ def read_colmap_cameras(extrinsics: dict, intrinsics: dict, images_folder: str):
         poses.append(np.block([[R, T.reshape(3, 1)], [np.zeros((1, 3)), 1]]))
         image_path = os.path.join(images_folder, os.path.basename(extr.name))
         image_name = os.path.basename(image_path).split(".")[0]
-        if intr.model != "PINHOLE":   # (io_formats' reader already refuses anything else, like the layout's writer only emits this)
-            raise ValueError("Colmap camera model not handled: only PINHOLE cameras are written by InstantSplat's init")
-        fovy, fovx = focal2fov(intr.params[1], intr.height), focal2fov(intr.params[0], intr.width)
+        if intr.model == "SIMPLE_PINHOLE":     # reference :129-132: one focal for both axes
+            fovy, fovx = focal2fov(intr.params[0], intr.height), focal2fov(intr.params[0], intr.width)
+        elif intr.model == "PINHOLE":          # :133-137 (what InstantSplat's init writes)
+            fovy, fovx = focal2fov(intr.params[1], intr.height), focal2fov(intr.params[0], intr.width)
+        else:
+            raise ValueError("Colmap camera model not handled: only undistorted datasets (PINHOLE or SIMPLE_PINHOLE cameras) supported")
         infos.append(CameraInfo(uid=intr.id, R=R, T=T, FovY=fovy, FovX=fovx, image=Image.open(image_path), image_path=image_path,
                                 image_name=image_name, width=intr.width, height=intr.height))
     return infos, poses
@@ -234,6 +239,34 @@ def load_init_scene(source_path: str, n_views: int, images: Optional[str] = None
                      points=torch.from_numpy(np.ascontiguousarray(info.points)).float(),
                      colors=torch.from_numpy(np.ascontiguousarray(info.colors)).float(),
                      confidence_lr=load_confidence_lr(source_path, n_views, device), scale_gaussian=scale_gaussian, info=info, rng=rng)
+
+
+def load_cameras(poses: np.ndarray, cameras: List[Camera]) -> List[Camera]:
+    """reference scene/dataset_readers.py:75-104 (`loadCameras`): give the cameras the stored world-to-camera matrices — the
+    optimised poses of `pose/ours_<it>/pose_optimized.npy` ([V,4,4], one per camera: in place) or a longer interpolated path
+    ([N > V,4,4]: the camera list is repeated to N copies, renumbered uid 0.., colmap_id 1.., image_name "00000".. like the
+    reference's).  Sets R, T, world_view_transform, full_proj_transform, camera_center."""
+    import copy
+    poses = np.asarray(poses)
+
+    def place(cam, m):
+        R, T = np.transpose(m[:3, :3]), m[:3, 3]
+        dev = cam.world_view_transform.device
+        cam.R, cam.T = R, T
+        cam.world_view_transform = torch.tensor(get_world2view2(R, T)).transpose(0, 1).to(dev)
+        cam.full_proj_transform = cam.world_view_transform.unsqueeze(0).bmm(cam.projection_matrix.unsqueeze(0)).squeeze(0)
+        cam.camera_center = cam.world_view_transform.inverse()[3, :3]
+
+    if poses.shape[0] == len(cameras):
+        for cam, m in zip(cameras, poses):
+            place(cam, m)
+    elif poses.shape[0] > len(cameras):
+        repeat = int(np.ceil(poses.shape[0] / len(cameras)))
+        cameras = [copy.deepcopy(c) for c in cameras * repeat][:poses.shape[0]]
+        for idx, (cam, m) in enumerate(zip(cameras, poses)):
+            cam.uid, cam.colmap_id, cam.image_name = idx, idx + 1, str(idx).zfill(5)
+            place(cam, m)
+    return cameras
 
 
 # ---------------------------------------------------------------------------------------------------- writer (tests / export)

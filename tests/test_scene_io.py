@@ -219,3 +219,34 @@ def test_eval_layout_reads_poses_from_sparse_1(tmp_path):
         assert torch.equal(b.world_view_transform, c.world_view_transform) and torch.equal(b.original_image, a.original_image)
     assert torch.equal(ev.points, tr.points)                       # ... the points of sparse_<n>/0
     assert ev.cameras_extent == float(scene_io.get_nerfpp_norm(ev.info.train_cameras)["radius"]) != tr.cameras_extent   # extent of the cameras read
+
+
+def test_load_cameras_matches_reference_loadCameras():
+    """Stored poses back into the cameras (reference scene/dataset_readers.py:75-104, as render.py does with pose_optimized.npy
+    and with an interpolated path), against the reference's own function (tests/golden/make_golden_loadcameras.py)."""
+    from instantsplat_amd.camera import Camera
+    L = np.load(os.path.join(HERE, "golden", "loadcameras_vectors.npz"))
+    for tag in ("same", "longer"):
+        cams = [Camera(i, torch.from_numpy(scene_io.get_world2view2(L[f"lc_{tag}_in_R"][i], L[f"lc_{tag}_in_T"][i])), 0.9, 0.7, 8, 6,
+                       image=torch.zeros(3, 6, 8), colmap_id=i + 1, image_name=f"v{i}") for i in range(3)]
+        res = scene_io.load_cameras(L[f"lc_{tag}_poses"], cams)
+        assert [[c.uid, c.colmap_id] for c in res] == L[f"lc_{tag}_uid_colmap"].tolist() and [c.image_name for c in res] == list(L[f"lc_{tag}_names"])
+        assert np.array_equal(np.stack([c.R for c in res]), L[f"lc_{tag}_R"]) and np.array_equal(np.stack([c.T for c in res]), L[f"lc_{tag}_T"])
+        assert np.array_equal(np.stack([c.world_view_transform.numpy() for c in res]), L[f"lc_{tag}_world_view_transform"])
+        for k in ("full_proj_transform", "camera_center"):
+            assert np.allclose(np.stack([getattr(c, k).numpy() for c in res]), L[f"lc_{tag}_{k}"], rtol=0, atol=2e-6), k
+        if tag == "longer":
+            assert len(res) == 7 and res[3] is not cams[0]             # copies, not aliases of the three originals
+
+
+def test_simple_pinhole_cameras(tmp_path):
+    """reference scene/dataset_readers.py:129-132: one focal length for both axes"""
+    L = np.load(os.path.join(HERE, "golden", "loadcameras_vectors.npz"))
+    with open(tmp_path / "cameras.txt", "w") as f:
+        f.write("# header\n1 SIMPLE_PINHOLE 8 6 7.5 4.0 3.0\n")
+    cams = iof.read_cameras_text(tmp_path / "cameras.txt")
+    assert np.allclose(iof.camera_fovs(cams[1]), L["simple_pinhole_fov"], rtol=0, atol=1e-15)
+    with open(tmp_path / "bad.txt", "w") as f:
+        f.write("1 OPENCV 8 6 7.5 7.5 4.0 3.0 0 0 0 0\n")
+    with pytest.raises(ValueError):
+        iof.read_cameras_text(tmp_path / "bad.txt")

@@ -97,6 +97,8 @@ def test_scene_trains_from_the_init_directory_and_exports(gpu, tmp_path):
     with torch.no_grad():
         for cam in sa.cameras:
             gt = sa.gt_images[cam.uid]
+            # (scene_io.load_cameras — the reference's loadCameras — puts the stored matrix into the camera; the pose 7-vector
+            # render() wants is read back from it exactly as the reference's render_set does)
             p_file = get_tensor_from_camera(torch.from_numpy(poses[cam.colmap_id - 1])).to(gpu)
             assert torch.allclose(get_tensor_from_camera(torch.from_numpy(poses[cam.colmap_id - 1]))[4:], sa.gaussians.P[cam.uid, 4:].cpu(), atol=1e-5)
             for p, acc in ((sa.gaussians.get_RT(cam.uid), vals_exact), (p_file, vals_file)):
