@@ -547,6 +547,9 @@ struct AdamPlan {
   Tensor live;
   uint32_t seq = 0;
   std::vector<int64_t> moment_version;
+  // the Parameters themselves (set_owners): the steady-state step reads their `.grad` and clears it from here, so the optimizer's
+  // Python between the loss read-back and the Adam launch — the GPU has nothing queued in that stretch — is a dozen lines
+  std::vector<Tensor> owners;
 
   AdamPlan(std::vector<Tensor> p, std::vector<Tensor> m, std::vector<Tensor> v, std::vector<c10::optional<Tensor>> pp, double b1, double b2,
            double e)
@@ -573,6 +576,29 @@ struct AdamPlan {
         row.push_back(1);
       }
     }
+  }
+
+  void set_owners(std::vector<Tensor> o) {
+    TORCH_CHECK(o.size() == params.size(), "AdamPlan.set_owners: one Parameter per tensor");
+    owners = std::move(o);
+  }
+  // The step with the gradients read from the Parameters: false (nothing done) if a Parameter has no dense gradient or no
+  // longer is the tensor this plan was built for — the caller then takes the general path.
+  bool step_owned(const std::vector<double>& lr, const std::vector<int64_t>& step_counts) {
+    const size_t n = params.size();
+    if (owners.size() != n) return false;
+    std::vector<Tensor> grads(n);
+    for (size_t t = 0; t < n; ++t) {
+      const Tensor& g = owners[t].grad();
+      if (!g.defined() || g.is_sparse() || owners[t].data_ptr() != params[t].data_ptr() || g.numel() != numel[t]) return false;
+      grads[t] = g;
+    }
+    this->step(grads, lr, step_counts);
+    return true;
+  }
+  // optimizer.zero_grad(set_to_none=True) for the plan's Parameters
+  void zero_owned() {
+    for (Tensor& o : owners) o.mutable_grad().reset();
   }
 
   // grads[t]: the tensor's .grad; lr[t], step[t] (1-based, already incremented by the caller)
@@ -660,6 +686,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   py::class_<AdamPlan>(m, "AdamPlan")
       .def(py::init<std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, std::vector<c10::optional<Tensor>>, double, double, double>())
       .def("step", &AdamPlan::step)
+      .def("set_owners", &AdamPlan::set_owners)
+      .def("step_owned", &AdamPlan::step_owned)
+      .def("zero_owned", &AdamPlan::zero_owned)
       .def_readonly("last_used_gates", &AdamPlan::last_used_gates)
       .def_readonly("last_gate_note", &AdamPlan::last_gate_note);
 }

@@ -68,6 +68,10 @@ class PerPointAdam(Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         """Same contract as torch.optim.Optimizer.zero_grad (the reference calls it with set_to_none=True, train.py:211),
         without the per-call profiler scopes and hook dispatch of the generic implementation (~25 us per iteration)."""
+        fast = self.__dict__.get("_fast")
+        if set_to_none and fast is not None and fast[4] and fast[3] == sum(len(g["params"]) for g in self.param_groups):
+            fast[2].zero_owned()   # every parameter of the optimizer is one of the compiled plan's: cleared from C++
+            return
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is not None:
@@ -175,25 +179,25 @@ class PerPointAdam(Optimizer):
 
     def _step_fast(self, fast):
         """The steady state of a training loop — the same tensors with a gradient each as in the previous step, one (betas,
-        eps) batch, no weight decay — without rebuilding anything: validate, bump the step counts, one call into the compiled
-        plan.  Returns False (having changed nothing) when anything differs; the general path then takes the step."""
+        eps) batch, no weight decay — without rebuilding anything: validate, one call into the compiled plan (which reads the
+        gradients off the Parameters itself), bump the step counts.  Returns False (having changed nothing) when anything
+        differs; the general path then takes the step."""
         entries, plan = fast[1], fast[2]
-        grads, lrs = [], []
+        lrs, steps = [], []
         for group, p, st, ptr, sig, m in entries:
-            g = p.grad
-            if g is None or g.is_sparse or p.data_ptr() != ptr or st.get("exp_avg") is not m or group["weight_decay"] != 0 \
-                    or not self._same_sig(self._group_sig(group), sig):
+            pp = group.get("per_point_lr")
+            if st.get("exp_avg") is not m or group["weight_decay"] != 0 or group["betas"] != sig[0] or group["eps"] != sig[1] \
+                    or pp is not sig[2] or (pp is not None and pp.data_ptr() != sig[3]):
                 return False
-            grads.append(g)
             lrs.append(group["lr"])
-        steps = []
-        for _, _, st, _, _, _ in entries:
-            st["step"] += 1
-            steps.append(st["step"])
+            steps.append(st["step"] + 1)
         if not self.use_backward_gates:
             fast[0].forget_gates()
             fast[0].shared_zero_grad(False)   # gradients are edited behind the version counter: no shared zero buffer either
-        plan.step(grads, lrs, steps)
+        if not plan.step_owned(lrs, steps):   # a parameter without a (dense) gradient, or re-allocated: nothing was done
+            return False
+        for (_, _, st, _, _, _), k in zip(entries, steps):
+            st["step"] = k
         return True
 
     def _step(self, closure=None):
@@ -247,8 +251,9 @@ class PerPointAdam(Optimizer):
                 plan.step([p.grad for p in b["params"]], [group["lr"] for group in b["groups"]], [s_["step"] for s_ in b["states"]])
                 if len(batches) == 1 and len(live) == sum(len(g["params"]) for g in self.param_groups):
                     # every parameter of the optimizer took part, in one batch: remember the line-up for _step_fast
+                    plan.set_owners(list(b["params"]))
                     self._fast = (ext, [(g_, p_, s_, p_.data_ptr(), self._group_sig(g_), s_["exp_avg"]) for g_, p_, s_ in zip(b["groups"], b["params"], b["states"])],
-                                  plan, len(live))
+                                  plan, len(live), True)
                 continue
             ptrs = []
             keep = []
