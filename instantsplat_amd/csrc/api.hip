@@ -5,16 +5,16 @@
 
 // launchers implemented next to their kernels
 int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*,
-                             const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*, uint8_t*,
+                             const float*, const float*, const CamParams&, int32_t*, GsRec*, float*, uint2*, uint8_t*, float*, uint8_t*,
                              const GsPrologue&);
-int gs_launch_count_tiles(hipStream_t, int, int, int, const uint2*, uint32_t*);
+int gs_launch_count_tiles(hipStream_t, int, int, int, const uint2*, uint32_t*, uint32_t*, uint32_t*);
 int gs_launch_preprocess_bwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, int, int,
                              const CamParams&, const int32_t*, const GsRec*, const float*, const uint8_t*, const GsGrad*, float*, float*,
                              float*, float*, float*, float*, float*, float*, float*, float*, float*);
 int gs_launch_mark_visible(hipStream_t, int, const float*, const float*, uint8_t*);
 int gs_launch_scan_tiles(hipStream_t, int, const uint32_t*, uint32_t*, int32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
-int gs_launch_binning(hipStream_t, int, int, int, const GsRec*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t,
-                      const uint32_t*);
+int gs_launch_binning(hipStream_t, int, int, int, const float*, const uint2*, const uint32_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t,
+                      const uint32_t*, const uint32_t*, const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             float*, float*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint4*, float4*, uint32_t,
                             const uint32_t*, unsigned long long*, uint32_t, uint32_t*, unsigned long long*);
@@ -130,9 +130,10 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
   gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
-                           (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped), visible, pro);
+                           (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped), (float*)(g + gl.depth), visible, pro);
   GS_CHECK_LAUNCH("preprocess_fwd");
-  gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count));
+  gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count), (uint32_t*)(g + gl.bin_entries),
+                        (uint32_t*)(g + gl.bin_n));
   GS_CHECK_LAUNCH("count_tiles");
   gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered,
                        (uint32_t*)(t + tl.order), (uint32_t*)(t + tl.meta), (uint32_t*)(t + tl.seg_first), (uint32_t*)(t + tl.part_first));
@@ -152,9 +153,10 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
   const char* g = (const char*)geom;
   char* t = (char*)tiles;
   char* b = (char*)binning;
-  gs_launch_binning(stream, P, tl.T, tl.gx, (const GsRec*)(g + gl.rec), (const uint2*)(g + gl.rect),
+  gs_launch_binning(stream, P, tl.T, tl.gx, (const float*)(g + gl.depth), (const uint2*)(g + gl.rect),
                     (const uint32_t*)(t + tl.start), (uint32_t*)(t + tl.cursor), (uint64_t*)(b + bl.keys),
-                    (uint32_t*)(b + bl.list), cap, (const uint32_t*)(t + tl.order));
+                    (uint32_t*)(b + bl.list), cap, (const uint32_t*)(t + tl.order), (const uint32_t*)(g + gl.bin_entries),
+                    (const uint32_t*)(g + gl.bin_n));
   GS_CHECK_LAUNCH("binning");
   {
     ProfScope prof(0, stream);

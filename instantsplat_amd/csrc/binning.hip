@@ -25,12 +25,21 @@ constexpr int SORT_LDS_CAP = 8192;    // large kernel: 16/32 keys per thread, 64
 // (count and start may alias: every thread reads an element before it overwrites it)
 // With `order` set it also writes order[] = tile indices by descending count (counting sort over 1024 count buckets — exact
 // order inside a bucket is irrelevant for load balance): the per-tile kernels launch their heaviest tiles first.
-// STAGED (frames with more tiles than threads: 1080p has 8160): thread t owns `per` CONSECUTIVE tiles, so its reads of count[]
-// are `per` words apart from its neighbour's — every pass over the counts (sum, maximum, histogram, order, units, starts) was a
-// loop of strided, dependent global loads in a kernel that is one workgroup's latency chain (30.2 us at 8160 tiles).  The counts
-// are instead fetched ONCE, coalesced and all loads in flight together, into LDS in the owner-major transposed layout
-// [k][thread] (element k of thread t at k * SCAN_THREADS + t: conflict-free for every later pass), and the passes read LDS:
-// 23.7 us (profiles/r04_c4_1M_1080p_kernel_stats.csv).
+// STAGED (frames with more tiles than threads: 1080p has 8160): thread t owns `per` CONSECUTIVE tiles, so its accesses to the
+// per-tile arrays are `per` words apart from its neighbour's.  Both directions of that were the kernel (one workgroup = one CU's
+// memory pipe and one latency chain): every pass over the counts was a loop of strided, dependent global loads (30.2 us at 8160
+// tiles), and the four per-tile results (order, first unit, first short unit, start) left as 4 x 8160 single-word stores, one
+// cache line each — the workgroup's body took 13 us and the kernel 24 (tools/ubench/scan_tiles.hip: the store queue of one CU
+// drains a line per clock).  So the counts are fetched ONCE, coalesced and all loads in flight together, into LDS, each thread
+// takes its own run into registers, and every per-tile result goes back through the same LDS buffer and leaves as whole lines.
+#ifdef GS_SCAN_PROBE   // tools/ubench/scan_tiles.hip: phase stamps of the single workgroup (100 MHz wall clock), thread 0
+__device__ long long g_scan_probe[16];
+#define SCAN_STAMP(k) do { if (threadIdx.x == 0) g_scan_probe[k] = wall_clock64(); } while (0)
+#else
+#define SCAN_STAMP(k) do { } while (0)
+#endif
+constexpr int SCAN_PER_MAX = (int)(SCAN_STAGE_MAX_BYTES / (SCAN_THREADS * 4));   // tiles per thread the staged form holds in registers
+
 template <bool STAGED>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered,
                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
@@ -41,16 +50,38 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
   const int lo = tid * per, hi = min(T, lo + per);
+  SCAN_STAMP(0);
+  uint32_t own[STAGED ? SCAN_PER_MAX : 1];
   if constexpr (STAGED) {
-    for (int e = tid; e < T; e += SCAN_THREADS) s_stage[(e % per) * SCAN_THREADS + e / per] = count[e];
+    for (int e = tid; e < T; e += SCAN_THREADS) s_stage[e] = count[e];
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_MAX; ++k) own[k] = lo + k < hi ? s_stage[lo + k] : 0u;
   }
-  auto cnt = [&](int i) -> uint32_t {   // the count of tile i, lo <= i < hi (one of this thread's own)
-    if constexpr (STAGED) return s_stage[(i - lo) * SCAN_THREADS + tid];
-    else return count[i];
+  // f(i, c): tile i of this thread's run and its count
+  auto for_own = [&](auto&& f) {
+    if constexpr (STAGED) {
+#pragma unroll
+      for (int k = 0; k < SCAN_PER_MAX; ++k)
+        if (lo + k < hi) f(lo + k, own[k]);
+    } else {
+      for (int i = lo; i < hi; ++i) f(i, count[i]);
+    }
   };
+  // out[i] = value(i, c) for every tile: directly (one tile per thread: already coalesced), or through the LDS buffer
+  auto emit = [&](uint32_t* out, auto&& value) {
+    if constexpr (STAGED) {
+      __syncthreads();   // the buffer's previous readers
+      for_own([&](int i, uint32_t c) { s_stage[i] = value(i, c); });
+      __syncthreads();
+      for (int e = tid; e < T; e += SCAN_THREADS) out[e] = s_stage[e];
+    } else {
+      for_own([&](int i, uint32_t c) { out[i] = value(i, c); });
+    }
+  };
+  SCAN_STAMP(1);
   uint32_t local = 0;
-  for (int i = lo; i < hi; ++i) local += cnt(i);
+  for_own([&](int, uint32_t c) { local += c; });
   // wave inclusive scan (DPP: this single-workgroup kernel is a chain of latencies, and a __shfl_up step is an LDS round trip)
   const uint32_t incl = gs_wave_scan_incl_u32(local);
   if (lane == 63) wave_tot[wave] = incl;
@@ -62,12 +93,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     if (w < wave) wave_off += v;
     total += v;
   }
+  SCAN_STAMP(2);
   // ---- the tile order first: it reads count[], which the scan below may overwrite (count and start can alias)
   if (order) {
     __shared__ uint32_t hist[SCAN_THREADS];
     __shared__ uint32_t s_max;
     uint32_t mx = 0;
-    for (int i = lo; i < hi; ++i) mx = max(mx, cnt(i));
+    for_own([&](int, uint32_t c) { mx = max(mx, c); });
     mx = gs_wave_max_u32(mx);
     hist[tid] = 0u;
     if (tid == 0) s_max = 0u;
@@ -79,8 +111,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     // a 64-bit division per tile and pass — a hundred-odd instructions each on this latency chain)
     const float bscale = (float)(SCAN_THREADS - 1) / (float)cmax;
     auto bucket = [&](uint32_t c) { return (uint32_t)(SCAN_THREADS - 1) - min((uint32_t)(SCAN_THREADS - 1), (uint32_t)((float)c * bscale)); };
-    for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(cnt(i))], 1u);
+    SCAN_STAMP(3);
+    for_own([&](int, uint32_t c) { atomicAdd(&hist[bucket(c)], 1u); });
     __syncthreads();
+    SCAN_STAMP(4);
     // exclusive scan of the 1024 bucket sizes (one per thread)
     const uint32_t h = hist[tid];
     const uint32_t hi_ = gs_wave_scan_incl_u32(h);
@@ -93,8 +127,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
       if (w < wave) hoff += hist_wave[w];
     hist[tid] = hoff + hi_ - h;
     __syncthreads();
-    for (int i = lo; i < hi; ++i) order[atomicAdd(&hist[bucket(cnt(i))], 1u)] = (uint32_t)i;
+    SCAN_STAMP(5);
+    if constexpr (STAGED) {   // the permutation is built in LDS (the counts are in registers by now) and leaves as whole lines
+      for_own([&](int i, uint32_t c) { s_stage[atomicAdd(&hist[bucket(c)], 1u)] = (uint32_t)i; });
+      __syncthreads();
+      for (int e = tid; e < T; e += SCAN_THREADS) order[e] = s_stage[e];
+    } else {
+      for_own([&](int i, uint32_t c) { order[atomicAdd(&hist[bucket(c)], 1u)] = (uint32_t)i; });
+    }
     __syncthreads();
+    SCAN_STAMP(6);
   }
   if (seg_first) {
     // Backward units (common.h): the unit length of this frame from its true instance count, then the first unit of every tile
@@ -111,7 +153,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
     // ... and, in the same pass, the prefix of "this tile's last unit is a short one" (part_first): the backward launches
     // the full-length units first and the short ones last, where they shorten the tail of the kernel (composite.hip)
     uint32_t lseg = 0, lpart = 0;
-    for (int i = lo; i < hi; ++i) { lseg += units_of(cnt(i)); lpart += short_of(cnt(i)); }
+    for_own([&](int, uint32_t c) { lseg += units_of(c); lpart += short_of(c); });
     const uint32_t iseg = gs_wave_scan_incl_u32(lseg), ipart = gs_wave_scan_incl_u32(lpart);
     __shared__ uint32_t seg_wave[SCAN_THREADS / GS_WAVE];
     __shared__ uint32_t part_wave[SCAN_THREADS / GS_WAVE];
@@ -124,24 +166,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
       stot += seg_wave[w]; ptot += part_wave[w];
     }
     uint32_t srun = soff + iseg - lseg, prun = poff + ipart - lpart;
-    for (int i = lo; i < hi; ++i) {
-      seg_first[i] = srun; part_first[i] = prun;
-      srun += units_of(cnt(i));
-      prun += short_of(cnt(i));
-    }
+    emit(seg_first, [&](int, uint32_t c) { const uint32_t v = srun; srun += units_of(c); return v; });
+    emit(part_first, [&](int, uint32_t c) { const uint32_t v = prun; prun += short_of(c); return v; });
     if (tid == 0) { part_first[T] = ptot; meta[3] = ptot; }
     if (tid == 0) { seg_first[T] = stot; meta[1] = stot; meta[2] = chunks; }
   }
+  SCAN_STAMP(7);
   uint32_t run = wave_off + incl - local;
-  for (int i = lo; i < hi; ++i) {
-    const uint32_t c = cnt(i);
-    start[i] = run;
-    run += c;
-  }
+  // (count and start can alias: the staged form holds the counts in registers, the other reads count[i] right before it writes start[i])
+  emit(start, [&](int, uint32_t c) { const uint32_t v = run; run += c; return v; });
   if (tid == 0) {
     start[T] = total;
     *num_rendered = (int32_t)total;
   }
+  SCAN_STAMP(8);
 }
 
 // ---- large exclusive scan (used for the kNN cell table, up to 2^24 entries): per-block sums -> scan of the sums by
@@ -188,9 +226,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(int n, const uint32_t* __res
 // serialise at the L2.  The scatter kernel turns each private count into a reserved range of its
 // tile's segment (one returning global atomic), then hands out slots with returning LDS atomics.
 // Order inside a tile is arbitrary here; K4's sort makes it deterministic.
-constexpr int BIN_CHUNK = 512;   // Gaussians per workgroup: 384 workgroups at 196k Gaussians (2048 left 160 of 256 CUs idle)
+constexpr int BIN_CHUNK = GS_BIN_CHUNK;   // Gaussians per workgroup: 384 workgroups at 196k Gaussians (2048 left 160 of 256 CUs idle)
 static_assert(BIN_CHUNK == 512, "two Gaussians per thread (own_depth selection in k_scatter_lds)");
 constexpr int BIN_MAX_LDS_TILES = 16384;  // 64 KiB of LDS; larger grids use the direct-atomic kernels
+static_assert(BIN_MAX_LDS_TILES <= 64 * 256, "k_count_tiles_lds keeps one bit per bin of a thread in a 64-bit mask");
 
 __device__ __forceinline__ bool unpack_rect(uint2 r, int& x0, int& y0, int& x1, int& y1) {
   x0 = r.x & 0xffff; y0 = r.x >> 16; x1 = r.y & 0xffff; y1 = r.y >> 16;
@@ -247,12 +286,20 @@ __device__ __forceinline__ void for_each_instance(int lo, int hi, const uint2 (&
   }
 }
 
+// The count kernel also leaves what it learned for the scatter kernel of the same frame: the workgroup's touched tiles with
+// their private counts, packed (tile | count << 16; tile < 2^14, count <= BIN_CHUNK), at a fixed place per workgroup
+// (entries[GS_BIN_ENTRIES * workgroup ...], entry_n[workgroup]).  The scatter then neither zeroes a histogram over all tiles nor
+// walks every rectangle a second time to recount, nor sweeps all T bins for the non-empty ones — at 1080p that was 40 of its
+// 60 us with the key stores taken out (profiles/r04_ab_binning_c4_count_scatter.txt).  A workgroup that touches more than
+// GS_BIN_ENTRIES tiles says so (entry_n = ~0) and its scatter workgroup recounts as before.
 __global__ __launch_bounds__(256) void k_count_tiles_lds(int P, int T, int gx, const uint2* __restrict__ rects,
-                                                          uint32_t* __restrict__ tile_count) {
+                                                          uint32_t* __restrict__ tile_count, uint32_t* __restrict__ entries,
+                                                          uint32_t* __restrict__ entry_n) {
   HIP_DYNAMIC_SHARED(uint32_t, s_bins)
   __shared__ uint32_t s_wide[BIN_CHUNK];
   __shared__ uint2 s_wide_rect[BIN_CHUNK];
   __shared__ uint32_t s_nwide;
+  __shared__ uint32_t s_wave_nz[4];
   const int tid = threadIdx.x;
   const int lo = blockIdx.x * BIN_CHUNK, hi = min(P, lo + BIN_CHUNK);
   uint2 own[BIN_PER_THREAD];
@@ -263,15 +310,41 @@ __global__ __launch_bounds__(256) void k_count_tiles_lds(int P, int T, int gx, c
   __syncthreads();
   for_each_instance(lo, hi, own, rects, s_wide, s_wide_rect, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
   __syncthreads();
-  for (int t = tid; t < T; t += 256) {
-    const uint32_t c = s_bins[t];
-    if (c) atomicAdd(&tile_count[t], c);
+  // (which of this thread's bins were non-empty is kept as a bit mask — T <= 16384 is 64 bins per thread — so that writing
+  // the list below revisits those bins only)
+  unsigned long long mask = 0ull;
+  {
+    int k = 0;
+    for (int t = tid; t < T; t += 256, ++k) {
+      const uint32_t c = s_bins[t];
+      if (c) { atomicAdd(&tile_count[t], c); mask |= 1ull << k; }
+    }
+  }
+  const uint32_t nz = (uint32_t)__popcll(mask);
+  // this thread's run of the entry list: exclusive scan of the per-thread non-empty counts over the workgroup
+  const uint32_t incl = gs_wave_scan_incl_u32(nz);
+  if ((tid & 63) == 63) s_wave_nz[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t off = incl - nz, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < (tid >> 6)) off += s_wave_nz[w];
+    total += s_wave_nz[w];
+  }
+  if (tid == 0) entry_n[blockIdx.x] = total <= (uint32_t)GS_BIN_ENTRIES ? total : 0xffffffffu;
+  if (total > (uint32_t)GS_BIN_ENTRIES) return;
+  uint32_t* mine = entries + (size_t)blockIdx.x * GS_BIN_ENTRIES + off;
+  while (mask) {
+    const int t = tid + 256 * (__ffsll((long long)mask) - 1);
+    mask &= mask - 1ull;
+    *mine++ = (uint32_t)t | (s_bins[t] << 16);
   }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const GsRec* __restrict__ recs,
+__global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const float* __restrict__ depths,
                                                       const uint2* __restrict__ rects, const uint32_t* __restrict__ start,
-                                                      uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, uint32_t capacity) {
+                                                      uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, uint32_t capacity,
+                                                      const uint32_t* __restrict__ entries, const uint32_t* __restrict__ entry_n) {
   HIP_DYNAMIC_SHARED(uint32_t, s_bins)
   __shared__ uint32_t s_wide[BIN_CHUNK];
   __shared__ uint2 s_wide_rect[BIN_CHUNK];
@@ -285,36 +358,59 @@ __global__ __launch_bounds__(256) void k_scatter_lds(int P, int T, int gx, const
   for (int j = 0; j < BIN_PER_THREAD; ++j) {
     const int ic = min(lo + tid + 256 * j, P - 1);
     own[j] = rects[ic];
-    own_depth[j] = __float_as_uint(recs[ic].q2.w);
+    own_depth[j] = __float_as_uint(depths[ic]);
   }
-  for (int t = tid; t < T; t += 256) s_bins[t] = 0;
-  if (tid == 0) s_nwide = 0;
-  __syncthreads();
-  for_each_instance(lo, hi, own, rects, s_wide, s_wide_rect, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
-  __syncthreads();
-  // Private counts -> first slot of this workgroup's range in each touched tile.  Four returning atomics per thread are in
-  // flight before the first result is consumed (one at a time they were four dependent trips to the L2).
-  for (int t0 = 0; t0 < T; t0 += 1024) {
-    uint32_t c[4], r[4], st[4];
+  // Private counts -> first slot of this workgroup's range in each touched tile: from the count kernel's entry list (only
+  // the touched tiles' bins are written, and only those are read by the walk below) ...
+  const uint32_t n_entries = entry_n[blockIdx.x];
+  if (n_entries != 0xffffffffu) {
+    const uint32_t* mine = entries + (size_t)blockIdx.x * GS_BIN_ENTRIES;
+    // (four returning atomics per thread in flight before the first result is consumed)
+    for (uint32_t e0 = 0; e0 < n_entries; e0 += 1024) {
+      uint32_t en[4], r[4], st[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int t = t0 + tid + 256 * j;
-      c[j] = t < T ? s_bins[t] : 0u;
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t e = e0 + tid + 256 * j;
+        en[j] = e < n_entries ? mine[e] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j] = 0u; st[j] = 0u;
+        if (en[j]) { r[j] = atomicAdd(&cursor[en[j] & 0xffffu], en[j] >> 16); st[j] = start[en[j] & 0xffffu]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (en[j]) s_bins[en[j] & 0xffffu] = st[j] + r[j];
     }
+  } else {
+    // ... or, for a workgroup that touched more tiles than the list holds, by counting again
+    for (int t = tid; t < T; t += 256) s_bins[t] = 0;
+    if (tid == 0) s_nwide = 0;
+    __syncthreads();
+    for_each_instance(lo, hi, own, rects, s_wide, s_wide_rect, &s_nwide, [&](int, int, int x, int y) { atomicAdd(&s_bins[y * gx + x], 1u); });
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += 1024) {
+      uint32_t c[4], r[4], st[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int t = t0 + tid + 256 * j;
-      r[j] = 0u; st[j] = 0u;
-      if (c[j]) { r[j] = atomicAdd(&cursor[t], c[j]); st[j] = start[t]; }
+      for (int j = 0; j < 4; ++j) {
+        const int t = t0 + tid + 256 * j;
+        c[j] = t < T ? s_bins[t] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = t0 + tid + 256 * j;
+        r[j] = 0u; st[j] = 0u;
+        if (c[j]) { r[j] = atomicAdd(&cursor[t], c[j]); st[j] = start[t]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c[j]) s_bins[t0 + tid + 256 * j] = st[j] + r[j];
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (c[j]) s_bins[t0 + tid + 256 * j] = st[j] + r[j];
   }
   if (tid == 0) s_nwide = 0;
   __syncthreads();
   for_each_instance(lo, hi, own, rects, s_wide, s_wide_rect, &s_nwide, [&](int i, int j, int x, int y) {
-    const uint32_t depth = j == 0 ? own_depth[0] : (j == 1 ? own_depth[BIN_PER_THREAD - 1] : __float_as_uint(recs[i].q2.w));
+    const uint32_t depth = j == 0 ? own_depth[0] : (j == 1 ? own_depth[BIN_PER_THREAD - 1] : __float_as_uint(depths[i]));
     const uint64_t key = ((uint64_t)depth << 32) | (uint32_t)i;
     const uint32_t pos = atomicAdd(&s_bins[y * gx + x], 1u);
     if (pos < capacity) keys[pos] = key;
@@ -332,14 +428,14 @@ __global__ __launch_bounds__(256) void k_count_tiles_direct(int P, int gx, const
     for (int x = x0; x < x1; ++x) atomicAdd(&tile_count[y * gx + x], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_scatter_direct(int P, int gx, const GsRec* __restrict__ recs, const uint2* __restrict__ rects,
+__global__ __launch_bounds__(256) void k_scatter_direct(int P, int gx, const float* __restrict__ depths, const uint2* __restrict__ rects,
                                                          const uint32_t* __restrict__ start, uint32_t* __restrict__ cursor,
                                                          uint64_t* __restrict__ keys, uint32_t capacity) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   int x0, y0, x1, y1;
   if (!unpack_rect(rects[i], x0, y0, x1, y1)) return;
-  const uint64_t key = ((uint64_t)__float_as_uint(recs[i].q2.w) << 32) | (uint32_t)i;
+  const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
   for (int y = y0; y < y1; ++y)
     for (int x = x0; x < x1; ++x) {
       const int t = y * gx + x;
@@ -635,23 +731,26 @@ int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t
   return 0;
 }
 
-int gs_launch_count_tiles(hipStream_t stream, int P, int T, int gx, const uint2* rects, uint32_t* tile_count) {
+int gs_launch_count_tiles(hipStream_t stream, int P, int T, int gx, const uint2* rects, uint32_t* tile_count, uint32_t* entries,
+                          uint32_t* entry_n) {
   if (P <= 0) return 0;
   if (T <= BIN_MAX_LDS_TILES)
-    hipLaunchKernelGGL(k_count_tiles_lds, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), (size_t)T * 4, stream, P, T, gx, rects, tile_count);
+    hipLaunchKernelGGL(k_count_tiles_lds, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), (size_t)T * 4, stream, P, T, gx, rects, tile_count,
+                       entries, entry_n);
   else
     hipLaunchKernelGGL(k_count_tiles_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, rects, tile_count);
   return 0;
 }
 
-int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const GsRec* recs, const uint2* rects, const uint32_t* start,
-                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity, const uint32_t* order) {
+int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const float* depths, const uint2* rects, const uint32_t* start,
+                      uint32_t* cursor, uint64_t* keys, uint32_t* list, uint32_t capacity, const uint32_t* order, const uint32_t* entries,
+                      const uint32_t* entry_n) {
   if (P <= 0 || capacity == 0) return 0;
   if (T <= BIN_MAX_LDS_TILES)
-    hipLaunchKernelGGL(k_scatter_lds, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), (size_t)T * 4, stream, P, T, gx, recs, rects,
-                       start, cursor, keys, capacity);
+    hipLaunchKernelGGL(k_scatter_lds, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), (size_t)T * 4, stream, P, T, gx, depths, rects,
+                       start, cursor, keys, capacity, entries, entry_n);
   else
-    hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, recs, rects, start, cursor, keys, capacity);
+    hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, depths, rects, start, cursor, keys, capacity);
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order);
   return 0;
 }

@@ -34,14 +34,23 @@ struct alignas(16) GsGrad {
 
 static inline size_t gs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Binning (binning.hip): a workgroup counts / scatters GS_BIN_CHUNK consecutive Gaussians; the count kernel leaves each
+// workgroup's touched tiles as up to GS_BIN_ENTRIES packed (tile | count << 16) words for the scatter kernel of the same frame.
+constexpr int GS_BIN_CHUNK = 512;
+constexpr int GS_BIN_ENTRIES = 1024;
+
 struct GeomLayout {
-  size_t rec, cov3D, rect, clamped, total;
+  size_t rec, cov3D, rect, clamped, depth, bin_entries, bin_n, total;
   __host__ explicit GeomLayout(int P) {
     size_t n = P > 0 ? (size_t)P : 1, o = 0;
     rec = o; o += gs_align(n * sizeof(GsRec));
     cov3D = o; o += gs_align(n * 6 * sizeof(float));
     rect = o; o += gs_align(n * sizeof(uint2));
     clamped = o; o += gs_align(n);
+    depth = o; o += gs_align(n * sizeof(float));   // the view depth once more, densely: the scatter reads 4 B per Gaussian, not a 48-B record's line
+    const size_t chunks = (n + GS_BIN_CHUNK - 1) / GS_BIN_CHUNK;
+    bin_entries = o; o += gs_align(chunks * GS_BIN_ENTRIES * sizeof(uint32_t));
+    bin_n = o; o += gs_align(chunks * sizeof(uint32_t));
     total = o;
   }
 };

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, CamParams cp,
     int32_t* __restrict__ radii, GsRec* __restrict__ recs, float* __restrict__ cov3Ds, uint2* __restrict__ rects,
-    uint8_t* __restrict__ clamped, uint8_t* __restrict__ visible, GsPosed posed, GsPrologue pro) {
+    uint8_t* __restrict__ clamped, float* __restrict__ depths, uint8_t* __restrict__ visible, GsPosed posed, GsPrologue pro) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // The frame's accumulators are cleared by its first kernel — this one — instead of memsets in front of it (a 2-4 us launch
   // and a dependent-dispatch boundary each): the per-tile counters always; the backward's moment records (and the gate flags
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(
   rec.q1 = make_float4(-0.5f * GS_LOG2E * ca, -0.5f * GS_LOG2E * cc, -GS_LOG2E * cb, opac);
   rec.q2 = make_float4(rgb.x, rgb.y, rgb.z, pv.z);
   recs[i] = rec;
+  depths[i] = pv.z;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,13 +548,14 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 int gs_launch_preprocess_fwd(hipStream_t stream, int P, int D, int M, const float* means3D, const float* shs, const float* shs_rest,
                              const float* colors_precomp, const float* opacities, const float* scales,
                              const float* rotations, const float* cov3D_precomp, const CamParams& cp, int32_t* radii,
-                             GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped, uint8_t* visible, const GsPrologue& pro) {
+                             GsRec* recs, float* cov3Ds, uint2* rects, uint8_t* clamped, float* depths, uint8_t* visible,
+                             const GsPrologue& pro) {
   if (P <= 0) return 0;
   const bool posed = g_fused.posed.pose != nullptr;
   const GsPosed pa = posed ? g_fused.posed : GsPosed();
 #define GS_FWD(POSED, DEG)                                                                                                              \
   hipLaunchKernelGGL((k_preprocess_fwd<POSED, DEG>), dim3((P + 255) / 256), dim3(256), 0, stream, P, M, means3D, shs, shs_rest,         \
-                     colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, visible, pa, pro)
+                     colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii, recs, cov3Ds, rects, clamped, depths, visible, pa, pro)
   const int deg = shs ? D : 0;  // one instantiation per active SH degree: coefficient arrays stay in registers
   if (posed) { if (deg == 0) GS_FWD(true, 0); else if (deg == 1) GS_FWD(true, 1); else if (deg == 2) GS_FWD(true, 2); else GS_FWD(true, 3); }
   else { if (deg == 0) GS_FWD(false, 0); else if (deg == 1) GS_FWD(false, 1); else if (deg == 2) GS_FWD(false, 2); else GS_FWD(false, 3); }

@@ -319,7 +319,7 @@ def check_operator_error_behaviour(dev, tmp_path):
     assert color.shape == (3, 32, 48) and radii.shape == (64,) and bool(torch.isfinite(color).all())
 
 
-def check_tile_lists_against_oracle(dev, n, W=80, H=48, seed=5):
+def check_tile_lists_against_oracle(dev, n, W=80, H=48, seed=5, scale_boost=1.0, entry_counts=None):
     """The binning stage against the ORACLE's lists (SURVEY.md 8d asked for num_rendered within 0.01 %; the device bins to
     a tighter rectangle on purpose, preprocess.hip "tight tile rects", so the property is stated exactly instead):
       * every per-tile list of the device is a SUBSET of the oracle's list of that tile (the reference's 3-sigma rectangle),
@@ -341,7 +341,7 @@ def check_tile_lists_against_oracle(dev, n, W=80, H=48, seed=5):
     q = q / q.norm(dim=1, keepdim=True)
     # a mix of sizes and opacities: faint large Gaussians are the ones whose 3-sigma rectangle is much larger than their
     # alpha >= 1/255 footprint
-    scales = 0.01 + 0.08 * torch.rand(n, 3, generator=g) ** 2
+    scales = (0.01 + 0.08 * torch.rand(n, 3, generator=g) ** 2) * scale_boost
     opac = 0.005 + 0.9 * torch.rand(n, generator=g) ** 3
     col = torch.rand(n, 3, generator=g)
     tanx = math.tan(math.radians(60) / 2)
@@ -367,6 +367,12 @@ def check_tile_lists_against_oracle(dev, n, W=80, H=48, seed=5):
     start = tiles[2 * al(T * 4): 2 * al(T * 4) + (T + 1) * 4].cpu().view(torch.int32).numpy()
     lst = binning[al(R * 8): al(R * 8) + R * 4].cpu().view(torch.int32).numpy()
     rec = geom[: n * 48].cpu().view(torch.float32).reshape(n, 12).numpy().astype(np.float64)
+    if entry_counts is not None:
+        # what the count kernel handed the scatter kernel (common.h GeomLayout): per 512-Gaussian workgroup, the number of
+        # touched tiles it listed, or ~0 = "more than the list holds, count again"
+        chunks = (n + 511) // 512
+        off = al(n * 48) + al(n * 24) + al(n * 8) + al(n) + al(n * 4) + al(chunks * 1024 * 4)
+        entry_counts.extend(int(v) for v in geom[off: off + chunks * 4].cpu().view(torch.int32).numpy().astype(np.int64) & 0xffffffff)
 
     settings = RasterSettings(image_height=H, image_width=W, tanfovx=tanx, tanfovy=tany, bg=torch.zeros(3), scale_modifier=1.0,
                               viewmatrix=torch.eye(4), projmatrix=cam.projection_matrix.cpu(), sh_degree=0, campos=torch.zeros(3),

@@ -227,3 +227,14 @@ def test_more_tiles_than_scan_threads(emu):
     from tests.util import assert_raster_parity, run_blob_case
     assert_raster_parity(run_blob_case(emu, 700, 608, 480, 1, scale_mean=0.08))
     edge_cases.check_tile_lists_against_oracle(emu, 500, W=608, H=480)
+
+
+def test_scatter_takes_the_count_kernels_tile_list_or_recounts(emu):
+    """The count kernel hands each 512-Gaussian workgroup's touched tiles to the scatter kernel (up to 1024 of them); a workgroup
+    that touches more says so and the scatter recounts.  Both ways against the oracle's per-tile lists, on a 1140-tile frame:
+    small Gaussians (listed), and the same ones much larger (one workgroup over almost every tile: recount)."""
+    n_small, n_big = [], []
+    edge_cases.check_tile_lists_against_oracle(emu, 500, W=608, H=480, scale_boost=0.25, entry_counts=n_small)
+    edge_cases.check_tile_lists_against_oracle(emu, 500, W=608, H=480, scale_boost=2.0, entry_counts=n_big)
+    assert len(n_small) == 1 and 0 < n_small[0] <= 1024, n_small
+    assert n_big == [0xffffffff], n_big
