@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 7
+#define MI355GS_ABI_VERSION 8
 
 /* error codes */
 #define MI355GS_OK 0
@@ -256,6 +256,10 @@ int mi355gs_pose_backward(void* stream, int P, const float* xyz, const float* ro
  *   mi355gs_raster_forward_preprocess / _backward.
  *   backward: pose_scratch = device float[16 * ((P + 255) / 256) + 32]; d_f_rest may be null while D == 0 (the reference's
  *   gradient for it is all zero then); d_* receive dL/d(raw parameter), d_pose[7] dL/dpose.
+ *   pose_rows / pose_row (ABI v8): with pose_rows > 0, d_pose is the gradient of the WHOLE pose table the 7-vector was taken
+ *   from — float[pose_rows, 7] (reference scene/gaussian_model.py:134-136, `P[idx]`): row pose_row receives dL/dpose and every
+ *   other row is written 0, which is what autograd's backward of the row selection builds with a fill and a copy of its own.
+ *   pose_rows == 0: d_pose[7] as before.
  *   Also written: PerPointAdam's whole-tensor gate flags for these gradients, float[8] at grad_scratch +
  *   mi355gs_raster_grad_gate_offset(P): flag k > 0 <=> the gradient of group k (xyz, f_dc, f_rest, opacity, scaling,
  *   rotation, pose) has a non-zero element — what mi355gs_adam_multi_step(gate=...) consumes instead of re-reading them.
@@ -271,8 +275,8 @@ int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float
                            const float* origin, float tanfovx, float tanfovy, const void* geom, void* tiles, const void* binning,
                            int64_t capacity, const int32_t* radii, const float* out_color, const float* dL_dpix,
                            void* grad_scratch, float* pose_scratch, float* d_xyz, float* d_means2D, float* d_f_dc, float* d_f_rest,
-                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int grad_scratch_is_clear,
-                           int debug);
+                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int pose_rows, int pose_row,
+                           int grad_scratch_is_clear, int debug);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole train iteration in one call

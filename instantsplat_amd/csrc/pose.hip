@@ -113,7 +113,15 @@ __global__ __launch_bounds__(256) void k_pose_bwd(int P, const float* __restrict
 __global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __restrict__ pose, const float* __restrict__ partial, int nrows,
                                                                float* __restrict__ d_pose, float* __restrict__ pose_gate,
                                                                const float* __restrict__ loss_partial, int loss_nblocks,
-                                                               double loss_inv_n, float lambda_dssim, float* __restrict__ loss) {
+                                                               double loss_inv_n, float lambda_dssim, float* __restrict__ loss,
+                                                               int table_rows, int table_row) {
+  // d_pose may be a whole [table_rows, 7] pose-table gradient (what autograd's select-backward builds with a fill and a copy
+  // from the 7 values): row table_row gets the gradient, every other row is zeroed here
+  if (table_rows > 0) {
+    for (int i = threadIdx.x; i < table_rows * 7; i += 1024)
+      if (i / 7 != table_row) d_pose[i] = 0.f;
+    d_pose += 7 * table_row;
+  }
   __shared__ float s_sum[16][17];
   __shared__ float s_tot[16];
   // the rows of pose sums first: their loads are in flight while the loss partials are reduced (this kernel is pure latency)
@@ -168,9 +176,9 @@ __global__ __launch_bounds__(1024) void k_pose_finish_partials(const float* __re
 // projection kernel stores one row per workgroup instead of issuing atomics): deterministic tree sum, then pose_finish
 int gs_launch_pose_finish_partials(hipStream_t stream, const float* pose, const float* partial, int nrows, float* d_pose,
                                    float* pose_gate, const float* loss_partial, int loss_nblocks, double loss_inv_n,
-                                   float lambda_dssim, float* loss) {
+                                   float lambda_dssim, float* loss, int table_rows, int table_row) {
   hipLaunchKernelGGL(k_pose_finish_partials, dim3(1), dim3(1024), 0, stream, pose, partial, nrows, d_pose, pose_gate, loss_partial,
-                     loss_nblocks, loss_inv_n, lambda_dssim, loss);
+                     loss_nblocks, loss_inv_n, lambda_dssim, loss, table_rows, table_row);
   return 0;
 }
 

@@ -18,7 +18,8 @@
 
 int gs_loss_fused(hipStream_t, int, int, int, const float*, const float*, float, float*, void*);
 int gs_loss_fused_nblocks(int, int, int);
-int gs_launch_pose_finish_partials(hipStream_t, const float*, const float*, int, float*, float*, const float*, int, double, float, float*);
+int gs_launch_pose_finish_partials(hipStream_t, const float*, const float*, int, float*, float*, const float*, int, double, float, float*, int,
+                                   int);
 
 namespace {
 
@@ -124,11 +125,13 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
                            const float* origin, float tanfovx, float tanfovy, const void* geom, void* tiles, const void* binning,
                            int64_t capacity, const int32_t* radii, const float* out_color, const float* dL_dpix,
                            void* grad_scratch, float* pose_scratch, float* d_xyz, float* d_means2D, float* d_f_dc, float* d_f_rest,
-                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int grad_scratch_is_clear,
-                           int debug) {
+                           float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int pose_rows, int pose_row,
+                           int grad_scratch_is_clear, int debug) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!pose || !pose_scratch || !d_pose || D < 0 || D > 3 || (D > 0 && (!f_rest || !d_f_rest))) return MI355GS_EINVAL;
-  if (P <= 0) return hipMemsetAsync(d_pose, 0, 7 * sizeof(float), stream) == hipSuccess ? MI355GS_OK : MI355GS_ELAUNCH;
+  if (pose_rows < 0 || (pose_rows > 0 && (pose_row < 0 || pose_row >= pose_rows))) return MI355GS_EINVAL;
+  if (P <= 0)
+    return hipMemsetAsync(d_pose, 0, (size_t)(pose_rows > 0 ? pose_rows : 1) * 7 * sizeof(float), stream) == hipSuccess ? MI355GS_OK : MI355GS_ELAUNCH;
   const int rows = (P + 255) / 256;
   float* gate = (float*)((char*)grad_scratch + mi355gs_raster_grad_gate_offset(P));
   int rc;
@@ -147,7 +150,7 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
                                  grad_scratch_is_clear, debug);
   }
   if (rc) return rc;
-  gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, gate + 6, nullptr, 0, 0.0, 0.f, nullptr);
+  gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, gate + 6, nullptr, 0, 0.0, 0.f, nullptr, pose_rows, pose_row);
   GS_CHECK_LAUNCH("pose_finish");
   return MI355GS_OK;
 }
@@ -249,7 +252,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
                                     g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0, 0)))
     return rc;
   gs_launch_pose_finish_partials(stream, pose, t->pose_partial, (P + 255) / 256, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6,
-                                 (const float*)t->ssim_scratch, gs_loss_fused_nblocks(3, H, W), 1.0 / (3.0 * H * W), lambda_dssim, loss_out);
+                                 (const float*)t->ssim_scratch, gs_loss_fused_nblocks(3, H, W), 1.0 / (3.0 * H * W), lambda_dssim, loss_out, 0, 0);
   GS_CHECK_LAUNCH("pose_finish");
   // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
   if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps, true);

@@ -162,6 +162,14 @@ template <class... T> bool any_requires_grad(const T&... t) {
   ((any = any || (t.defined() && t.requires_grad())), ...);
   return any;
 }
+// ... asked where the operator is CALLED: inside a custom function's forward() grad mode is off, so the question would always be
+// answered "no" there (round 4 shipped it that way for a while: the backward's memset stayed, profiles/r04_dropin_aten_ops.txt)
+thread_local bool t_backward_follows = false;
+bool g_forward_owns_scratch = true;   // A/B switch (forward_owns_scratch): false = the backward allocates and memsets, as before ABI v7
+struct BackwardFollows {
+  explicit BackwardFollows(bool v) { t_backward_follows = v && g_forward_owns_scratch; }
+  ~BackwardFollows() { t_backward_follows = false; }
+};
 
 // The all-zero gradient of `f_rest` below its SH degree (what the reference's cat(f_dc, f_rest) backward produces: 35 MB of
 // zeros per iteration at C3, filled by a kernel every backward).  ONE persistent zero buffer per (device, shape) is handed
@@ -193,6 +201,72 @@ Tensor zero_grad_like(const Tensor& like) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// GaussianModel.get_RT: row `idx` of the learnable pose table (reference scene/gaussian_model.py:134-136, `self.P[idx]`).
+// Autograd's own backward of that selection fills a zero table and copies the seven values into it — two launches per
+// iteration of the reference loop.  As a node of this binding the selection can be seen by the render node: its backward then
+// has the pose-finishing kernel write the WHOLE table gradient (mi355gs_posed_backward, pose_rows / pose_row) and hands this
+// node a 7-element alias of it, which is recognised here and widened back to the table without a launch.  Anything else
+// arriving as the row's gradient (a sum with another consumer's gradient, a gradient from the op-by-op render path) takes the
+// general path: zeros + copy, as autograd would.
+// ------------------------------------------------------------------------------------------------
+struct PoseRowSeen {   // forward side, per calling thread: the last row handed out
+  c10::weak_intrusive_ptr<c10::TensorImpl> row{c10::intrusive_ptr<c10::TensorImpl>()};
+  int64_t rows = 0, index = 0;
+};
+thread_local PoseRowSeen t_pose_row;
+struct PoseTableWritten {   // backward side: the table gradient the render node's backward wrote last
+  c10::weak_intrusive_ptr<c10::StorageImpl> storage{c10::intrusive_ptr<c10::StorageImpl>()};
+  int64_t rows = 0, index = 0;
+  bool valid = false;
+};
+PoseTableWritten g_pose_table;   // under g_gate_mutex
+
+struct PoseRowFn : public torch::autograd::Function<PoseRowFn> {
+  static Tensor forward(AutogradContext* ctx, Tensor table, int64_t index) {
+    TORCH_CHECK(table.dim() == 2 && table.size(1) == 7, "pose_row: the pose table must be [views, 7]");
+    const int64_t rows = table.size(0);
+    if (index < 0) index += rows;
+    TORCH_CHECK(index >= 0 && index < rows, "pose_row: index ", index, " is out of range for ", rows, " poses");
+    ctx->saved_data["rows"] = rows;
+    ctx->saved_data["index"] = index;
+    Tensor row = table.select(0, index).detach();   // the same memory, no autograd view relation to keep consistent
+    t_pose_row.row = c10::weak_intrusive_ptr<c10::TensorImpl>(row.getIntrusivePtr());
+    t_pose_row.rows = table.is_contiguous() && table.scalar_type() == at::kFloat ? rows : 0;
+    t_pose_row.index = index;
+    return row;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const int64_t rows = ctx->saved_data["rows"].toInt(), index = ctx->saved_data["index"].toInt();
+    const Tensor& g = grad_out[0];
+    if (!g.defined()) return {Tensor(), Tensor()};
+    {
+      std::lock_guard<std::mutex> lock(g_gate_mutex);
+      auto strong = g_pose_table.storage.lock();
+      const bool mine = g_pose_table.valid && strong && strong.get() == g.storage().unsafeGetStorageImpl() && g_pose_table.rows == rows &&
+                        g_pose_table.index == index && g.scalar_type() == at::kFloat && g.dim() == 1 && g.numel() == 7 && g.is_contiguous() &&
+                        g.storage_offset() == 7 * index;
+      g_pose_table.valid = false;
+      if (mine) {
+        Tensor full = at::empty({0}, g.options());
+        full.set_(g.storage(), 0, {rows, 7}, {7, 1});
+        // the optimizer's record of "gradients this backward wrote" (group 6 = the pose table): the table is what P.grad becomes
+        if (g_gates.valid && g_gates.storage.size() == 7) {
+          g_gates.storage[6] = full.storage().getWeakStorageImpl();
+          g_gates.numel[6] = full.numel();
+          g_gates.version[6] = (int64_t)full._version();
+        }
+        return {full, Tensor()};
+      }
+    }
+    Tensor full = at::zeros({rows, 7}, g.options());
+    full.select(0, index).copy_(g);
+    return {full, Tensor()};
+  }
+};
+
+Tensor pose_row(Tensor table, int64_t index) { return PoseRowFn::apply(table, index); }
+
+// ------------------------------------------------------------------------------------------------
 // render()'s differentiable body: raw GaussianModel tensors + the 7-vector camera pose in, image out
 // (reference gaussian_renderer/__init__.py:81-135; the Python twin is instantsplat_amd/fused.py::_RenderPosed)
 // ------------------------------------------------------------------------------------------------
@@ -218,7 +292,7 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     Tensor geom = empty_bytes(g_abi.geom_bytes(P), xyz), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), xyz);
     // a backward will follow: its accumulator buffer is allocated now and cleared by the projection kernel on its way
     Tensor scratch;
-    if (any_requires_grad(xyz_, rot_, scaling_, opl_, f_dc_, f_rest_, pose_, means2D)) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
+    if (t_backward_follows) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
     int32_t* count = count_slot.data_ptr<int32_t>();  // pinned host memory the tile-scan kernel stores into (a CPU word under emulation)
     auto preprocess = [&]() {
       *reinterpret_cast<volatile int32_t*>(count) = -1;   // "not written yet" for wait_for_count
@@ -265,6 +339,12 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     ctx->saved_data["dims"] = std::vector<int64_t>{P, D, W, H, R};
     ctx->saved_data["scalars"] = std::vector<double>{tanfovx, tanfovy, scale_modifier};
     ctx->saved_data["scratch_is_clear"] = scratch.defined();
+    {
+      // is the pose the row get_RT just handed out on this thread?  Then the backward writes the table's gradient (PoseRowFn)
+      auto seen = t_pose_row.row.lock();
+      const bool is_row = seen && seen.get() == pose_.unsafeGetTensorImpl() && t_pose_row.rows > 0;
+      ctx->saved_data["pose_table"] = std::vector<int64_t>{is_row ? t_pose_row.rows : 0, is_row ? t_pose_row.index : 0};
+    }
     ctx->save_for_backward({xyz, rot, scaling, opl, f_dc, f_rest, pose, radii, geom, tiles, binning, bg, view, proj, origin, color,
                             scratch.defined() ? scratch : Tensor()});
     ctx->mark_non_differentiable({radii, visible});
@@ -291,7 +371,14 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     // below its SH degree f_rest gets the all-zero gradient cat(f_dc, f_rest) would give it (the optimizer then takes
     // PerPointAdam's zero-gradient step on it, as in the reference)
     Tensor d_frest = D == 0 ? zero_grad_like(f_rest) : at::empty_like(f_rest);
-    Tensor d_pose = at::empty({7}, xyz.options());
+    const auto pose_table = ctx->saved_data["pose_table"].toIntVector();
+    const int64_t pose_rows = pose_table[0], pose_index = pose_table[1];
+    Tensor d_pose_store = at::empty({pose_rows > 0 ? pose_rows * 7 : 7}, xyz.options());   // the 7 values, or the whole table's gradient
+    Tensor d_pose = d_pose_store;
+    if (pose_rows > 0) {   // an alias of row `pose_index` (not a view: nothing keeps the table's tensor alive but its memory)
+      d_pose = at::empty({0}, xyz.options());
+      d_pose.set_(d_pose_store.storage(), 7 * pose_index, {7}, {1});
+    }
     // the accumulator buffer the forward allocated and had cleared — once: a second backward of the same frame (retain_graph)
     // finds it used and lets the library clear it
     Tensor scratch = saved.size() > 16 ? saved[16] : Tensor();
@@ -302,11 +389,16 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     check(g_abi.posed_backward(dev.stream, P, D, W, H, fp(bg), fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling), (float)sc[2], fp(rot),
                                fp(pose), fp(view), fp(proj), fp(origin), (float)sc[0], (float)sc[1], geom.data_ptr(), tiles.data_ptr(),
                                binning.data_ptr(), R, radii.data_ptr<int32_t>(), fp(color), fp(g), scratch.data_ptr(), fp(pose_scratch),
-                               fp(d_xyz), fp(d_m2d), fp(d_fdc), D ? fp(d_frest) : nullptr, fp(d_opl), fp(d_scaling), fp(d_rot), fp(d_pose),
-                               scratch_is_clear, 0),
+                               fp(d_xyz), fp(d_m2d), fp(d_fdc), D ? fp(d_frest) : nullptr, fp(d_opl), fp(d_scaling), fp(d_rot),
+                               fp(d_pose_store), (int)pose_rows, (int)pose_index, scratch_is_clear, 0),
           "posed_backward");
     {
       std::lock_guard<std::mutex> lock(g_gate_mutex);
+      g_pose_table.valid = pose_rows > 0;
+      if (pose_rows > 0) {
+        g_pose_table.storage = d_pose_store.storage().getWeakStorageImpl();
+        g_pose_table.rows = pose_rows; g_pose_table.index = pose_index;
+      }
       const Tensor* outs[7] = {&d_xyz, &d_fdc, &d_frest, &d_opl, &d_scaling, &d_rot, &d_pose};   // the optimizer's group order
       g_gates.storage.clear();
       for (int k = 0; k < 7; ++k) {
@@ -328,6 +420,7 @@ std::vector<Tensor> render_posed(Tensor xyz, Tensor rot, Tensor scaling, Tensor 
                                  Tensor means2D, Tensor bg, Tensor view, Tensor proj, Tensor origin, int64_t H, int64_t W,
                                  double tanfovx, double tanfovy, double scale_modifier, int64_t D, int64_t capacity, int64_t count_hint,
                                  Tensor count_slot) {
+  const BackwardFollows scope(any_requires_grad(xyz, rot, scaling, opl, f_dc, f_rest, pose, means2D));
   return RenderPosedFn::apply(xyz, rot, scaling, opl, f_dc, f_rest, pose, means2D, bg, view, proj, origin, H, W, tanfovx, tanfovy,
                               scale_modifier, D, capacity, count_hint, count_slot);
 }
@@ -364,12 +457,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     Tensor color = at::empty({3, H, W}, means3D.options());
     Tensor geom = empty_bytes(g_abi.geom_bytes(P), means3D), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), means3D);
     Tensor scratch;   // see RenderPosedFn::forward
-    {
-      const Tensor none;
-      auto val = [&](const OptTensor& t) -> const Tensor& { return t.has_value() ? *t : none; };
-      if (any_requires_grad(means3D_, means2D, opac_, val(sh_), val(colors_), val(scales_), val(rot_), val(cov_), val(sh_rest_)))
-        scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
-    }
+    if (t_backward_follows) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
     int32_t* count = count_slot.data_ptr<int32_t>();
     auto preprocess = [&]() {
       *reinterpret_cast<volatile int32_t*>(count) = -1;
@@ -450,6 +538,9 @@ std::vector<Tensor> rasterize(Tensor means3D, Tensor means2D, c10::optional<Tens
                               c10::optional<Tensor> scales, c10::optional<Tensor> rot, c10::optional<Tensor> cov, c10::optional<Tensor> sh_rest,
                               Tensor bg, Tensor view, Tensor proj, Tensor campos, int64_t H, int64_t W, double tanfovx, double tanfovy,
                               double scale_modifier, int64_t D, bool prefiltered, int64_t capacity, int64_t count_hint, Tensor count_slot) {
+  const Tensor none;
+  auto val = [&](const c10::optional<Tensor>& t) -> const Tensor& { return t.has_value() ? *t : none; };
+  const BackwardFollows scope(any_requires_grad(means3D, means2D, opac, val(sh), val(colors), val(scales), val(rot), val(cov), val(sh_rest)));
   return RasterizeFn::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, sh_rest, bg, view, proj, campos, H, W,
                             tanfovx, tanfovy, scale_modifier, D, prefiltered, capacity, count_hint, count_slot);
 }
@@ -667,6 +758,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled PyTorch binding of libmi355gs.so's drop-in operators (no compute of its own)";
   m.def("bind", &bind_abi, "hand over the C-ABI entry points (name -> address) of the loaded libmi355gs build; allow_cpu_tensors: test tier only");
   m.def("render_posed", &render_posed);
+  m.def("forward_owns_scratch", [](bool on) { const bool was = g_forward_owns_scratch; g_forward_owns_scratch = on; return was; },
+        "A/B switch: true (default) = a forward that a backward will follow allocates the backward's accumulators and has the projection kernel clear them");
+  m.def("pose_row", &pose_row, "GaussianModel.get_RT: row `index` of the [views, 7] pose table as a node the render node's backward cooperates with");
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);
   m.def("fused_ssim", &fused_ssim);

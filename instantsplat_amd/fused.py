@@ -127,7 +127,7 @@ class _RenderPosed(torch.autograd.Function):
                 _lib.ptr(origin), float(s.tanfovx), float(s.tanfovy), _lib.ptr(geom), _lib.ptr(tiles), _lib.ptr(binning),
                 int(ctx.capacity), _lib.ptr(radii), _lib.ptr(color), _lib.ptr(g), _lib.ptr(scratch), _lib.ptr(pose_scratch),
                 _lib.ptr(d_xyz), _lib.ptr(d_m2d), _lib.ptr(d_fdc), _lib.ptr(d_frest) if D else None, _lib.ptr(d_opl),
-                _lib.ptr(d_scaling), _lib.ptr(d_rot), _lib.ptr(d_pose), 0, 1 if s.debug else 0), "posed_backward")
+                _lib.ptr(d_scaling), _lib.ptr(d_rot), _lib.ptr(d_pose), 0, 0, 0, 1 if s.debug else 0), "posed_backward")
         return d_xyz, d_rot, d_scaling, d_opl, d_fdc, d_frest, d_pose, d_m2d, None
 
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .optim import PerPointAdam, get_expon_lr_func
 from .pose_utils import get_tensor_from_camera
 from .sh_utils import RGB2SH
@@ -113,7 +114,16 @@ class GaussianModel:
         poses = [get_tensor_from_camera(cam.world_view_transform.transpose(0, 1).cpu()) for cam in cameras]
         self.P = torch.stack(poses).to(device).requires_grad_(True)
 
+    POSE_ROW_NODE = True   # A/B switch: False = plain indexing (autograd's select-backward builds the table gradient)
+
     def get_RT(self, idx):
+        """Row `idx` of the learnable pose table (reference :134-136).  Through the compiled binding it is a node of its own whose
+        backward receives the whole table's gradient from the render node's last kernel (csrc_torch/binding.cpp PoseRowFn)
+        instead of building it with a fill and a copy; values and gradients are those of `self.P[idx]`."""
+        if self.POSE_ROW_NODE and type(idx) is int and self.P.is_contiguous():
+            ext = _lib.compiled()
+            if ext is not None:
+                return ext.pose_row(self.P, idx)
         return self.P[idx]
 
     # ---- initialisation from a point cloud (reference :146-172)

@@ -59,7 +59,11 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+// (counted: tests assert that a training iteration of the drop-in path issues no memset of its own — the frame's accumulators are
+// cleared by the projection kernel on its way)
+inline long g_emu_memset_calls = 0;
+extern "C" __attribute__((weak, visibility("default"))) long mi355gs_emu_memset_calls() { return g_emu_memset_calls; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { ++g_emu_memset_calls; memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };

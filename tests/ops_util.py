@@ -595,13 +595,19 @@ def check_dropin_node_housekeeping(dev, Wm=10, W=32, H=24):
                 pkg0 = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
             assert torch.equal(pkg0["visibility_filter"], vis) and pkg0["render"].grad_fn is None
             loss, _ = fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), 0.2)
+            memsets = getattr(_lib.lib(), "mi355gs_emu_memset_calls", None)      # emulated library only: hipMemsetAsync calls so far
+            n_memsets = memsets() if memsets else 0
             loss.backward(retain_graph=True)
+            if memsets:   # the forward saw that a backward follows (asked OUTSIDE the custom function, where grad mode is on)
+                assert memsets() == n_memsets, "the first backward of a frame cleared its accumulators with a memset"
             first = {n: getattr(g, n).grad.clone() for n in names}
             fr = g._features_rest.grad
             assert fr is not None and float(fr.abs().max()) == 0.0
             for n in names + ("_features_rest",):
                 getattr(g, n).grad = None
             loss.backward()                                         # the same frame again: the accumulators were used once already
+            if memsets:
+                assert memsets() == n_memsets + 1, "a second backward of the same frame must clear the used accumulators itself"
             for n in names:
                 bound("dropin_housekeeping/second_backward" + n, rel_l2(getattr(g, n).grad, first[n]), 2e-4 if cuda else 0.0)
             # ---- the shared zero gradient
@@ -1038,8 +1044,8 @@ def check_compiled_binding_equals_ctypes(dev, iters=5, Wm=12, W=40, H=32):
     """The drop-in loop (train_iteration: render -> loss -> backward -> loss.item() -> PerPointAdam.step) through the compiled
     binding vs through the ctypes / Python autograd.Function binding: the same C-ABI calls with the same arguments, so under
     the emulator (deterministic atomics) every loss and parameter is bit-identical; on the GPU to float-atomic order.  Also
-    the statement that the compiled Adam took the backward's gate flags for the six tensors the backward writes directly
-    (the pose table's gradient is scattered by autograd from one row and is summed by the library) — and that a run in
+    the statement that the compiled Adam took the backward's gate flags for all seven tensors (since ABI v8 the pose TABLE's
+    gradient is written by the backward too, PoseRowFn; before, autograd scattered it from one row) — and that a run in
     which f_rest is gated off (degree 0), trained (degree 1) and gated off again keeps matching."""
     from instantsplat_amd.arguments import OptimizationParams
     from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
@@ -1062,7 +1068,7 @@ def check_compiled_binding_equals_ctypes(dev, iters=5, Wm=12, W=40, H=32):
                                 {n: g.optimizer.state[getattr(g, n)]["exp_avg_sq"].detach().cpu().clone() for n in names})
                 if binding == "compiled":
                     plans = [b["compiled"] for pl in g.optimizer._plans.values() for b in pl["batches"] if "compiled" in b]
-                    assert plans and all(p.last_used_gates == 6 for p in plans), [(p.last_used_gates, p.last_gate_note) for p in plans]
+                    assert plans and all(p.last_used_gates == 7 for p in plans), [(p.last_used_gates, p.last_gate_note) for p in plans]
             BinningPolicy.reset("exact")
         for a_, b_ in zip(res["ctypes"][0], res["compiled"][0]):
             bound("compiled_vs_ctypes/loss", abs(a_ - b_) / max(abs(a_), 1e-6), 1e-3 if cuda else 0.0)   # MI355X, two runs of one binding: 1.4e-4
@@ -1127,7 +1133,8 @@ def check_compiled_gate_flags_are_sound(dev, Wm=10, W=32, H=24):
             n: g.optimizer.state[getattr(g, n)]["exp_avg_sq"].detach().cpu().clone() for n in names}, used
 
     try:
-        expect = {"fresh": 6, "accumulated": 0, "clipped": 5, "replaced": 5, "zeroed": 5, "zeroed_behind_the_version_counter": 0}
+        # (seven with the pose table, whose gradient the backward writes too since ABI v8 — get_RT is a node of the binding)
+        expect = {"fresh": 7, "accumulated": 0, "clipped": 6, "replaced": 6, "zeroed": 6, "zeroed_behind_the_version_counter": 0}
         for kind, n_flags in expect.items():
             with _with_binding("ctypes"):
                 pa, va, _ = scenario(kind)
@@ -1212,3 +1219,79 @@ def check_trainer_keeps_its_unit_length_knob(dev, Wm=14, W=48, H=32):
     finally:
         L.mi355gs_tune_min_units(old)
         BinningPolicy.reset("exact")
+
+
+def check_pose_row_node(dev, Wm=10, W=32, H=24):
+    """GaussianModel.get_RT through the compiled binding (PoseRowFn, ABI v8 pose_rows / pose_row) against plain `P[idx]`:
+      * same values, same memory as the table's row;
+      * after render -> loss -> backward, P.grad is the [views, 7] table with the gradient in row idx and EXACT zeros elsewhere,
+        equal to what autograd's select-backward gives for the same frame — written by the render node's last kernel (no
+        fill, no copy: the table arrives as an alias of the memory that kernel wrote);
+      * the optimizer then finds the table among "the gradients this backward wrote" (gated by the backward's flag);
+      * a row that is ALSO used by something else (its gradient arrives as a sum), a row rendered through the op-by-op path, and
+        two rows alive at once (the render node must not mistake one for the other) all give P[idx]'s gradients;
+      * negative and out-of-range indices behave like indexing."""
+    from instantsplat_amd import _lib
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.fused_ssim import fused_l1_ssim_loss
+    from instantsplat_amd.gaussian_renderer import render
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training
+    import pytest
+    sc = syn_pointmap(3, Wm, Wm, W, H, seed=4)
+    cuda = torch.device(dev).type == "cuda"
+    with _with_binding("compiled"):
+        ext = _lib.compiled()
+        st = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+        g = st.gaussians
+        names = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation", "P")
+
+        def clear():
+            for n in names + ("_features_rest",):
+                getattr(g, n).grad = None
+
+        def frame(cam, pose, extra=None):
+            clear()
+            pkg = render(cam, g, st.pipe, st.background, camera_pose=pose)
+            loss, _ = fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), 0.2)
+            if extra is not None:
+                loss = loss + extra
+            loss.backward()
+            return {n: getattr(g, n).grad.clone() for n in names}
+
+        cam = st.cameras[1]
+        row = g.get_RT(1)
+        assert row.grad_fn is not None and "PoseRow" in row.grad_fn.name(), row.grad_fn.name()
+        assert torch.equal(row, g.P[1]) and row.data_ptr() == g.P[1].data_ptr()
+        assert torch.equal(g.get_RT(-1), g.P[-1])
+        with pytest.raises((RuntimeError, IndexError)):
+            g.get_RT(3)
+        ref = frame(cam, g.P[1])                       # autograd's own selection: zeros + copy
+        memsets = getattr(_lib.lib(), "mi355gs_emu_memset_calls", None)
+        got = frame(cam, g.get_RT(1))
+        assert g.P.grad.shape == g.P.shape and g.P.grad.is_contiguous()
+        assert float(g.P.grad[0].abs().max()) == 0.0 and float(g.P.grad[2].abs().max()) == 0.0 and float(g.P.grad[1].abs().max()) > 0.0
+        for n in names:
+            bound("pose_row/" + n, rel_l2(got[n], ref[n]), 2e-4 if cuda else 0.0)
+        # the optimizer's fast path takes all seven gradients from the backward's record (pose table included)
+        opt = g.optimizer
+        opt.step()
+        plan = opt._fast[2] if getattr(opt, "_fast", None) else None
+        if plan is not None:
+            assert plan.last_used_gates == 7, (plan.last_used_gates, plan.last_gate_note)
+        # ---- the general path: the row's gradient arrives as a sum
+        row = g.get_RT(1)
+        got = frame(cam, row, extra=(row * row).sum() * 0.5)
+        clear()
+        pr = g.P[1]
+        ref = frame(cam, pr, extra=(pr * pr).sum() * 0.5)
+        for n in names:
+            bound("pose_row_sum/" + n, rel_l2(got[n], ref[n]), 2e-4 if cuda else 1e-6)
+        # ---- two rows alive at once: the render of camera 0 gets row 0, while row 2 was handed out last
+        r0, r2 = g.get_RT(0), g.get_RT(2)
+        got = frame(st.cameras[0], r0)
+        ref = frame(st.cameras[0], g.P[0])
+        for n in names:
+            bound("pose_row_two/" + n, rel_l2(got[n], ref[n]), 2e-4 if cuda else 0.0)
+        assert float(g.P.grad[2].abs().max()) == 0.0
+        del r2

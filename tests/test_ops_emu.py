@@ -153,7 +153,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.mi355gs_abi_version.restype = ctypes.c_int
-    assert lib.mi355gs_abi_version() == 7
+    assert lib.mi355gs_abi_version() == 8
 
 
 def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
@@ -222,3 +222,7 @@ def test_operator_bindings_agree(emu):
 
 def test_trainer_keeps_its_unit_length_knob(emu):
     ops_util.check_trainer_keeps_its_unit_length_knob(emu)
+
+
+def test_pose_row_node(emu):
+    ops_util.check_pose_row_node(emu)

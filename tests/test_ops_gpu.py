@@ -120,3 +120,8 @@ def test_operator_bindings_agree(gpu):
 
 def test_trainer_keeps_its_unit_length_knob(gpu):
     ops_util.check_trainer_keeps_its_unit_length_knob(gpu, Wm=40, W=128, H=96)
+
+
+@pytest.mark.gpu
+def test_pose_row_node(gpu):
+    ops_util.check_pose_row_node(gpu, Wm=48, W=128, H=96)
