@@ -67,8 +67,10 @@ struct MultiAdamArgs {
   uint32_t* live;
   uint32_t seq;
   // commit gate (fused trainer only): if *commit_count > commit_capacity the launch writes nothing at all
+  // ... and neither does any later gated launch of the same trainer: the first one leaves *commit_poison = 1 (sticky)
   const uint32_t* commit_count;
   unsigned long long commit_capacity;
+  uint32_t* commit_poison;
 };
 
 __device__ __forceinline__ int mt_find(const MultiAdamArgs& a, int b) {
@@ -104,7 +106,13 @@ __global__ __launch_bounds__(256) void k_adam_sumsq(MultiAdamArgs a, float* __re
 
 __global__ __launch_bounds__(256) void k_adam_multi(MultiAdamArgs a, const float* __restrict__ sumsq, float beta1, float beta2,
                                                      float eps) {
-  if (a.commit_count && (unsigned long long)*a.commit_count > a.commit_capacity) return;   // wave-uniform (one scalar load)
+  if (a.commit_count) {   // wave-uniform (scalar loads)
+    const bool over = (unsigned long long)*a.commit_count > a.commit_capacity;
+    if (over || (a.commit_poison && *a.commit_poison)) {
+      if (over && a.commit_poison && blockIdx.x == 0 && threadIdx.x == 0) *a.commit_poison = 1u;
+      return;
+    }
+  }
   const int t = mt_find(a, blockIdx.x);
   const long long lo = (long long)(blockIdx.x - a.first_block[t]) * MT_CHUNK;
   const long long hi = min(a.numel[t], lo + MT_CHUNK);
@@ -222,11 +230,11 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
     }
   }
   a.first_block[MT_MAX] = blocks;
-  a.live = nullptr; a.seq = 0; a.commit_count = nullptr; a.commit_capacity = 0;
+  a.live = nullptr; a.seq = 0; a.commit_count = nullptr; a.commit_capacity = 0; a.commit_poison = nullptr;
   if (blocks == 0) return MI355GS_OK;
   if (!gate && g_fused.gate == scratch) {
     a.live = g_fused.adam_live; a.seq = g_fused.adam_seq;
-    a.commit_count = g_fused.commit_count; a.commit_capacity = g_fused.commit_capacity;
+    a.commit_count = g_fused.commit_count; a.commit_capacity = g_fused.commit_capacity; a.commit_poison = g_fused.commit_poison;
   } else if (live && seq != 0u) {
     a.live = live; a.seq = seq;   // the caller's own memory of gated-off tensors (include/mi355gs.h)
   }

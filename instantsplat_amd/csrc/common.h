@@ -318,6 +318,7 @@ struct GsFusedStepHooks {
   // instances, its gradients are not the iteration's — so the step can be enqueued whole, before the host has seen the count.
   const uint32_t* commit_count = nullptr;
   unsigned long long commit_capacity = 0;
+  uint32_t* commit_poison = nullptr;   // device word, sticky: set by a launch that discarded itself; later gated launches then discard themselves too
   int gate_xyz = -1, gate_rot = -1, gate_scaling = -1, gate_opacity = -1, gate_sh = -1, gate_sh_rest = -1, gate_pose = -1;
 };
 extern thread_local GsFusedStepHooks g_fused;

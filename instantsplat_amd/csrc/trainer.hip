@@ -90,6 +90,7 @@ int trainer_adam(Trainer* t, hipStream_t stream, const float* lr, const int32_t*
     const TilesLayout tl(t->W, t->H);
     g_fused.commit_count = (const uint32_t*)(t->tiles + tl.start) + tl.T;   // tile_start[T]: the frame's instance count
     g_fused.commit_capacity = (unsigned long long)t->capacity;
+    g_fused.commit_poison = t->adam_live + 15;   // (words 0..13 are MultiAdamArgs::live's; cleared with them before the first step)
   }
   return mi355gs_adam_multi_step(stream, 7, numel, row, params, grads, t->m, t->v, pplr, lr, beta1, beta2, eps, step, t->adam_scratch, nullptr, nullptr, nullptr, 0u);
 }
@@ -257,6 +258,12 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   // ---- optimizer: groups in the reference's order xyz, f_dc, f_rest, opacity, scaling, rotation, pose
   if (do_optimizer_step) return trainer_adam(t, stream, lr, step, beta1, beta2, eps, true);
   return MI355GS_OK;
+}
+
+int mi355gs_trainer_rearm(void* handle, void* stream_) {
+  Trainer* t = (Trainer*)handle;
+  if (!t) return MI355GS_EINVAL;
+  return hipMemsetAsync(t->adam_live + 15, 0, sizeof(uint32_t), (hipStream_t)stream_) == hipSuccess ? MI355GS_OK : MI355GS_ELAUNCH;
 }
 
 int mi355gs_trainer_optimizer_step(void* handle, void* stream_, const float* lr, const int32_t* step, float beta1, float beta2,

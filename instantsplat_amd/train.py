@@ -438,6 +438,11 @@ class RunAhead:
       BinningPolicy).  At each window boundary all counts of the window are verified; if any frame overflowed, the
       parameters, optimizer state, RNG and view stack are restored from the snapshot taken at the previous boundary
       and the window is replayed with exact sizing — so an overflow costs time, never correctness.
+    * On the one-call step there is nothing to restore on the device: its commit gate is sticky (include/mi355gs.h) — the
+      optimizer launch of an overflowed iteration and of every iteration enqueued behind it writes nothing, so parameters and
+      moments ARE the ones the iteration before the overflow left.  The host only rewinds its own half (iteration counter,
+      LR, view stack, RNG, step counts: a tuple kept per iteration of the window) to that iteration and redoes the rest of the
+      window with exact sizing.  (The snapshot was 21 tensor copies — ~57 MB at the bench size — per window: 20 us per iteration.)
     """
 
     def __init__(self, st: TrainState, window: int = 10, fused_loss: bool = True, fused_step: bool = True):
@@ -449,10 +454,13 @@ class RunAhead:
         self.ema = 0.0
         self.n_in_window = 0
         self.replays = 0
+        self.partial_replays = 0     # ... of which began inside a window (the iterations before the overflow stood)
         BinningPolicy.reset("bounded")
-        self._snapshot()
+        self.snap, self._host_hist = None, []
         if fused_step and FusedTrainer.supported(st):
             self._make_trainer()
+        if self.trainer is None:
+            self._snapshot()
 
     def _make_trainer(self):
         """Instance capacity from an exact count of every training view (one un-timed forward each)."""
@@ -504,9 +512,15 @@ class RunAhead:
     def step(self):
         """One training iteration; returns the EMA loss at window boundaries (like the reference's progress bar), else None."""
         if self.trainer is not None and FusedTrainer.supported(self.st):
+            if self.snap is not None and self.n_in_window == 0:
+                self.snap = None       # (a window that began on the autograd path ended: the sticky gate takes over)
+            self._host_hist.append(_host_state(self.st, self.trainer))
             # (flush() reads the loss ring back — a blocking copy on this stream — before it polls the counts: no events needed)
             self.trainer.step(self.ring[self.n_in_window:self.n_in_window + 1], record_event=False)
         else:
+            if self.snap is None:      # the configuration left the one-call step's domain mid-window: this path needs a state to return to
+                self.flush()
+                self._snapshot()
             loss = _forward_backward_step(self.st, self.fused)
             self.ring[self.n_in_window] = loss
             _optimizer_step(self.st)
@@ -521,12 +535,22 @@ class RunAhead:
         if n == 0:
             return self.ema
         losses = self.ring[:n].tolist()           # the only blocking read-back of the window
-        if BinningPolicy.poll(block=True):
+        overflowed = BinningPolicy.poll(block=True)
+        if overflowed:
             self.replays += 1
-            self._restore()
+            first = 0
+            if len(self._host_hist) == n:
+                # one-call steps only: everything from the first overflowed iteration on discarded itself on the device
+                its = [h[0] + 1 for h in self._host_hist]            # the iteration number each step of the window ran as
+                first = min(its.index(t) for t in overflowed if t in its) if any(t in its for t in overflowed) else 0
+                _restore_host_state(self.st, self.trainer, self._host_hist[first])
+                losses = losses[:first]
+                self.partial_replays += first > 0
+            else:
+                self._restore()
+                losses = []
             BinningPolicy.mode = "exact"
-            losses = []
-            for _ in range(n):
+            for _ in range(n - first):
                 l = _forward_backward_step(self.st, self.fused)
                 losses.append(float(l.item()))
                 _optimizer_step(self.st)
@@ -539,11 +563,13 @@ class RunAhead:
             self.ema = 0.4 * l + 0.6 * self.ema   # reference train.py:188
         self.st.last_loss = losses[-1]
         self.n_in_window = 0
+        self._host_hist = []
         if self.trainer is not None:  # grow the fixed-capacity buffers before the scene outgrows them
             need = max(BinningPolicy.known.get(hint_key(self.st, c), 0) for c in self.st.cameras)
             if need * 1.2 + 1024 > self.trainer.capacity:
                 self._make_trainer()
-        self._snapshot()
+        if self.trainer is None:
+            self._snapshot()
         return self.ema
 
 

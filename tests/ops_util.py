@@ -297,6 +297,45 @@ def check_run_ahead_equals_sync_loop(dev, iters=23, force_overflow=False, Wm=20,
         BinningPolicy.reset("exact")
 
 
+def check_run_ahead_sticky_commit_gate(dev, iters=17, Wm=20, W=48):
+    """An overflow in the MIDDLE of a run-ahead window on the one-call step: the buffers hold every view but the heaviest one, so
+    windows overflow at whatever position that view is drawn.  The sticky commit gate (include/mi355gs.h) makes that iteration's
+    optimizer launch and every one enqueued behind it a no-op; RunAhead keeps the iterations before it, rewinds only its host
+    half and redoes the rest — no snapshot of parameters or moments exists on this path.  Must equal the synchronous loop."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import RunAhead, hint_key, setup_training, train_iteration
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=7)
+    mk = lambda: generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
+    try:
+        st_a = mk()
+        ema = 0.0
+        for _ in range(iters):
+            ema = 0.4 * train_iteration(st_a) + 0.6 * ema
+        st_b = mk()
+        ra = RunAhead(st_b, window=6)
+        assert ra.trainer is not None and ra.snap is None        # one-call step, nothing to restore from
+        counts = sorted(BinningPolicy.known[hint_key(st_b, c)] for c in st_b.cameras)
+        assert counts[-1] > counts[-2] + 8, counts               # the scene must have one strictly heaviest view
+        # every (re)made handle holds the second-heaviest view with a little room, not the heaviest
+        BinningPolicy.slack, BinningPolicy.pad = (counts[-2] + (counts[-1] - counts[-2]) * 0.5) / counts[-1], 0
+        ra._make_trainer()
+        for _ in range(iters):
+            ra.step()
+        ema_b = ra.flush()
+        assert ra.replays >= 1 and ra.partial_replays >= 1, (ra.replays, ra.partial_replays)
+        cuda = torch.device(dev).type == "cuda"
+        bound("run_ahead_sticky/ema", abs(ema - ema_b) / max(1e-3, abs(ema)), 2e-3 if cuda else 1e-6)
+        for n in names:
+            bound("run_ahead_sticky/param" + n, rel_l2(getattr(st_b.gaussians, n), getattr(st_a.gaussians, n)), 2e-3 if cuda else 1e-5)
+        assert st_b.iteration == st_a.iteration
+    finally:
+        BinningPolicy.slack, BinningPolicy.pad = 1.5, 16384
+        BinningPolicy.reset("exact")
+
+
 def check_pose_tracking(dev, num_iter, Wm=16, W=40, min_gain=0.0):
     """render_set_optimize (reference render.py:99-170): Gaussians frozen, a perturbed view pose is pulled back
     towards the pose that explains the image (masked L1)."""

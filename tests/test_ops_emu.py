@@ -226,3 +226,7 @@ def test_trainer_keeps_its_unit_length_knob(emu):
 
 def test_pose_row_node(emu):
     ops_util.check_pose_row_node(emu)
+
+
+def test_run_ahead_sticky_commit_gate(emu):
+    ops_util.check_run_ahead_sticky_commit_gate(emu)

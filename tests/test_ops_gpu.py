@@ -125,3 +125,8 @@ def test_trainer_keeps_its_unit_length_knob(gpu):
 @pytest.mark.gpu
 def test_pose_row_node(gpu):
     ops_util.check_pose_row_node(gpu, Wm=48, W=128, H=96)
+
+
+@pytest.mark.gpu
+def test_run_ahead_sticky_commit_gate(gpu):
+    ops_util.check_run_ahead_sticky_commit_gate(gpu)
