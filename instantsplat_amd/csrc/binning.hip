@@ -502,6 +502,9 @@ __device__ __forceinline__ uint32_t sort_xor32(uint32_t u) {
 // (0: none — rounds 1-2; 1: all exchanges; 2: only the ones that would need a v_permlane*_swap + select — lane masks 16, 31,
 // 32, 63: 12 VALU issue cycles per 32-bit word against one ds_bpermute.  Measured at C3: 0: 14.3 us, 1: 18.7 us (the network is
 // a chain of dependent stages and the crossbar's latency is not covered when every stage takes it), 2: 13.5 us)
+#ifndef GS_SORT_TWO_RUNS
+#define GS_SORT_TWO_RUNS 2   // A/B build switch: 0 = one network per tile; 1 = tiles of 1025 ... 1536 keys as two sorted runs merged by rank (sort_tile_two_runs); 2 = also 513 ... 768; 3 = also 1537 ... 2048 (no gain)
+#endif
 template <int LM>
 __device__ __forceinline__ uint32_t lane_xchg32(uint32_t v) {
   constexpr bool SORT_BPERMUTE = GS_SORT_BPERMUTE == 1 || (GS_SORT_BPERMUTE == 2 && LM >= 16);
@@ -624,6 +627,47 @@ __device__ __forceinline__ void sort_tile_regs(uint64_t* __restrict__ s_keys, co
   }
 }
 
+// Tiles a little longer than a power of two — at 1080p with a million Gaussians a fifth of the tiles hold 1025 ... 1400 keys
+// (mean 890) and the 2048-key network costs 2.4 x the 1024-key one (66 stages of 8 keys per thread against 55 of 4): they took
+// 40 % of the kernel.  Such a tile is sorted as TWO runs by the register network — the first SORT_THREADS * EA keys and the
+// rest (up to SORT_THREADS * EB) — which are then merged by rank: both sorted runs are parked in LDS, every key counts the
+// keys of the OTHER run below it (a branch-free binary search; keys are distinct) and that count plus its position in its own
+// run is its place in the tile.  55 + 45 (or 36) register stages on 4 + 2 (1) keys and ~11 dependent LDS reads per key.
+template <int NMAX>
+__device__ __forceinline__ uint32_t sort_count_below(const uint64_t* __restrict__ run, int n, uint64_t key) {
+  int lo = 0;   // number of run[0 .. n) below key, n <= NMAX (a power of two)
+#pragma unroll
+  for (int step = NMAX; step >= 1; step >>= 1)
+    if (lo + step <= n && run[lo + step - 1] < key) lo += step;
+  return (uint32_t)lo;
+}
+template <int EA, int EB>
+__device__ __forceinline__ void sort_tile_two_runs(uint64_t* __restrict__ s_keys, const uint64_t* keys, uint32_t* __restrict__ list,
+                                                   uint32_t s, int n) {
+  constexpr int NA = SORT_THREADS * EA, NBMAX = SORT_THREADS * EB;
+  static_assert(NA + NBMAX <= SORT_SMALL_CAP, "both sorted runs are parked in the kernel's LDS array");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base_a = wave * (64 * EA) + lane * EA, base_b = wave * (64 * EB) + lane * EB, nb = n - NA;   // NA < n <= NA + NBMAX
+  uint64_t ka[EA], kb[EB];
+#pragma unroll
+  for (int e = 0; e < EA; ++e) ka[e] = keys[s + base_a + e];
+#pragma unroll
+  for (int e = 0; e < EB; ++e) kb[e] = (base_b + e < nb) ? keys[s + NA + base_b + e] : ~0ull;
+  sort_merge_from<EA, 2, NA>(ka, s_keys, base_a);
+  sort_merge_from<EB, 2, NBMAX>(kb, s_keys, base_b);
+  __syncthreads();   // the networks' last LDS stages have been read
+#pragma unroll
+  for (int e = 0; e < EA; ++e) s_keys[base_a + e] = ka[e];
+#pragma unroll
+  for (int e = 0; e < EB; ++e) s_keys[NA + base_b + e] = kb[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EA; ++e) list[s + base_a + e + sort_count_below<NBMAX>(s_keys + NA, nb, ka[e])] = (uint32_t)ka[e];
+#pragma unroll
+  for (int e = 0; e < EB; ++e)
+    if (base_b + e < nb) list[s + base_b + e + sort_count_below<NA>(s_keys, NA, kb[e])] = (uint32_t)kb[e];
+}
+
 // Tiles longer than SORT_SMALL_CAP (rare: the C3 maximum is under 1100): sort runs of SORT_SMALL_CAP keys with the register
 // network (keys rewritten in place), then place every key by RANK — its index in its own run plus, for every other run staged
 // in LDS, the number of keys below it (keys are distinct, so the ranks are a permutation).  Same registers and LDS as the
@@ -679,7 +723,17 @@ __device__ __forceinline__ void sort_one_tile(int tile, const uint32_t* __restri
   if (n <= 0) return;
   if (n <= SORT_THREADS) sort_tile_regs<1>(s_keys, keys, list, s, n);
   else if (n <= SORT_THREADS * 2) sort_tile_regs<2>(s_keys, keys, list, s, n);
+#if GS_SORT_TWO_RUNS >= 2
+  else if (n <= SORT_THREADS * 3) sort_tile_two_runs<2, 1>(s_keys, keys, list, s, n);
+#endif
   else if (n <= SORT_THREADS * 4) sort_tile_regs<4>(s_keys, keys, list, s, n);
+#if GS_SORT_TWO_RUNS >= 1
+  else if (n <= SORT_THREADS * 5) sort_tile_two_runs<4, 1>(s_keys, keys, list, s, n);
+  else if (n <= SORT_THREADS * 6) sort_tile_two_runs<4, 2>(s_keys, keys, list, s, n);
+#endif
+#if GS_SORT_TWO_RUNS >= 3
+  else if (n <= SORT_SMALL_CAP) sort_tile_two_runs<4, 4>(s_keys, keys, list, s, n);
+#endif
   else if (n <= SORT_SMALL_CAP) sort_tile_regs<8>(s_keys, keys, list, s, n);
   else if (n <= SORT_LDS_CAP) sort_long_tile(s_keys, keys, list, s, n);
   else {

@@ -194,6 +194,7 @@ def check_tile_lists_sorted(dev, n):
     depth = geom[: n * 48].cpu().view(torch.float32).reshape(n, 12).numpy()[:, 11]
     assert start[0] == 0 and start[T] == R and R > 0
     longest = 0
+    check_tile_lists_sorted.lengths = [int(start[tile + 1] - start[tile]) for tile in range(T)]
     for tile in range(T):
         seg = lst[start[tile]:start[tile + 1]]
         longest = max(longest, len(seg))

@@ -238,3 +238,14 @@ def test_scatter_takes_the_count_kernels_tile_list_or_recounts(emu):
     edge_cases.check_tile_lists_against_oracle(emu, 500, W=608, H=480, scale_boost=2.0, entry_counts=n_big)
     assert len(n_small) == 1 and 0 < n_small[0] <= 1024, n_small
     assert n_big == [0xffffffff], n_big
+
+
+@pytest.mark.parametrize("n", [850, 1100, 1600, 1900, 2200])
+def test_tile_lists_sorted_as_two_runs(emu, n):
+    """Tiles of 513 ... 768 and 1025 ... 1536 keys: two sorted runs (512 + up to 256, 1024 + up to 256 / 512 keys) merged by rank
+    (binning.hip sort_tile_two_runs)."""
+    edge_cases.check_tile_lists_sorted(emu, n)
+    lengths = edge_cases.check_tile_lists_sorted.lengths
+    assert any((512 < x <= 768) if n < 1200 else (1024 < x <= 1536) for x in lengths), lengths
+    if n == 1900:
+        assert any(1024 < x <= 1280 for x in lengths) and any(1280 < x <= 1536 for x in lengths), lengths

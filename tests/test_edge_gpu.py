@@ -49,6 +49,13 @@ def test_tile_lists_sorted(gpu, n, longer_than):
     assert edge_cases.check_tile_lists_sorted(gpu, n) > longer_than
 
 
+@pytest.mark.parametrize("n", [850, 1100, 1600, 1900, 2200])
+def test_tile_lists_sorted_as_two_runs(gpu, n):
+    edge_cases.check_tile_lists_sorted(gpu, n)
+    lengths = edge_cases.check_tile_lists_sorted.lengths
+    assert any((512 < x <= 768) if n < 1200 else (1024 < x <= 1536) for x in lengths), lengths
+
+
 @pytest.mark.parametrize("n", [400, 5000])
 def test_tile_lists_are_the_oracles_minus_invisible_instances(gpu, n):
     R, R_ref, worst = edge_cases.check_tile_lists_against_oracle(gpu, n)
