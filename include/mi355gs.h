@@ -299,7 +299,7 @@ int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float
  *   do_optimizer_step = 1 step of that handle discards itself too, whatever its own count — so a caller that enqueues many steps
  *   ahead of its reads of the counts finds parameters and moments exactly as the last step BEFORE the first overflow left them,
  *   needs no snapshot to return to, and continues from there (with larger buffers, i.e. a new handle, or after
- *   mi355gs_trainer_rearm).  (mi355gs_trainer_optimizer_step, below, is the caller's own decision and is not gated.)
+ *   mi355gs_trainer_rearm).  (mi355gs_trainer_optimizer_step, below, is gated only if asked to be.)
  *   lr[7], step[7] (1-based Adam step of each group): host arrays.  loss_out: device float[1].
  * ---------------------------------------------------------------------------------------------- */
 size_t mi355gs_trainer_workspace_bytes(int P, int W, int H, int V, int64_t capacity);
@@ -312,9 +312,13 @@ int mi355gs_trainer_step(void* trainer, void* stream, int view, int sh_degree, c
 /* Re-arms the commit gate of a handle whose step overflowed (stream-ordered: steps enqueued after it commit again). */
 int mi355gs_trainer_rearm(void* trainer, void* stream);
 /* PerPointAdam over all 7 groups with the gradients left by the last mi355gs_trainer_step(..., do_optimizer_step = 0):
- * lets a caller inspect the loss / instance count of an iteration before committing its update. */
+ * lets a caller inspect the loss / instance count of an iteration before committing its update (commit_gate = 0: the caller's
+ * own decision, not gated) — or, commit_gate = 1 (ABI v8), split an iteration in two enqueues without having seen the count:
+ * the launch then carries the same sticky device-side gate as a do_optimizer_step = 1 step, on the count of the frame whose
+ * gradients it applies.  (What that buys: forward + backward of iteration t + 1 can be enqueued BEFORE the host reads the loss
+ * of iteration t, its update after — the device never waits for the host and the host still sees every loss.) */
 int mi355gs_trainer_optimizer_step(void* trainer, void* stream, const float* lr, const int32_t* step, float beta1, float beta2,
-                                   float eps);
+                                   float eps, int commit_gate);
 void mi355gs_trainer_destroy(void* trainer);
 /* Device pointer of the gradient buffer of parameter group k (0..6: xyz, f_dc, f_rest, opacity, scaling, rotation, poses)
  * as left by the last mi355gs_trainer_step — for tests and diagnostics (gradient parity of the fused step). */

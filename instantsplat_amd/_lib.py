@@ -60,7 +60,7 @@ _SIGNATURES = {
     "mi355gs_trainer_create": (c_void_p, [c_int, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_trainer_step": (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
                                      c_int, _P, _P]),
-    "mi355gs_trainer_optimizer_step": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float]),
+    "mi355gs_trainer_optimizer_step": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_int]),
     "mi355gs_trainer_destroy": (None, [_P]),
     "mi355gs_trainer_grad": (_P, [_P, c_int]),
 }

@@ -726,6 +726,9 @@ __device__ __forceinline__ void sort_one_tile(int tile, const uint32_t* __restri
 #if GS_SORT_TWO_RUNS >= 2
   else if (n <= SORT_THREADS * 3) sort_tile_two_runs<2, 1>(s_keys, keys, list, s, n);
 #endif
+#if GS_SORT_TWO_RUNS >= 4
+  else if (n <= SORT_THREADS * 4) sort_tile_two_runs<2, 2>(s_keys, keys, list, s, n);
+#endif
   else if (n <= SORT_THREADS * 4) sort_tile_regs<4>(s_keys, keys, list, s, n);
 #if GS_SORT_TWO_RUNS >= 1
   else if (n <= SORT_THREADS * 5) sort_tile_two_runs<4, 1>(s_keys, keys, list, s, n);

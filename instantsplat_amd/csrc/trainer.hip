@@ -267,12 +267,13 @@ int mi355gs_trainer_rearm(void* handle, void* stream_) {
 }
 
 int mi355gs_trainer_optimizer_step(void* handle, void* stream_, const float* lr, const int32_t* step, float beta1, float beta2,
-                                   float eps) {
+                                   float eps, int commit_gate) {
   Trainer* t = (Trainer*)handle;
   if (!t || !lr || !step || !t->consts_ready) return MI355GS_EINVAL;  // needs the gradients of a preceding step
   // gate flags of the gradients produced by the preceding mi355gs_trainer_step(..., do_optimizer_step = 0) are still in place
   g_fused.gate = t->adam_scratch;
-  const int rc = trainer_adam(t, (hipStream_t)stream_, lr, step, beta1, beta2, eps, false);   // the caller has seen the count
+  // commit_gate = 0: the caller has seen the count; 1: it has not — the launch decides on the device like a one-call step's
+  const int rc = trainer_adam(t, (hipStream_t)stream_, lr, step, beta1, beta2, eps, commit_gate != 0);
   g_fused = GsFusedStepHooks();
   return rc;
 }

@@ -50,8 +50,8 @@ class TrainState:
     rng: random.Random = field(default_factory=lambda: random.Random(0))
     last_loss: Optional[torch.Tensor] = None
     _trainer: object = None
-    _loss_slot: Optional[torch.Tensor] = None
-    _prepared: object = None   # (saved host state, arguments) of the NEXT iteration's host half, see _fused_synced_iteration
+    _prepared: object = None   # the NEXT iteration, host half done and forward + backward enqueued: (saved host state, arguments,
+                               # result slot, event, camera), see _fused_synced_iteration
 
 
 def setup_training_from_init(scene, device, opt: OptimizationParams | None = None, pipe: PipelineParams | None = None,
@@ -201,14 +201,18 @@ def release_trainer(st: TrainState):
 
 
 def _fused_synced_iteration(st: TrainState):
-    """The reference's loop shape — loss read back on the host every iteration — on the one-call fused step: the WHOLE
-    iteration is enqueued (forward, backward, optimizer), loss and instance count come back in ONE read-back.  The optimizer
-    launch carries a device-side commit gate (it writes nothing when the frame's instance count exceeded the buffers,
-    csrc/trainer.hip), so the host does not have to see the count before the update is enqueued, and an iteration that did
-    overflow is simply redone on the exact-sizing autograd path: parameters and moments are still the ones it started from.
-    While the device works on iteration t the host runs the host half of iteration t + 1 (LR schedule, view sampling, step
-    counts, argument marshalling: FusedTrainer.prepare) — results cannot depend on when that happens, the blocking read-back of
-    every iteration stays (train.py:188), and `cancel_prepared` takes the half iteration back when the loop is left."""
+    """The reference's loop shape — loss read back on the host every iteration — on the one-call fused step, with the device
+    never waiting for the host.  An iteration is enqueued in two parts: forward + backward (mi355gs_trainer_step with the
+    optimizer deferred) and the optimizer launch (mi355gs_trainer_optimizer_step), which carries the sticky device-side commit
+    gate: it writes nothing when the frame's instance count exceeded the buffers (and neither does any launch behind it), so
+    nothing enqueued depends on the host having seen a count.  A call for iteration t
+      1. enqueues iteration t's optimizer launch (its forward + backward were enqueued by the previous call — or are now),
+      2. runs the host half of iteration t + 1 (LR schedule, view sampling, step counts: FusedTrainer.prepare) and enqueues its
+         forward + backward — they read the parameters iteration t's update leaves, in stream order, and write only scratch,
+      3. waits for the event recorded behind iteration t's backward and reads its loss and count from pinned host memory.
+    When the call returns, the state is iteration t's (parameters and moments after its update, in stream order); what is in
+    flight for t + 1 has changed nothing but the handle's scratch, and `cancel_prepared` takes its host half back when the loop
+    is left.  An iteration that overflowed is redone on the exact-sizing autograd path: the device discarded its update."""
     tr = getattr(st, "_trainer", None)
     if tr is None:
         st._prepared = None
@@ -218,26 +222,35 @@ def _fused_synced_iteration(st: TrainState):
                     render(cam, st.gaussians, st.pipe, st.background, camera_pose=st.gaussians.get_RT(cam.uid))
         need = max(BinningPolicy.known[hint_key(st, c)] for c in st.cameras)
         tr = st._trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
-        # loss and instance count are stored by the kernels that produce them straight into two words of pinned, device-mapped
+        # loss and instance count are stored by the kernels that produce them straight into words of pinned, device-mapped
         # host memory (count as int32: a float32 detour would round counts above 2^24, reachable at 1 M Gaussians / 1080p, and
-        # could hide an overflow of a few instances): the iteration's read-back is a wait for the stream, not a copy
-        st._host_words = torch.zeros(2, dtype=torch.int32, pin_memory=(tr.dev.type == "cuda"))
-        st._loss_slot = st._host_words[0:1].view(torch.float32)
-    pre = getattr(st, "_prepared", None)
-    if pre is None:
+        # could hide an overflow of a few instances): the iteration's read-back is a wait for an event, not a copy.  Two pairs:
+        # iteration t + 1 writes its own while iteration t's are still to be read.
+        st._host_words = torch.zeros(4, dtype=torch.int32, pin_memory=(tr.dev.type == "cuda"))
+        st._loss_slots = [st._host_words[0:1].view(torch.float32), st._host_words[2:3].view(torch.float32)]
+        st._count_slots = [st._host_words[1:2], st._host_words[3:4]]
+    cuda = tr.dev.type == "cuda"
+
+    def enqueue_forward_backward(slot):
         saved = _host_state(st, tr)
         args = tr.prepare()
-    else:
-        saved, args = pre
-        st._prepared = None
-    cam = tr.launch(args, st._loss_slot, st._host_words[1:2])
+        cam = tr.launch(args, st._loss_slots[slot], st._count_slots[slot], defer_optimizer=True)
+        ev = None
+        if cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(tr.dev))
+        return saved, args, slot, ev, cam
+
+    pre = getattr(st, "_prepared", None)
+    st._prepared = None
+    saved, args, slot, ev, cam = pre if pre is not None else enqueue_forward_backward(0)
+    tr.apply_optimizer(gated=True)            # (no launch on the run's last iteration: prepare() left nothing pending)
     nxt = None
     if args["it"] < st.opt.iterations:        # (the run's last iteration has no successor)
-        nxt_saved = _host_state(st, tr)
-        nxt = (nxt_saved, tr.prepare())       # host half of the next iteration, under the device's work on this one
-    if tr.dev.type == "cuda":
-        torch.cuda.current_stream(tr.dev).synchronize()
-    loss, r = float(st._loss_slot[0]), int(st._host_words[1])
+        nxt = enqueue_forward_backward(slot ^ 1)
+    if ev is not None:
+        ev.synchronize()
+    loss, r = float(st._loss_slots[slot][0]), int(st._count_slots[slot][0])
     BinningPolicy.known[hint_key(st, cam)] = int(r)
     if r > tr.capacity:   # dropped instances (the device left the update out): redo exactly, and grow the buffers for the next iterations
         _restore_host_state(st, tr, saved)
@@ -418,12 +431,14 @@ class FusedTrainer:
             BinningPolicy.defer(count_out, self.capacity, self.dev, event=record_event)
         return cam
 
-    def apply_optimizer(self):
+    def apply_optimizer(self, gated: bool = False):
+        """The optimizer launch of the last `launch(..., defer_optimizer=True)`.  gated: the host has not seen that frame's
+        instance count — the launch carries the device-side commit gate (include/mi355gs.h)."""
         if self._pending_opt is not None:
             lr, steps, b1, b2, eps = self._pending_opt
             with _lib.on_device(self.dev):
                 _lib.check(_lib.lib().mi355gs_trainer_optimizer_step(ctypes.c_void_p(self.handle), _lib.stream_ptr(self.dev), lr, steps,
-                                                                     b1, b2, eps), "trainer_optimizer_step")
+                                                                     b1, b2, eps, 1 if gated else 0), "trainer_optimizer_step")
             self._pending_opt = None
 
 
@@ -596,8 +611,11 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
              fused_loss: bool = True, model_path: str | None = None, saving_iterations=(), checkpoint_iterations=(),
              start_checkpoint: str | None = None, opt: OptimizationParams | None = None, n_views: int | None = None,
              model: ModelParams | None = None, after_setup=None, resolution=1) -> dict:
-    """Train one scene. run_ahead=True uses the sync-free driver (identical results, see RunAhead);
-    run_ahead=False reproduces the reference's per-iteration host read-backs.
+    """Train one scene.  run_ahead=True (default): the fastest loop with the reference's results — the one-call step with every
+    iteration's loss read back while the device already works on the next iteration (`train_iteration(fused_step=True)`,
+    _fused_synced_iteration) for the configuration the reference's scripts run, the window-verified RunAhead driver on the
+    autograd operators otherwise.  run_ahead=False: the reference's own loop shape on the drop-in operators (autograd,
+    `loss.item()`, `optimizer.step()` per iteration).
 
     scene: a synthetic PointmapScene, a `scene_io.InitScene`, or the path of an init directory (`-s <source_path>` with
     `n_views` and `-r <resolution>`; loaded with `scene_io.load_init_scene`, which also leaves input.ply and cameras.json in
@@ -644,9 +662,17 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     first = last = None
-    ra = RunAhead(st, fused_loss=fused_loss) if run_ahead else None
+    one_call = bool(run_ahead and fused_loss and FusedTrainer.supported(st))
+    ra = RunAhead(st, fused_loss=fused_loss) if run_ahead and not one_call else None
+    ema = 0.0
     for i in range(int(first_iter), iterations):
-        if ra is not None:
+        if one_call:
+            last = train_iteration(st, fused_step=True)
+            first = last if first is None else first
+            ema = 0.4 * last + 0.6 * ema   # reference train.py:188
+            if log_every and (i + 1) % log_every == 0:
+                print(f"[iter {i + 1}] ema loss {ema:.6f}")
+        elif ra is not None:
             ema = ra.step()
             if first is None and ema is not None:
                 first = st.last_loss
@@ -666,7 +692,7 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
                 _save_outputs(st, it, model_path, colmap_ids)
             if it in checkpoints:
                 torch.save((st.gaussians.capture(), it), os.path.join(model_path, f"chkpnt{it}.pth"))
-    cancel_prepared(st)
+    release_trainer(st)
     if ra is not None:
         ra.flush()
         last = st.last_loss
