@@ -9,7 +9,9 @@ LR schedule, random view, render (pose transform + rasterizer forward), fused L1
 `GaussianRasterizer` / `fused_ssim` / `PerPointAdam` through the compiled binding, autograd, and BOTH of the reference's blocking
 host read-backs per iteration (the operator's instance count, `loss.item()` at train.py:188).  Measured next to it under the same
 protocol and reported as siblings (`loops`): the same iteration behind one library call with the loss read back every iteration
-(`one_call_synced`) and without that read-back (`one_call_run_ahead`: identical results, the loss EMA is evaluated every 10).
+(`one_call_synced`: the library's two-part step — forward + backward of iteration t + 1 are enqueued before the host reads
+iteration t's loss, its optimizer launch, gated on the device, after: the device never waits for the host) and without that
+read-back (`one_call_run_ahead`: identical results, the loss EMA is evaluated every 10, the queue drains at every window).
 
 Timed region: each loop runs on a fresh state fast-forwarded (untimed) to iteration 200 of training, W warm-up iterations, then
 blocks of exactly --steps iterations, each bracketed by barrier + device synchronize, MAX over ranks; the blocks cover iterations
@@ -530,11 +532,12 @@ def main():
                                                                           "torch's own l1_loss (abs / mean), the drop-in fused_ssim, scalar arithmetic in "
                                                                           "eager PyTorch — the headline takes (1-l)*L1 + l*(1-SSIM) as one node, "
                                                                           "instantsplat_amd.fused_ssim.fused_l1_ssim_loss"),
-                      "one_call_synced": dict(synced, what="mi355gs_trainer_step: the whole iteration behind one library call, loss and instance "
-                                                           "count read back every iteration (device-side commit gate, host half of the next "
-                                                           "iteration overlapped)"),
-                      "one_call_run_ahead": dict(run_ahead, what="the same step without the per-iteration read-back (identical results; EMA "
-                                                                 "evaluated every 10 iterations)", window_replays=sum(replays))},
+                      "one_call_synced": dict(synced, what="mi355gs_trainer_step + mi355gs_trainer_optimizer_step(commit_gate=1): loss and instance count of "
+                                                           "EVERY iteration read back on the host; forward + backward of iteration t + 1 are enqueued "
+                                                           "before that read, the (device-gated, sticky) optimizer launch after it — what "
+                                                           "instantsplat_amd.train.training() runs by default"),
+                      "one_call_run_ahead": dict(run_ahead, what="the one-call step without the per-iteration read-back (identical results; EMA "
+                                                                 "evaluated and counts verified every 10 iterations, where the queue drains)", window_replays=sum(replays))},
             "iters_per_sec_dropin_reference_loop": headline["iters_per_sec"], "iters_per_sec_autograd_path": headline["iters_per_sec"],
             "iters_per_sec_dropin_reference_loop_torch_l1": strict["iters_per_sec"],
             "iters_per_sec_with_per_iteration_loss_readback": synced["iters_per_sec"], "iters_per_sec_one_call_synced": synced["iters_per_sec"],
