@@ -768,7 +768,7 @@ void gs_pin_min_units(int v) { g_min_units_pinned = v; }
 int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint32_t* start, int32_t* num_rendered, uint32_t* order,
                          uint32_t* meta, uint32_t* seg_first, uint32_t* part_first) {
   // more tiles than threads and the counts fit the workgroup's dynamic LDS: the staged form (see the kernel)
-  const size_t stage_bytes = (size_t)((T + SCAN_THREADS - 1) / SCAN_THREADS) * SCAN_THREADS * 4;   // [per][SCAN_THREADS] words
+  const size_t stage_bytes = (size_t)((T + SCAN_THREADS - 1) / SCAN_THREADS) * SCAN_THREADS * 4;   // T words, rounded up to whole rounds of the workgroup
   if (T > SCAN_THREADS && stage_bytes <= SCAN_STAGE_MAX_BYTES)
     hipLaunchKernelGGL(k_scan_tiles<true>, dim3(1), dim3(SCAN_THREADS), stage_bytes, stream, T, count, start, num_rendered, order, meta,
                        seg_first, part_first, (uint32_t)gs_min_units());
