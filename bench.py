@@ -218,6 +218,9 @@ def main():
         return (lambda: train_iteration(st_)), (lambda: None), (lambda: None)
 
     def dropin_loop_reference_loss(st_):   # ... with the loss formed exactly as train.py:171-176 does: torch l1_loss + fused_ssim + scalar arithmetic
+        return (lambda: train_iteration(st_, fused_loss="torch")), (lambda: None), (lambda: None)
+
+    def dropin_loop_train_py_loss(st_):    # ... the same expression with utils/loss_utils.l1_loss aliased to this package's drop-in (one HIP node)
         return (lambda: train_iteration(st_, fused_loss=False)), (lambda: None), (lambda: None)
 
     def one_call_synced(st_):  # the same iteration behind ONE library call, loss read back every iteration
@@ -255,6 +258,7 @@ def main():
     # ---- the timed region.  NO instrumentation runs inside it (round 3 sampled kernel events there: ~1 % of ms_per_step).
     headline, st = measure(dropin_loop)
     strict, _ = measure(dropin_loop_reference_loss)
+    train_py, _ = measure(dropin_loop_train_py_loss)
     synced, _ = measure(one_call_synced)
     run_ahead, _ = measure(one_call_run_ahead)
     elapsed = headline["ms_per_step"] * 1e-3 * args.steps
@@ -532,6 +536,9 @@ def main():
                                                                           "torch's own l1_loss (abs / mean), the drop-in fused_ssim, scalar arithmetic in "
                                                                           "eager PyTorch — the headline takes (1-l)*L1 + l*(1-SSIM) as one node, "
                                                                           "instantsplat_amd.fused_ssim.fused_l1_ssim_loss"),
+                      "dropin_reference_loop_train_py_loss": dict(train_py, what="train.py:171-176 as written — l1_loss(image, gt), fused_ssim, scalar "
+                                                                                "arithmetic — with utils/loss_utils aliased to instantsplat_amd.loss_utils "
+                                                                                "like the operator packages (l1_loss = one HIP node: 3 launches for 7)"),
                       "one_call_synced": dict(synced, what="mi355gs_trainer_step + mi355gs_trainer_optimizer_step(commit_gate=1): loss and instance count of "
                                                            "EVERY iteration read back on the host; forward + backward of iteration t + 1 are enqueued "
                                                            "before that read, the (device-gated, sticky) optimizer launch after it — what "
@@ -540,6 +547,7 @@ def main():
                                                                  "evaluated and counts verified every 10 iterations, where the queue drains)", window_replays=sum(replays))},
             "iters_per_sec_dropin_reference_loop": headline["iters_per_sec"], "iters_per_sec_autograd_path": headline["iters_per_sec"],
             "iters_per_sec_dropin_reference_loop_torch_l1": strict["iters_per_sec"],
+            "iters_per_sec_dropin_reference_loop_train_py_loss": train_py["iters_per_sec"],
             "iters_per_sec_with_per_iteration_loss_readback": synced["iters_per_sec"], "iters_per_sec_one_call_synced": synced["iters_per_sec"],
             "iters_per_sec_run_ahead": run_ahead["iters_per_sec"], "run_ahead_window_replays": sum(replays),
             "binding": _lib.BINDING,

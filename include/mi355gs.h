@@ -182,6 +182,16 @@ int mi355gs_ssim_backward(void* stream, int B, int C, int H, int W, const float*
  * The binding's forward calls this and keeps the gradient; its backward multiplies it by the incoming dL/dloss. */
 int mi355gs_l1_ssim_loss_fused(void* stream, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
                                float lambda_dssim, float* ssim_mean, float* l1_mean, float* loss, float* dloss_dimg1);
+
+/* ------------------------------------------------------------------------------------------------
+ * l1_loss(network_output, gt) = mean |a - b| over n contiguous floats (reference utils/loss_utils.py:39-40, called at
+ * train.py:171) and its gradient w.r.t. a: sgn(a - b) * (*grad_scale) / n, as autograd computes it for abs(a - b).mean()
+ * (ABI v8).  scratch: mi355gs_l1_scratch_bytes(n) bytes of device memory; mean_out, grad_scale: device float[1].
+ * Two launches forward (per-workgroup partial sums in float, finished in double in a fixed order), one backward.
+ * ---------------------------------------------------------------------------------------------- */
+size_t mi355gs_l1_scratch_bytes(int64_t n);
+int mi355gs_l1_loss_forward(void* stream, int64_t n, const float* a, const float* b, void* scratch, float* mean_out);
+int mi355gs_l1_loss_backward(void* stream, int64_t n, const float* a, const float* b, const float* grad_scale, float* d_a);
 /* ------------------------------------------------------------------------------------------------
  * simple-knn
  * replaces: simple_knn._C.distCUDA2(points) at reference scene/gaussian_model.py:156 —

@@ -469,7 +469,55 @@ __global__ __launch_bounds__(FTHREADS) void k_l1_ssim_fused(int H, int W, const 
   }
 }
 
+// ---- l1_loss(network_output, gt) = mean |a - b| (reference utils/loss_utils.py:39-40; train.py:171) as one pass + the
+// finishing launch above instead of PyTorch's sub / abs / mean, and its gradient sgn(a - b) * g / n as one launch instead of
+// the four of (mean, abs, sub)'s backward nodes.  Partial sums per workgroup in float, finished in double, in a fixed order.
+constexpr int L1_THREADS = 256, L1_PER_THREAD = 16;   // 4096 elements per workgroup
+__global__ __launch_bounds__(L1_THREADS) void k_l1_partial(long long n, const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ partial) {
+  __shared__ float s_red[L1_THREADS / 64];
+  const long long base = (long long)blockIdx.x * (L1_THREADS * L1_PER_THREAD);
+  float acc = 0.f;
+  const bool vec = ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) && base + L1_THREADS * L1_PER_THREAD <= n;
+  if (vec) {
+#pragma unroll
+    for (int r = 0; r < L1_PER_THREAD / 4; ++r) {
+      const long long j = (base >> 2) + threadIdx.x + (long long)L1_THREADS * r;
+      const float4 x = reinterpret_cast<const float4*>(a)[j], y = reinterpret_cast<const float4*>(b)[j];
+      acc += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+    }
+  } else {
+    for (int r = 0; r < L1_PER_THREAD; ++r) {
+      const long long i = base + threadIdx.x + (long long)L1_THREADS * r;
+      if (i < n) acc += fabsf(a[i] - b[i]);
+    }
+  }
+  acc = gs_wave_sum_row3(acc);   // the total is in lane 63
+  if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    partial[2 * blockIdx.x + 1] = 0.f;   // (the finishing kernel sums pairs: [ssim, l1] for its other callers)
+  }
+}
+
+__global__ __launch_bounds__(256) void k_l1_bwd(long long n, const float* __restrict__ a, const float* __restrict__ b,
+                                                const float* __restrict__ grad_scale, float n_as_float, float* __restrict__ d_a) {
+  // what autograd computes for abs(a - b).mean(): the incoming gradient divided by the element count, times sgn(a - b) (0 at 0)
+  const float s = *grad_scale / n_as_float;
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (((((uintptr_t)a | (uintptr_t)b | (uintptr_t)d_a) & 15) == 0) && i0 + 4 <= n) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i0 >> 2], y = reinterpret_cast<const float4*>(b)[i0 >> 2];
+    auto sg = [&](float d) { return d > 0.f ? s : (d < 0.f ? -s : 0.f); };
+    reinterpret_cast<float4*>(d_a)[i0 >> 2] = make_float4(sg(x.x - y.x), sg(x.y - y.y), sg(x.z - y.z), sg(x.w - y.w));
+  } else {
+    for (long long i = i0; i < min(n, i0 + 4); ++i) { const float d = a[i] - b[i]; d_a[i] = d > 0.f ? s : (d < 0.f ? -s : 0.f); }
+  }
+}
+
 }  // namespace
+
+static inline int l1_nblocks(long long n) { return (int)((n + L1_THREADS * L1_PER_THREAD - 1) / (L1_THREADS * L1_PER_THREAD)); }
 
 static inline int ssim_nblocks(int B, int C, int H, int W) { return B * C * ((H + TS - 1) / TS) * ((W + TSX - 1) / TSX); }
 
@@ -517,6 +565,29 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
                      ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1);
   GS_CHECK_LAUNCH("ssim_bwd");
+  return MI355GS_OK;
+}
+
+size_t mi355gs_l1_scratch_bytes(int64_t n) { return gs_align((size_t)(n > 0 ? l1_nblocks(n) : 1) * 2 * sizeof(float)); }
+
+int mi355gs_l1_loss_forward(void* stream_, int64_t n, const float* a, const float* b, void* scratch, float* mean_out) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (n <= 0 || n > (int64_t)1 << 40 || !a || !b || !scratch || !mean_out) return MI355GS_EINVAL;
+  hipLaunchKernelGGL(k_l1_partial, dim3(l1_nblocks(n)), dim3(L1_THREADS), 0, stream, (long long)n, a, b, (float*)scratch);
+  GS_CHECK_LAUNCH("l1_partial");
+  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, l1_nblocks(n), 1.0 / (double)n, (const float*)scratch, mean_out,
+                     (float*)nullptr, (float*)nullptr, 0.f);
+  GS_CHECK_LAUNCH("l1_finish");
+  return MI355GS_OK;
+}
+
+int mi355gs_l1_loss_backward(void* stream_, int64_t n, const float* a, const float* b, const float* grad_scale, float* d_a) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (n <= 0 || n > (int64_t)1 << 40 || !a || !b || !grad_scale || !d_a) return MI355GS_EINVAL;
+  hipLaunchKernelGGL(k_l1_bwd, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, (long long)n, a, b, grad_scale, (float)n, d_a);
+  GS_CHECK_LAUNCH("l1_bwd");
   return MI355GS_OK;
 }
 

@@ -42,6 +42,9 @@ struct Abi {
   decltype(&mi355gs_posed_backward) posed_backward = nullptr;
   decltype(&mi355gs_ssim_scratch_bytes) ssim_scratch_bytes = nullptr;
   decltype(&mi355gs_l1_ssim_loss_fused) l1_ssim_loss_fused = nullptr;
+  decltype(&mi355gs_l1_scratch_bytes) l1_scratch_bytes = nullptr;
+  decltype(&mi355gs_l1_loss_forward) l1_loss_forward = nullptr;
+  decltype(&mi355gs_l1_loss_backward) l1_loss_backward = nullptr;
   decltype(&mi355gs_ssim_forward) ssim_forward = nullptr;
   decltype(&mi355gs_ssim_backward) ssim_backward = nullptr;
   decltype(&mi355gs_adam_multi_step) adam_multi_step = nullptr;
@@ -70,6 +73,9 @@ void bind_abi(const std::map<std::string, uintptr_t>& sym, bool allow_cpu_tensor
   GS_BIND(posed_backward, mi355gs_posed_backward);
   GS_BIND(ssim_scratch_bytes, mi355gs_ssim_scratch_bytes);
   GS_BIND(l1_ssim_loss_fused, mi355gs_l1_ssim_loss_fused);
+  GS_BIND(l1_scratch_bytes, mi355gs_l1_scratch_bytes);
+  GS_BIND(l1_loss_forward, mi355gs_l1_loss_forward);
+  GS_BIND(l1_loss_backward, mi355gs_l1_loss_backward);
   GS_BIND(ssim_forward, mi355gs_ssim_forward);
   GS_BIND(ssim_backward, mi355gs_ssim_backward);
   GS_BIND(adam_multi_step, mi355gs_adam_multi_step);
@@ -581,6 +587,36 @@ struct L1SsimLossFn : public torch::autograd::Function<L1SsimLossFn> {
 std::vector<Tensor> l1_ssim_loss(Tensor img1, Tensor img2, double lambda_dssim) { return L1SsimLossFn::apply(img1, img2, lambda_dssim); }
 
 // ------------------------------------------------------------------------------------------------
+// l1_loss(network_output, gt) = abs(a - b).mean() (reference utils/loss_utils.py:39-40, train.py:171; Python twin:
+// loss_utils.py::_L1Loss): two launches instead of sub / abs / mean, one instead of their four backward kernels.  The gradient
+// goes to network_output only (gt is data wherever the reference calls it).
+// ------------------------------------------------------------------------------------------------
+struct L1LossFn : public torch::autograd::Function<L1LossFn> {
+  static Tensor forward(AutogradContext* ctx, Tensor a_, Tensor b_) {
+    TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    const Tensor a = f32c(a_, "network_output", a_), b = f32c(b_, "gt", a);
+    TORCH_CHECK(a.sizes() == b.sizes() && a.numel() > 0, "l1_loss expects two non-empty tensors of equal shape");
+    const DeviceScope dev(a);
+    Tensor scratch = empty_bytes(g_abi.l1_scratch_bytes(a.numel()), a);
+    Tensor out = at::empty({}, a.options());
+    check(g_abi.l1_loss_forward(dev.stream, a.numel(), fp(a), fp(b), scratch.data_ptr(), fp(out)), "l1_loss_forward");
+    ctx->save_for_backward({a, b});
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &a = saved[0], &b = saved[1];
+    const Tensor g = f32c(grad_out[0], "grad", a);
+    const DeviceScope dev(a);
+    Tensor d = at::empty_like(a);
+    check(g_abi.l1_loss_backward(dev.stream, a.numel(), fp(a), fp(b), fp(g), fp(d)), "l1_loss_backward");
+    return {d, Tensor()};
+  }
+};
+
+Tensor l1_loss(Tensor a, Tensor b) { return L1LossFn::apply(a, b); }
+
+// ------------------------------------------------------------------------------------------------
 // fused_ssim(img1, img2, padding, train): the operator the reference imports at train.py:39-43 and calls at :173
 // (Python twin: fused_ssim/__init__.py::_FusedSSIM).  Gradient with respect to img1 only, as upstream.
 // ------------------------------------------------------------------------------------------------
@@ -757,6 +793,7 @@ struct AdamPlan {
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled PyTorch binding of libmi355gs.so's drop-in operators (no compute of its own)";
   m.def("bind", &bind_abi, "hand over the C-ABI entry points (name -> address) of the loaded libmi355gs build; allow_cpu_tensors: test tier only");
+  m.def("l1_loss", &l1_loss, "utils/loss_utils.py::l1_loss as one node (mi355gs_l1_loss_forward / _backward)");
   m.def("render_posed", &render_posed);
   m.def("forward_owns_scratch", [](bool on) { const bool was = g_forward_owns_scratch; g_forward_owns_scratch = on; return was; },
         "A/B switch: true (default) = a forward that a backward will follow allocates the backward's accumulators and has the projection kernel clear them");

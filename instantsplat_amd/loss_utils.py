@@ -1,0 +1,101 @@
+"""Drop-in for the reference's `utils/loss_utils.py` (same names, arguments and results) on the HIP kernels.
+
+    l1_loss(network_output, gt)                       -> abs(network_output - gt).mean()      (reference :39-40, train.py:171)
+    l2_loss(network_output, gt)                       -> ((network_output - gt) ** 2).mean()  (reference :42-43)
+    ssim(img1, img2, window_size=11, size_average=True) -> mean SSIM, 11x11 Gaussian window   (reference :55-85; what train.py:175
+                                                         falls back to without the fused_ssim package)
+    l1_loss_mask(network_output, gt, mask)            (reference :17-23, pose tracking)
+
+`l1_loss` is ONE autograd node over `mi355gs_l1_loss_forward / _backward` (two launches forward, one backward) where the
+reference's expression is three eager kernels forward and four backward — the loop an unmodified train.py runs is bound by the
+host's launch rate, so launches are what count (bench.py `loops.dropin_reference_loop_torch_l1`).  Alias it like the operator
+packages:  sys.modules["utils.loss_utils"] = instantsplat_amd.loss_utils
+Inputs the kernels do not take (other dtypes, a `gt` that requires a gradient, size_average=False, other window sizes) go
+through the reference's own PyTorch expressions, restated below.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .fused_ssim import fused_ssim
+
+
+class _L1Loss(torch.autograd.Function):
+    """ctypes twin of csrc_torch/binding.cpp::L1LossFn"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        L = _lib.lib()
+        a, b = _lib.f32c(a), _lib.f32c(b)
+        dev = _lib.require_device(a, b)
+        n = a.numel()
+        scratch = torch.empty(int(L.mi355gs_l1_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(L.mi355gs_l1_loss_forward(_lib.stream_ptr(dev), n, _lib.ptr(a), _lib.ptr(b), _lib.ptr(scratch), _lib.ptr(out)),
+                       "l1_loss_forward")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        L = _lib.lib()
+        g = _lib.f32c(g)
+        d = torch.empty_like(a)
+        with _lib.on_device(a.device):
+            _lib.check(L.mi355gs_l1_loss_backward(_lib.stream_ptr(a.device), a.numel(), _lib.ptr(a), _lib.ptr(b), _lib.ptr(g), _lib.ptr(d)),
+                       "l1_loss_backward")
+        return d, None
+
+
+def _kernel_can_take(network_output, gt):
+    return (isinstance(network_output, torch.Tensor) and isinstance(gt, torch.Tensor) and network_output.dtype == torch.float32
+            and gt.dtype == torch.float32 and network_output.shape == gt.shape and network_output.numel() > 0
+            and network_output.device == gt.device and not gt.requires_grad)
+
+
+def l1_loss(network_output, gt):
+    if not _kernel_can_take(network_output, gt):
+        return torch.abs((network_output - gt)).mean()
+    ext = _lib.compiled()
+    if ext is not None:
+        return ext.l1_loss(network_output, gt)
+    return _L1Loss.apply(network_output, gt)
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def l1_loss_mask(network_output, gt, mask):
+    masked_diff = torch.abs(network_output - gt) * mask
+    return masked_diff.sum() / mask.sum()
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """The reference's conv2d SSIM (zero padding, 11x11 Gaussian window of sigma 1.5) = fused_ssim(padding="same")."""
+    if window_size == 11 and size_average and img1.dtype == torch.float32:
+        a = img1 if img1.dim() == 4 else img1.unsqueeze(0)
+        b = img2 if img2.dim() == 4 else img2.unsqueeze(0)
+        return fused_ssim(a, b)
+    return _ssim_conv2d(img1, img2, window_size, size_average)
+
+
+def _ssim_conv2d(img1, img2, window_size, size_average):
+    """SSIM as the reference spells it in PyTorch (:45-85): a (window_size x window_size) Gaussian of sigma 1.5, built from
+    float64 values rounded to float32 and normalised in float32, applied per channel with zero padding; C1 = 0.01^2, C2 = 0.03^2."""
+    import math
+    import torch.nn.functional as F
+    channel = img1.size(-3)
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / (2 * 1.5 ** 2)) for x in range(window_size)], dtype=torch.float32)
+    g = (g / g.sum()).unsqueeze(1)
+    window = g.mm(g.t()).unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous().to(img1.device).type_as(img1)
+    blur = lambda x: F.conv2d(x, window, padding=window_size // 2, groups=channel)
+    mu1, mu2 = blur(img1), blur(img2)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1, s2, s12 = blur(img1 * img1) - mu1_sq, blur(img2 * img2) - mu2_sq, blur(img1 * img2) - mu12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)

@@ -27,8 +27,7 @@ from .scene import GaussianModel, confidence_to_lr_modifiers
 from .synthetic import PointmapScene
 
 
-def l1_loss(a, b):
-    return torch.abs(a - b).mean()
+from .loss_utils import l1_loss   # reference utils/loss_utils.py:39-40 as one HIP node
 
 
 def psnr(img1, img2):
@@ -151,10 +150,12 @@ def _forward_backward_step(st: TrainState, fused_loss: bool):
         pkg = render(cam, g, st.pipe, bg, camera_pose=pose)
     image = pkg["render"]
     gt = st.gt_images[cam.uid]
-    if fused_loss:
+    if fused_loss is True:
         loss, _ = fused_l1_ssim_loss(image.unsqueeze(0), gt.unsqueeze(0), opt.lambda_dssim)
     else:
-        Ll1 = l1_loss(image, gt)
+        # train.py:171-176 as written: l1_loss + fused_ssim + scalar arithmetic.  fused_loss=False: utils/loss_utils.l1_loss is this
+        # package's drop-in (loss_utils.py: one HIP node); fused_loss="torch": the reference's own PyTorch expression for it
+        Ll1 = l1_loss(image, gt) if fused_loss is False else torch.abs((image - gt)).mean()
         loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - fused_ssim(image.unsqueeze(0), gt.unsqueeze(0)))
     loss.backward()
     return loss.detach()
@@ -268,7 +269,7 @@ def _fused_synced_iteration(st: TrainState):
 def train_iteration(st: TrainState, fused_loss: bool = True, sync_loss: bool = True, fused_step: bool = False):
     """One pass of reference train.py:140-211, with the reference's per-iteration `loss.item()` (sync_loss=True).
     fused_step=True takes the one-call library step when the configuration allows it (same results)."""
-    if fused_step and sync_loss and fused_loss and FusedTrainer.supported(st):
+    if fused_step and sync_loss and fused_loss is True and FusedTrainer.supported(st):
         out = _fused_synced_iteration(st)
         if out is not None:
             st.last_loss = out

@@ -1334,3 +1334,40 @@ def check_pose_row_node(dev, Wm=10, W=32, H=24):
             bound("pose_row_two/" + n, rel_l2(got[n], ref[n]), 2e-4 if cuda else 0.0)
         assert float(g.P.grad[2].abs().max()) == 0.0
         del r2
+
+
+def check_loss_utils_against_the_references_own(dev):
+    """instantsplat_amd.loss_utils (the drop-in for the reference's utils/loss_utils.py) against vectors its functions produced
+    (tests/golden/make_golden_loss_utils.py): l1_loss through both bindings — value to a relative 3e-7 (per-workgroup float
+    sums finished in double against PyTorch's float tree), gradient BIT for bit (sgn(a - b) * g / n, zero at exact ties) —,
+    l2_loss, ssim for the fused case (11 x 11, mean) and the cases that stay PyTorch (other window, per-image mean), l1_loss_mask."""
+    import os
+    import numpy as np
+    from instantsplat_amd import loss_utils
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_utils_vectors.npz"))
+    T = lambda k: torch.from_numpy(G[k]).to(dev)
+    cuda = torch.device(dev).type == "cuda"
+    for binding in ("compiled", "ctypes"):
+        with _with_binding(binding):
+            for k in range(5):
+                a, b = T(f"l1_{k}_a").requires_grad_(True), T(f"l1_{k}_b")
+                v = loss_utils.l1_loss(a, b)
+                assert v.dim() == 0 and v.grad_fn is not None and "L1Loss" in v.grad_fn.name(), v.grad_fn
+                (v * 1.7).backward()
+                bound("loss_utils/l1_value", abs(float(v) - float(G[f"l1_{k}_value"])) / float(G[f"l1_{k}_value"]), 3e-7)
+                assert torch.equal(a.grad.cpu(), torch.from_numpy(G[f"l1_{k}_grad"])), (binding, k)
+                bound("loss_utils/l2_value", abs(float(loss_utils.l2_loss(a.detach(), b)) - float(G[f"l2_{k}_value"])) / float(G[f"l2_{k}_value"]), 3e-7)
+            # non-contiguous input, and a gt that wants a gradient (the kernel gives none: PyTorch's expression takes over)
+            a, b = T("l1_1_a"), T("l1_1_b")
+            at = a.transpose(1, 2).contiguous().transpose(1, 2).requires_grad_(True)
+            assert not at.is_contiguous()
+            bound("loss_utils/l1_value_strided", abs(float(loss_utils.l1_loss(at, b)) - float(G["l1_1_value"])) / float(G["l1_1_value"]), 3e-7)
+            bg = b.clone().requires_grad_(True)
+            loss_utils.l1_loss(a, bg).backward()
+            assert bg.grad is not None and float(bg.grad.abs().sum()) > 0
+    x, y, mask = T("ssim_x"), T("ssim_y"), T("ssim_mask")
+    bound("loss_utils/ssim_11", abs(float(loss_utils.ssim(x, y)) - float(G["ssim_11"])), 2e-6 if cuda else 1e-6)
+    bound("loss_utils/ssim_3d", abs(float(loss_utils.ssim(x[0], y[0])) - float(G["ssim_3d"])), 2e-6 if cuda else 1e-6)
+    bound("loss_utils/ssim_7", abs(float(loss_utils.ssim(x, y, window_size=7)) - float(G["ssim_7"])), 2e-6)
+    bound("loss_utils/ssim_per_image", float((loss_utils.ssim(x, y, size_average=False).cpu() - torch.from_numpy(G["ssim_11_per_image"])).abs().max()), 2e-6)
+    bound("loss_utils/l1_mask", abs(float(loss_utils.l1_loss_mask(x, y, mask)) - float(G["l1_mask"])), 1e-6)

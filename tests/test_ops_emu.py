@@ -230,3 +230,7 @@ def test_pose_row_node(emu):
 
 def test_run_ahead_sticky_commit_gate(emu):
     ops_util.check_run_ahead_sticky_commit_gate(emu)
+
+
+def test_loss_utils_against_the_references_own(emu):
+    ops_util.check_loss_utils_against_the_references_own(emu)

@@ -130,3 +130,8 @@ def test_pose_row_node(gpu):
 @pytest.mark.gpu
 def test_run_ahead_sticky_commit_gate(gpu):
     ops_util.check_run_ahead_sticky_commit_gate(gpu)
+
+
+@pytest.mark.gpu
+def test_loss_utils_against_the_references_own(gpu):
+    ops_util.check_loss_utils_against_the_references_own(gpu)
