@@ -329,7 +329,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 R, binning = run()
 
         if _KEEP_LAST_FRAME:
-            _LAST_FRAME.update(tiles=tiles, W=W, H=H)
+            _LAST_FRAME.update(tiles=tiles, W=W, H=H, geom=geom, binning=binning, capacity=int(R), P=P)
         ctx.raster_settings = s
         ctx.num_rendered = R
         ctx.dims = (P, D, M, W, H)

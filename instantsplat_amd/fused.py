@@ -98,7 +98,7 @@ class _RenderPosed(torch.autograd.Function):
                 debug), "posed_forward_preprocess")
             R, binning = dgr.size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug)
         if dgr._KEEP_LAST_FRAME:
-            dgr._LAST_FRAME.update(tiles=tiles, W=W, H=H)
+            dgr._LAST_FRAME.update(tiles=tiles, W=W, H=H, geom=geom, binning=binning, capacity=int(R), P=P)
         ctx.settings, ctx.capacity, ctx.dims = s, R, (P, D, W, H)
         ctx.save_for_backward(xyz, rot, scaling, opl, f_dc, f_rest, pose, radii, geom, tiles, binning, bg, view, proj, origin, color)
         ctx.mark_non_differentiable(radii)

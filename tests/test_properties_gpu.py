@@ -89,3 +89,47 @@ def test_largest_config_1M_gaussians_1080p(gpu):
         assert bool(torch.isfinite(x).all()), n
         ref = -0.5 * x
         assert float((y - ref).norm() / (ref.norm() + 1e-30)) <= 1e-4, n
+
+
+def _all_tile_lists_sorted_on_device(frame):
+    """Every per-tile list of the kept frame: ascending (depth bits, Gaussian index) keys, no duplicates — checked on the device
+    over the whole instance array at once (scratch layouts: csrc/common.h).  -> (instances, per-tile counts)"""
+    tiles, geom, binning, W, H, R, P = (frame[k] for k in ("tiles", "geom", "binning", "W", "H", "capacity", "P"))
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    al = lambda x: (x + 255) & ~255
+    start = tiles[2 * al(T * 4): 2 * al(T * 4) + (T + 1) * 4].view(torch.int32).long()
+    n = int(start[T])
+    assert 0 < n <= R and int(start[0]) == 0
+    lst = binning[al(R * 8): al(R * 8) + n * 4].view(torch.int32).long()
+    assert int(lst.min()) >= 0 and int(lst.max()) < P
+    depth_bits = geom[: P * 48].view(torch.int32).view(P, 12)[:, 11].long()      # the record's depth word (non-negative floats: ordered as ints)
+    key = (depth_bits[lst] << 32) | lst
+    ascending = key[1:] > key[:-1]
+    first_of_tile = torch.zeros(n + 1, dtype=torch.bool, device=key.device)
+    first_of_tile[start[: T + 1]] = True                                          # list boundaries: no order across them
+    bad = ~ascending & ~first_of_tile[1:n]
+    assert not bool(bad.any()), int(bad.sum())
+    return n, (start[1:] - start[:-1])
+
+
+def test_c4_tile_lists_are_sorted(gpu):
+    """Sortedness at BASELINE's largest size (C4: 995,328 Gaussians, 1920x1080, 8160 tiles of ~900 keys — the lengths where the
+    tile sort takes its two-run form for a fifth of the tiles): all 7.3 M instances in ascending (depth, index) order per tile."""
+    from instantsplat_amd import diff_gaussian_rasterization as dgr
+    from instantsplat_amd.gaussian_renderer import render
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training
+    st = setup_training(syn_pointmap(12, 288, 288, 1920, 1080, seed=0), gpu)
+    g = st.gaussians
+    dgr.keep_last_frame(True)
+    try:
+        for v in (0, 7):
+            cam = st.cameras[v]
+            with torch.no_grad():
+                render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+            n, counts = _all_tile_lists_sorted_on_device(dgr._LAST_FRAME)
+            assert n > 5_000_000 and int(counts.max()) > 1024                     # (some tiles beyond one 1024-key network)
+            two_run = int(((counts > 1024) & (counts <= 1536)).sum()) + int(((counts > 512) & (counts <= 768)).sum())
+            assert two_run > 500, two_run
+    finally:
+        dgr.keep_last_frame(False)
