@@ -92,8 +92,9 @@ def test_largest_config_1M_gaussians_1080p(gpu):
 
 
 def _all_tile_lists_sorted_on_device(frame):
-    """Every per-tile list of the kept frame: ascending (depth bits, Gaussian index) keys, no duplicates — checked on the device
-    over the whole instance array at once (scratch layouts: csrc/common.h).  -> (instances, per-tile counts)"""
+    """Every per-tile list of the kept frame: ascending (depth bits, Gaussian index) keys, no duplicates, and together exactly the
+    (Gaussian, tile) pairs of the tile rectangles — checked on the device over the whole instance array at once (scratch
+    layouts: csrc/common.h).  -> (instances, per-tile counts)"""
     tiles, geom, binning, W, H, R, P = (frame[k] for k in ("tiles", "geom", "binning", "W", "H", "capacity", "P"))
     T = ((W + 15) // 16) * ((H + 15) // 16)
     al = lambda x: (x + 255) & ~255
@@ -109,6 +110,17 @@ def _all_tile_lists_sorted_on_device(frame):
     first_of_tile[start[: T + 1]] = True                                          # list boundaries: no order across them
     bad = ~ascending & ~first_of_tile[1:n]
     assert not bool(bad.any()), int(bad.sum())
+    # ... and the lists are exactly the (Gaussian, tile) pairs of the projection kernel's tile rectangles: as many instances as
+    # the rectangles have tiles, every entry's rectangle contains its tile (with the lists duplicate-free: a bijection)
+    rect = geom[al(P * 48) + al(P * 24): al(P * 48) + al(P * 24) + P * 8].view(torch.int32).view(P, 2).long()
+    x0, y0, x1, y1 = rect[:, 0] & 0xffff, (rect[:, 0] >> 16) & 0xffff, rect[:, 1] & 0xffff, (rect[:, 1] >> 16) & 0xffff
+    area = (x1 - x0).clamp(min=0) * (y1 - y0).clamp(min=0)
+    assert int(area.sum()) == n, (int(area.sum()), n)
+    gx = (W + 15) // 16
+    tile = torch.searchsorted(start[1:].contiguous(), torch.arange(n, device=key.device), right=True)
+    tx, ty = tile % gx, tile // gx
+    inside = (x0[lst] <= tx) & (tx < x1[lst]) & (y0[lst] <= ty) & (ty < y1[lst])
+    assert bool(inside.all()), int((~inside).sum())
     return n, (start[1:] - start[:-1])
 
 
