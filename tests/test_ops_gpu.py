@@ -135,3 +135,23 @@ def test_run_ahead_sticky_commit_gate(gpu):
 @pytest.mark.gpu
 def test_loss_utils_against_the_references_own(gpu):
     ops_util.check_loss_utils_against_the_references_own(gpu)
+
+
+@pytest.mark.gpu
+def test_l1_loss_at_1080p_equals_the_references_expression(gpu):
+    """l1_loss at BASELINE's largest image (3 x 1080 x 1920, C4) against the reference's expression on the same device:
+    abs(a - b).mean() (utils/loss_utils.py:39-40) — value to 1e-6 relative, gradient bit for bit, exact ties included."""
+    import torch
+    from instantsplat_amd import loss_utils
+    g = torch.Generator().manual_seed(77)
+    a = torch.rand(3, 1080, 1920, generator=g).to(gpu).requires_grad_(True)
+    b = torch.rand(3, 1080, 1920, generator=g).to(gpu)
+    b.view(-1)[::5] = a.detach().view(-1)[::5]
+    v = loss_utils.l1_loss(a, b)
+    assert "L1Loss" in v.grad_fn.name()
+    (v * 0.8).backward()
+    mine, a.grad = a.grad.clone(), None
+    r = torch.abs((a - b)).mean()
+    (r * 0.8).backward()
+    assert abs(float(v) - float(r)) <= 1e-6 * float(r), (float(v), float(r))
+    assert torch.equal(mine, a.grad)
