@@ -234,3 +234,29 @@ def test_run_ahead_sticky_commit_gate(emu):
 
 def test_loss_utils_against_the_references_own(emu):
     ops_util.check_loss_utils_against_the_references_own(emu)
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """No compute (the hipcc-built library, no GPU needed: every check comes before the first HIP call): the ABI-v8 entry points
+    return MI355GS_EINVAL for null pointers, non-positive sizes, a pose row outside its table, a null trainer handle."""
+    import __graft_entry__ as ge
+    from instantsplat_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    L = _lib._bind(_lib.LIB_PATH)
+    EINVAL = -1
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.mi355gs_l1_loss_forward(None, 0, p, p, p, p) == EINVAL
+    assert L.mi355gs_l1_loss_forward(None, 16, None, p, p, p) == EINVAL and L.mi355gs_l1_loss_forward(None, 16, p, p, None, p) == EINVAL
+    assert L.mi355gs_l1_loss_backward(None, -3, p, p, p, p) == EINVAL and L.mi355gs_l1_loss_backward(None, 16, p, p, None, p) == EINVAL
+    assert L.mi355gs_l1_scratch_bytes(0) >= 8 and L.mi355gs_l1_scratch_bytes(3 * 1080 * 1920) >= 8 * ((3 * 1080 * 1920 + 4095) // 4096)
+    assert L.mi355gs_trainer_rearm(None, None) == EINVAL
+    F7, I7 = ctypes.c_float * 7, ctypes.c_int32 * 7
+    assert L.mi355gs_trainer_optimizer_step(None, None, F7(), I7(), 0.9, 0.999, 1e-15, 1) == EINVAL
+    # mi355gs_posed_backward(..., d_pose, pose_rows, pose_row, ...): a row outside its table, a negative table
+    def posed_backward(rows, row):
+        return L.mi355gs_posed_backward(None, 0, 0, 16, 16, p, p, p, p, p, p, 1.0, p, p, p, p, p, 1.0, 1.0, p, p, p, 0, p, p, p, p, p, p, p, p, p, p,
+                                        p, p, p, rows, row, 0, 0)
+    assert posed_backward(-1, 0) == EINVAL and posed_backward(3, 3) == EINVAL and posed_backward(3, -1) == EINVAL
+    assert L.mi355gs_error_string(EINVAL)
