@@ -122,6 +122,36 @@ void wait_for_count(const int32_t* count, const DeviceScope& dev, const Tensor& 
   TORCH_CHECK(*reinterpret_cast<const volatile int32_t*>(count) >= 0, "mi355gs: the forward did not report its instance count");
 }
 
+// The same wait for a caller's own result words (instantsplat_amd/train.py: loss and instance count of an iteration, stored by
+// the kernels that produce them into pinned host memory the caller preset to `sentinel`): spin until none of them holds the
+// sentinel, GIL released; past `timeout_us` fall back to waiting for `like`'s current stream.  No event is recorded behind the
+// producing kernels for this (an event is a marker packet on the queue: ~7 us between two kernels, tools/gap_analysis.py).
+void wait_for_words(Tensor words, int64_t sentinel, Tensor like, int64_t timeout_us) {
+  TORCH_CHECK(words.scalar_type() == at::kInt && !words.is_cuda() && words.is_contiguous(), "wait_for_words: an int32 host tensor");
+  const volatile int32_t* w = words.data_ptr<int32_t>();
+  const int64_t n = words.numel();
+  auto all_there = [&]() {
+    for (int64_t i = 0; i < n; ++i)
+      if (w[i] == (int32_t)sentinel) return false;
+    return true;
+  };
+  if (all_there()) return;
+  {
+    std::optional<py::gil_scoped_release> nogil;
+    if (PyGILState_Check()) nogil.emplace();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+      if (all_there()) return;
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(timeout_us)) break;
+    }
+    if (like.is_cuda()) {
+      const DeviceScope dev(like);
+      dev.synchronize(like);
+    }
+  }
+  TORCH_CHECK(all_there(), "mi355gs: the step did not report its results");
+}
+
 Tensor f32c(const Tensor& t, const char* name, const Tensor& like) {
   TORCH_CHECK(t.is_cuda() || g_abi.allow_cpu, "instantsplat_amd operators run on the GPU only (got a CPU tensor; there is no CPU fallback)");
   TORCH_CHECK(t.scalar_type() == at::kFloat, "expected float32, got ", t.scalar_type(), " (", name, ")");
@@ -797,6 +827,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("render_posed", &render_posed);
   m.def("forward_owns_scratch", [](bool on) { const bool was = g_forward_owns_scratch; g_forward_owns_scratch = on; return was; },
         "A/B switch: true (default) = a forward that a backward will follow allocates the backward's accumulators and has the projection kernel clear them");
+  m.def("wait_for_words", &wait_for_words, "spin (GIL released) until no element of an int32 pinned host tensor holds the sentinel; stream wait after timeout_us");
   m.def("pose_row", &pose_row, "GaussianModel.get_RT: row `index` of the [views, 7] pose table as a node the render node's backward cooperates with");
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);

@@ -201,6 +201,38 @@ def release_trainer(st: TrainState):
         st._trainer = None
 
 
+WAIT_WITH_EVENT = False   # A/B switch: True = an event recorded behind every iteration's backward (the first form of the loop)
+_NOT_YET = -2   # as float32 a NaN with a payload no arithmetic produces; as a count impossible
+
+
+def _wait_for_words(words: torch.Tensor, dev):
+    """Until the kernels of an iteration have stored its loss and instance count into `words` (pinned, device-mapped host
+    memory preset to _NOT_YET).  Polled rather than waited for with an event: an event is a marker packet on the queue between
+    the iteration's last kernel and the next one (~7 us of idle device per iteration, tools/gap_analysis.py), and a stream
+    synchronize would also wait for the NEXT iteration's forward + backward, which are already enqueued."""
+    ext = _lib.compiled()
+    if ext is not None:
+        ext.wait_for_words(words, _NOT_YET, _device_token(dev), 50_000)
+        return
+    for spin in range(200_000):
+        if int(words[0]) != _NOT_YET and int(words[1]) != _NOT_YET:
+            return
+    torch.cuda.current_stream(dev).synchronize()
+    if int(words[0]) == _NOT_YET or int(words[1]) == _NOT_YET:
+        raise RuntimeError("mi355gs: the step did not report its results")
+
+
+_DEVICE_TOKEN = {}
+
+
+def _device_token(dev):
+    """a tensor that names the device (and through it the current stream) for the binding"""
+    t = _DEVICE_TOKEN.get(dev)
+    if t is None:
+        t = _DEVICE_TOKEN[dev] = torch.empty(1, device=dev)
+    return t
+
+
 def _fused_synced_iteration(st: TrainState):
     """The reference's loop shape — loss read back on the host every iteration — on the one-call fused step, with the device
     never waiting for the host.  An iteration is enqueued in two parts: forward + backward (mi355gs_trainer_step with the
@@ -210,7 +242,8 @@ def _fused_synced_iteration(st: TrainState):
       1. enqueues iteration t's optimizer launch (its forward + backward were enqueued by the previous call — or are now),
       2. runs the host half of iteration t + 1 (LR schedule, view sampling, step counts: FusedTrainer.prepare) and enqueues its
          forward + backward — they read the parameters iteration t's update leaves, in stream order, and write only scratch,
-      3. waits for the event recorded behind iteration t's backward and reads its loss and count from pinned host memory.
+      3. waits until iteration t's kernels have stored its loss and count into pinned host memory (polling: no event, no
+         stream synchronize) and reads them.
     When the call returns, the state is iteration t's (parameters and moments after its update, in stream order); what is in
     flight for t + 1 has changed nothing but the handle's scratch, and `cancel_prepared` takes its host half back when the loop
     is left.  An iteration that overflowed is redone on the exact-sizing autograd path: the device discarded its update."""
@@ -225,7 +258,7 @@ def _fused_synced_iteration(st: TrainState):
         tr = st._trainer = FusedTrainer(st, int(BinningPolicy.slack * need) + BinningPolicy.pad)
         # loss and instance count are stored by the kernels that produce them straight into words of pinned, device-mapped
         # host memory (count as int32: a float32 detour would round counts above 2^24, reachable at 1 M Gaussians / 1080p, and
-        # could hide an overflow of a few instances): the iteration's read-back is a wait for an event, not a copy.  Two pairs:
+        # could hide an overflow of a few instances): the iteration's read-back is a poll of these words, not a copy.  Two pairs:
         # iteration t + 1 writes its own while iteration t's are still to be read.
         st._host_words = torch.zeros(4, dtype=torch.int32, pin_memory=(tr.dev.type == "cuda"))
         st._loss_slots = [st._host_words[0:1].view(torch.float32), st._host_words[2:3].view(torch.float32)]
@@ -235,9 +268,10 @@ def _fused_synced_iteration(st: TrainState):
     def enqueue_forward_backward(slot):
         saved = _host_state(st, tr)
         args = tr.prepare()
+        st._host_words[2 * slot: 2 * slot + 2] = _NOT_YET      # the two kernels overwrite these; the wait below polls them
         cam = tr.launch(args, st._loss_slots[slot], st._count_slots[slot], defer_optimizer=True)
         ev = None
-        if cuda:
+        if cuda and WAIT_WITH_EVENT:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(tr.dev))
         return saved, args, slot, ev, cam
@@ -251,6 +285,8 @@ def _fused_synced_iteration(st: TrainState):
         nxt = enqueue_forward_backward(slot ^ 1)
     if ev is not None:
         ev.synchronize()
+    elif cuda:
+        _wait_for_words(st._host_words[2 * slot: 2 * slot + 2], tr.dev)
     loss, r = float(st._loss_slots[slot][0]), int(st._count_slots[slot][0])
     BinningPolicy.known[hint_key(st, cam)] = int(r)
     if r > tr.capacity:   # dropped instances (the device left the update out): redo exactly, and grow the buffers for the next iterations
