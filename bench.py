@@ -14,7 +14,8 @@ iteration t's loss, its optimizer launch, gated on the device, after: the device
 read-back (`one_call_run_ahead`: identical results, the loss EMA is evaluated every 10, the queue drains at every window).
 
 Timed region: each loop runs on a fresh state fast-forwarded (untimed) to iteration 200 of training, W warm-up iterations, then
-blocks of exactly --steps iterations, each bracketed by barrier + device synchronize, MAX over ranks; the blocks cover iterations
+blocks of exactly --steps iterations, each bracketed by barrier + device synchronize on both sides, MAX over ranks of each rank's
+own interval (barrier released -> its K iterations complete on its device); the blocks cover iterations
 200 .. 1000 whatever --steps is (40 blocks at the driver's --steps 20), `value` / `ms_per_step` are the MEDIAN block.  Nothing is
 instrumented inside it: kernel durations for `roofline` come from HIP events in a separate, untimed pass over the same stretch.
 
@@ -187,9 +188,11 @@ def main():
             step()
         finish()
         dev_sync()
-        own = time.perf_counter() - t0   # this rank's own clock, before it waits for the others
+        own = time.perf_counter() - t0   # this rank's K iterations, device-synchronized, before it waits for the others
         sync()
-        return reduce_max(time.perf_counter() - t0), own
+        # MAX over ranks of each rank's own interval: the closing barrier brackets the block, it is not part of the K iterations
+        # (an RCCL barrier is a collective launch + a device synchronize: tens of microseconds on a 6 ms block at N = 8)
+        return reduce_max(own), own
 
     # the contract's K steps are one block; the blocks cover iterations PIN_ITER + W .. ~1000 whatever K is (the driver's
     # --steps 20 gives 40 blocks of 6 ms), and the MEDIAN block is reported.  The count is a function of K alone.

@@ -20,6 +20,39 @@ import torch
 import torch.distributed as dist
 
 
+def _physical_core_of(cpu: int):
+    """(package, core) of a logical CPU from sysfs, or None where the kernel does not say."""
+    base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+    try:
+        with open(base + "physical_package_id") as f:
+            pkg = int(f.read())
+        with open(base + "core_id") as f:
+            return pkg, int(f.read())
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_slices(cpus: list, n: int, core_of=_physical_core_of) -> list:
+    """`cpus` cut into n disjoint slices of whole PHYSICAL cores, neighbours in (package, core) order.  Linux numbers the
+    second hardware thread of every core after all the first ones (0..C-1, then C..2C-1), so equal runs of the sorted ids
+    would hand rank r and rank r + n/2 the two threads of the SAME cores — two spinning launch loops sharing an execution
+    unit.  Falls back to equal runs of ids when the topology is not readable or has fewer cores than slices."""
+    cpus = sorted(cpus)
+    cores = {}
+    for c in cpus:
+        key = core_of(c)
+        if key is None:
+            cores = None
+            break
+        cores.setdefault(key, []).append(c)
+    if cores is None or len(cores) < n:
+        per = len(cpus) // n
+        return [cpus[r * per:(r + 1) * per] for r in range(n)]
+    order = sorted(cores)
+    per = len(order) // n
+    return [sorted(c for key in order[r * per:(r + 1) * per] for c in cores[key]) for r in range(n)]
+
+
 def pin_rank_to_cpu_slice(local_rank: int, local_world: int) -> list:
     """One process per GPU means N Python hosts on one socket: give each rank its own slice of the CPUs this job may use
     (sched_setaffinity) and cap its thread pools to it, so that eight eager launch loops do not migrate over and preempt
@@ -30,9 +63,9 @@ def pin_rank_to_cpu_slice(local_rank: int, local_world: int) -> list:
         return []
     if local_world <= 1 or len(cpus) < local_world:   # (0: a multi-node job without LOCAL_WORLD_SIZE — not sliced)
         return cpus
-    per = len(cpus) // local_world
-    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    mine = cpu_slices(cpus, local_world)[local_rank]
     os.sched_setaffinity(0, mine)
+    per = len(mine)
     n_threads = max(1, min(per, 8))
     os.environ["OMP_NUM_THREADS"] = str(n_threads)
     torch.set_num_threads(n_threads)

@@ -131,3 +131,21 @@ def test_launch_report_carries_the_host_and_multi_node_is_not_sliced(monkeypatch
     assert launch.local_world_size(8) == 0 and launch.pin_rank_to_cpu_slice(0, 0) == sorted(os.sched_getaffinity(0))
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
     assert launch.local_world_size(8) == 4
+
+
+def test_cpu_slices_are_whole_physical_cores():
+    """Two sockets x 4 cores x 2 hardware threads in Linux's numbering (cpu c and c + 8 share a core): no two ranks may get
+    threads of one core, every CPU is handed out once, and an unreadable topology degrades to equal runs of ids."""
+    from instantsplat_amd.launch import cpu_slices
+    core_of = lambda c: ((c % 8) // 4, c % 4)
+    for n in (2, 4, 8):
+        sl = cpu_slices(list(range(16)), n, core_of=core_of)
+        assert sorted(c for s in sl for c in s) == list(range(16)) and len({len(s) for s in sl}) == 1
+        owners = {}
+        for r, s in enumerate(sl):
+            for c in s:
+                assert owners.setdefault(core_of(c), r) == r, (n, sl)
+    assert cpu_slices(list(range(16)), 8, core_of=core_of)[0] == [0, 8]
+    assert cpu_slices(list(range(16)), 4, core_of=lambda c: None) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    assert cpu_slices(list(range(4)), 4, core_of=lambda c: (0, c // 2)) == [[0], [1], [2], [3]]   # fewer cores than slices
+    assert [len(s) for s in cpu_slices(sorted(os.sched_getaffinity(0)), 1)] == [len(os.sched_getaffinity(0))]
