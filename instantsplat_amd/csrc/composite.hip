@@ -746,8 +746,13 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
     cus_of[dev] = cus = n;
   }
   const int per_wg = GS_FWD_TILES ? GS_FWD_TILES : (T <= 4 * cus ? 4 : (T <= 4 * cus * 2 ? 2 : 1));
+  // GS_FWD_LDS_PAD (A/B builds): unused dynamic LDS per workgroup, which bounds how many workgroups a CU holds at once — fewer
+  // resident waves than work items, so that the dispatcher hands the lightest tiles to whichever CU frees a slot first
+#ifndef GS_FWD_LDS_PAD
+#define GS_FWD_LDS_PAD 0
+#endif
 #define GS_FWD(N, CNT)                                                                                                              \
-  hipLaunchKernelGGL((k_composite_fwd<N, CNT>), dim3((T + N - 1) / N), dim3(256 * N), 0, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, \
+  hipLaunchKernelGGL((k_composite_fwd<N, CNT>), dim3((T + N - 1) / N), dim3(256 * N), GS_FWD_LDS_PAD, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, \
                      out_color, final_T, n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax, counters)
   if (counters) { if (per_wg == 4) GS_FWD(4, true); else if (per_wg == 2) GS_FWD(2, true); else GS_FWD(1, true); }
   else { if (per_wg == 4) GS_FWD(4, false); else if (per_wg == 2) GS_FWD(2, false); else GS_FWD(1, false); }
