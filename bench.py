@@ -314,6 +314,24 @@ def main():
     keep_last_frame(False)
     R_eff = sum(Reffs) / len(Reffs)
 
+    # ---- what kind of box this is: the pool has boxes on which the same build runs every kernel 25-70 % longer;
+    # a plain device-to-device copy of 256 MiB says which kind the line comes from (fast boxes: 4.8-5.5 TB/s read + write)
+    box = None
+    if not emulated:
+        src_ = torch.empty(1 << 26, dtype=torch.float32, device=dev)
+        dst_ = torch.empty_like(src_)
+        for _ in range(3):
+            dst_.copy_(src_)
+        dev_sync()
+        tb = time.perf_counter()
+        for _ in range(20):
+            dst_.copy_(src_)
+        dev_sync()
+        box = {"device_copy_TB_per_s": 2 * src_.numel() * 4 * 20 / (time.perf_counter() - tb) / 1e12,
+               "what": "256 MiB torch copy_ on the device, read + write bytes / time, after the timed loops",
+               "cpus_visible": os.cpu_count()}
+        del src_, dst_
+
     # ---- final metric reduction: the only collective on the path
     red = torch.tensor([psnr_after, 1.0, float(args.steps), elapsed], dtype=torch.float64, device=red_dev)
     if collectives:
@@ -526,7 +544,7 @@ def main():
                                    f"{' as in the reference first 1000 iterations' if args.sh_degree == 0 else ' (exploratory)'}"
                                    f"), one scene per GPU", "views": V, "gaussians": P, "width": res, "height": res,
                        "parallelism": f"scene-per-gpu x{world}"},
-            "rasterize_ms_per_frame": raster_ms,
+            "rasterize_ms_per_frame": raster_ms, "box": box,
             "value_path": "drop-in reference loop",
             "loop": "the reference's train.py loop shape on the drop-in operators (render() / GaussianRasterizer / fused_ssim / PerPointAdam "
                     "through the compiled binding): autograd, the operator's blocking instance-count read-back and the blocking "
