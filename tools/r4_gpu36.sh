@@ -1,7 +1,7 @@
 #!/bin/bash
 # final-tree records of round 4 (second session): GPU tier, smoke, bench lines (driver args, default), the N > 1 timing path
 # with real process groups (RCCL at world size 1, two ranks sharing the one GPU over gloo)
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r4g
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r4g; python tools/box_probe.py 2>&1 | grep -E "device copy|v_fma_f32 +waves/SIMD 4" | tee gpurun_out/r4g/box.txt
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/r4g/gpu_tier.log; cat gpurun_out/r4g/gpu_tier.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4g/bench_driver_args.json 2> gpurun_out/r4g/bench_driver_args.err; echo "bench1 rc $?"
