@@ -41,6 +41,8 @@ with torch.no_grad():
     torch.cuda.synchronize()
     raw.mi355gs_probe_set(ctypes.c_void_p(0), 0)
 b = buf.cpu().numpy().astype(np.float64)
+if os.environ.get("GS_PROBE_DUMP"):   # raw rows (t0, t1, hits, wait, groups, instances, physical CU, walk ticks) per (tile, quadrant) for offline what-ifs
+    np.save(os.environ["GS_PROBE_DUMP"], buf.cpu().numpy())
 t0, t1, hits, wait, groups, inst, cu, walk = [b[:, i] for i in range(8)]
 ok = t1 > 0
 tick = 0.01  # wall_clock64: 100 MHz -> us
