@@ -103,7 +103,9 @@ def main():
                                          init_collectives, local_world_size, pin_rank_to_cpu_slice)
     # N Python hosts on one socket: each rank keeps to its own slice of the CPUs (the scaling risk is host
     # contention, not the fabric)
-    cpus = pin_rank_to_cpu_slice(local_rank, local_world_size(world)) if world > 1 else sorted(os.sched_getaffinity(0))
+    # ... and every rank, a single one included, stays on the NUMA node of its GPU (launch.gpu_local_cpus)
+    n_dev_ = 1 if emulated else torch.cuda.device_count()
+    cpus = pin_rank_to_cpu_slice(local_rank, local_world_size(world), device_of_rank=None if emulated else (lambda r: r % n_dev_))
     collectives = world > 1 or args.force_collectives   # a process group exists: every barrier / reduction below goes through it
     selftest = None
     if collectives:

@@ -53,22 +53,72 @@ def cpu_slices(cpus: list, n: int, core_of=_physical_core_of) -> list:
     return [sorted(c for key in order[r * per:(r + 1) * per] for c in cores[key]) for r in range(n)]
 
 
-def pin_rank_to_cpu_slice(local_rank: int, local_world: int) -> list:
-    """One process per GPU means N Python hosts on one socket: give each rank its own slice of the CPUs this job may use
-    (sched_setaffinity) and cap its thread pools to it, so that eight eager launch loops do not migrate over and preempt
-    each other — the scaling risk SURVEY.md 8e names is host contention, not the fabric.  Returns the CPUs kept."""
+def parse_cpulist(text: str) -> list:
+    """'0-63,128-191' -> [0, .., 63, 128, .., 191] (the kernel's cpulist format)"""
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(out))
+
+
+def gpu_local_cpus(device_index: int):
+    """The CPUs of the NUMA node GPU `device_index` hangs off (sysfs `local_cpulist` of its PCI function), or None where
+    that cannot be read.  Measured on an MI355X box (2 sockets, the GPU on node 1; tools/ab_numa.sh,
+    profiles/r04_ab_numa_affinity.txt): the host-bound loops — train.py's loss spelled out in eager PyTorch around the
+    drop-in operators — run 12-14 % faster with the process kept on the GPU's node than left to the scheduler."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        addr = "%04x:%02x:%02x.0" % (int(p.pci_domain_id), int(p.pci_bus_id), int(p.pci_device_id))
+        with open(f"/sys/bus/pci/devices/{addr}/local_cpulist") as f:
+            cpus = parse_cpulist(f.read())
+        return cpus or None
+    except Exception:   # no such attribute / file / a CPU device: the caller falls back to topology-blind slices
+        return None
+
+
+def rank_cpu_plan(local_rank: int, local_world: int, allowed: list, local_cpus_of_rank=None, core_of=_physical_core_of) -> list:
+    """The CPUs rank `local_rank` of `local_world` ranks on this node keeps.  local_cpus_of_rank(r) -> the CPUs next to rank r's
+    GPU (or None): ranks whose GPUs share a NUMA node split THAT node's physical cores among themselves, in rank order; without
+    the information (or when a node's CPUs are not in `allowed`) all ranks split `allowed` into equal runs of physical cores."""
+    allowed = sorted(allowed)
+    if local_world <= 0 or len(allowed) < max(local_world, 1):
+        return allowed
+    if local_cpus_of_rank is not None:
+        near = [local_cpus_of_rank(r) for r in range(local_world)]
+        if all(n is not None for n in near):
+            keep = set(allowed)
+            near = [tuple(c for c in n if c in keep) for n in near]
+            mates = [r for r in range(local_world) if near[r] == near[local_rank]]
+            if all(len(n) >= local_world for n in near):   # every rank decides from the same table, so the slices are disjoint
+                return cpu_slices(list(near[local_rank]), len(mates), core_of=core_of)[mates.index(local_rank)]
+    if local_world == 1:
+        return allowed
+    return cpu_slices(allowed, local_world, core_of=core_of)[local_rank]
+
+
+def pin_rank_to_cpu_slice(local_rank: int, local_world: int, device_of_rank=None) -> list:
+    """One process per GPU means N Python hosts on one box: give each rank its own slice of the CPUs this job may use
+    (sched_setaffinity) — whole physical cores, on the NUMA node of its GPU when `device_of_rank(r)` (rank -> device index)
+    is given and sysfs knows the node — and cap its thread pools to it, so that eight eager launch loops do not migrate over
+    and preempt each other: the scaling risk SURVEY.md 8e names is host contention, not the fabric.  A single rank with a
+    device is kept on its GPU's node.  Returns the CPUs kept."""
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:   # not Linux
         return []
-    if local_world <= 1 or len(cpus) < local_world:   # (0: a multi-node job without LOCAL_WORLD_SIZE — not sliced)
+    near = (lambda r: gpu_local_cpus(device_of_rank(r))) if device_of_rank is not None else None
+    if local_world <= 0 or len(cpus) < local_world or (local_world == 1 and near is None):
+        return cpus            # (0: a multi-node job without LOCAL_WORLD_SIZE — not sliced)
+    mine = rank_cpu_plan(local_rank, local_world, cpus, near)
+    if not mine or mine == cpus:
         return cpus
-    mine = cpu_slices(cpus, local_world)[local_rank]
     os.sched_setaffinity(0, mine)
-    per = len(mine)
-    n_threads = max(1, min(per, 8))
-    os.environ["OMP_NUM_THREADS"] = str(n_threads)
-    torch.set_num_threads(n_threads)
+    if local_world > 1:   # (a single rank keeps its thread pools: it has a whole NUMA node to itself)
+        n_threads = max(1, min(len(mine), 8))
+        os.environ["OMP_NUM_THREADS"] = str(n_threads)
+        torch.set_num_threads(n_threads)
     return mine
 
 
@@ -181,7 +231,8 @@ def main():
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cpus = pin_rank_to_cpu_slice(local, local_world_size(world))
+    n_dev = max(torch.cuda.device_count(), 1)
+    cpus = pin_rank_to_cpu_slice(local, local_world_size(world), device_of_rank=lambda r: r % n_dev)
     selftest = None
     if world > 1 or args.force_collectives:
         init_collectives("nccl", rank, world, dev)

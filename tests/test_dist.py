@@ -149,3 +149,24 @@ def test_cpu_slices_are_whole_physical_cores():
     assert cpu_slices(list(range(16)), 4, core_of=lambda c: None) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
     assert cpu_slices(list(range(4)), 4, core_of=lambda c: (0, c // 2)) == [[0], [1], [2], [3]]   # fewer cores than slices
     assert [len(s) for s in cpu_slices(sorted(os.sched_getaffinity(0)), 1)] == [len(os.sched_getaffinity(0))]
+
+
+def test_rank_cpu_plan_keeps_a_rank_on_its_gpus_numa_node():
+    """Two NUMA nodes x 4 cores x 2 hardware threads (cpu c and c + 8 share a core; node = core // 4).  GPUs enumerated against
+    the node order (ranks 0, 1 next to node 1; ranks 2, 3 next to node 0): every rank gets whole cores of ITS GPU's node, the
+    slices are disjoint, a single rank keeps the whole node of its GPU, and missing information degrades to topology-blind slices."""
+    from instantsplat_amd.launch import parse_cpulist, rank_cpu_plan
+    assert parse_cpulist("0-3,8-11\n") == [0, 1, 2, 3, 8, 9, 10, 11] and parse_cpulist("5") == [5] and parse_cpulist("") == []
+    core_of = lambda c: ((c % 8) // 4, c % 8)
+    node_cpus = {0: parse_cpulist("0-3,8-11"), 1: parse_cpulist("4-7,12-15")}
+    near = lambda r: node_cpus[1 if r < 2 else 0]
+    plans = [rank_cpu_plan(r, 4, list(range(16)), near, core_of=core_of) for r in range(4)]
+    assert plans == [[4, 5, 12, 13], [6, 7, 14, 15], [0, 1, 8, 9], [2, 3, 10, 11]]
+    assert rank_cpu_plan(0, 1, list(range(16)), near, core_of=core_of) == node_cpus[1]          # N = 1: the GPU's node
+    assert rank_cpu_plan(0, 2, list(range(16)), lambda r: node_cpus[1], core_of=core_of) == [4, 5, 12, 13]   # two ranks sharing one GPU
+    assert rank_cpu_plan(1, 2, list(range(16)), lambda r: node_cpus[1], core_of=core_of) == [6, 7, 14, 15]
+    blind = [rank_cpu_plan(r, 4, list(range(16)), lambda r: None, core_of=core_of) for r in range(4)]
+    assert blind == [[0, 1, 8, 9], [2, 3, 10, 11], [4, 5, 12, 13], [6, 7, 14, 15]]
+    assert rank_cpu_plan(0, 1, list(range(16)), None, core_of=core_of) == list(range(16))
+    # the job may only use node 0's CPUs (a cgroup): a GPU on node 1 has nothing local to offer -> topology-blind slices of what is allowed
+    assert rank_cpu_plan(0, 2, node_cpus[0], near, core_of=core_of) == [0, 1, 8, 9]
