@@ -104,8 +104,11 @@ def main():
     # N Python hosts on one socket: each rank keeps to its own slice of the CPUs (the scaling risk is host
     # contention, not the fabric)
     # ... and every rank, a single one included, stays on the NUMA node of its GPU (launch.gpu_local_cpus)
+    # ... on ONE last-level-cache domain of it, a core per thread (launch.compact_cpus).  The CPU baseline leg gets every CPU back.
     n_dev_ = 1 if emulated else torch.cuda.device_count()
-    cpus = pin_rank_to_cpu_slice(local_rank, local_world_size(world), device_of_rank=None if emulated else (lambda r: r % n_dev_))
+    all_cpus = sorted(os.sched_getaffinity(0))
+    cpus = pin_rank_to_cpu_slice(local_rank, local_world_size(world), device_of_rank=None if emulated else (lambda r: r % n_dev_),
+                                 compact=not emulated)
     collectives = world > 1 or args.force_collectives   # a process group exists: every barrier / reduction below goes through it
     selftest = None
     if collectives:
@@ -498,7 +501,14 @@ def main():
     cpu_baseline = None
     if cpu_trainer is not None:
         from oracle import gs_ref
-        threads = min(os.cpu_count() or 1, 32)  # beyond ~32 threads the tile-parallel C port stops scaling
+        # the GPU loops ran on a few cores next to the GPU; the CPU path gets the whole box back — every thread of the process
+        # (an affinity mask is per thread, and pools created meanwhile inherited the narrow one)
+        for tid_ in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid_), all_cpus)
+            except OSError:
+                pass
+        threads = min(len(all_cpus) or 1, 32)   # beyond ~32 threads the tile-parallel C port stops scaling
         threads = int(gs_ref.lib().gsref_set_threads(threads))
         torch.set_num_threads(threads)
         cpu_trainer.iteration()  # warm-up (page-in, OpenMP pool)

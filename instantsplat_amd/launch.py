@@ -98,12 +98,40 @@ def rank_cpu_plan(local_rank: int, local_world: int, allowed: list, local_cpus_o
     return cpu_slices(allowed, local_world, core_of=core_of)[local_rank]
 
 
-def pin_rank_to_cpu_slice(local_rank: int, local_world: int, device_of_rank=None) -> list:
+def _l3_domain_of(cpu: int):
+    """The CPUs that share cpu's last-level cache (sysfs index3/shared_cpu_list: a CCD on an EPYC), as a tuple, or None."""
+    try:
+        with open(f"/sys/devices/system/cpu/cpu{cpu}/cache/index3/shared_cpu_list") as f:
+            return tuple(parse_cpulist(f.read()))
+    except (OSError, ValueError):
+        return None
+
+
+def compact_cpus(cpus: list, core_of=_physical_core_of, l3_of=_l3_domain_of, min_cores: int = 4) -> list:
+    """One hardware thread per physical core of ONE last-level-cache domain of `cpus` (the first with at least `min_cores`
+    cores).  The threads that matter to a launch loop — the Python thread, the autograd engine's device thread, the HIP
+    runtime's helpers — hand work to each other every few microseconds; on one CCD they meet in a shared L3, and each has a
+    core to itself.  Measured (tools/ab_numa2.sh, profiles/r04_ab_numa_affinity.txt): the drop-in loop + 5 %, train.py's loss in
+    eager PyTorch + 10 % over the whole NUMA node.  Returns `cpus` unchanged where the cache topology is not readable."""
+    domains = {}
+    for c in sorted(cpus):
+        dom, core = l3_of(c), core_of(c)
+        if dom is None or core is None:
+            return sorted(cpus)
+        domains.setdefault(dom, {}).setdefault(core, c)   # first (lowest) hardware thread of each core
+    for dom in sorted(domains):
+        if len(domains[dom]) >= min_cores:
+            return sorted(domains[dom].values())
+    return sorted(cpus)
+
+
+def pin_rank_to_cpu_slice(local_rank: int, local_world: int, device_of_rank=None, compact: bool = False) -> list:
     """One process per GPU means N Python hosts on one box: give each rank its own slice of the CPUs this job may use
     (sched_setaffinity) — whole physical cores, on the NUMA node of its GPU when `device_of_rank(r)` (rank -> device index)
     is given and sysfs knows the node — and cap its thread pools to it, so that eight eager launch loops do not migrate over
     and preempt each other: the scaling risk SURVEY.md 8e names is host contention, not the fabric.  A single rank with a
-    device is kept on its GPU's node.  Returns the CPUs kept."""
+    device is kept on its GPU's node.  compact: narrow the slice further to one last-level-cache domain, one hardware thread
+    per core (`compact_cpus`).  Returns the CPUs kept."""
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:   # not Linux
@@ -112,6 +140,8 @@ def pin_rank_to_cpu_slice(local_rank: int, local_world: int, device_of_rank=None
     if local_world <= 0 or len(cpus) < local_world or (local_world == 1 and near is None):
         return cpus            # (0: a multi-node job without LOCAL_WORLD_SIZE — not sliced)
     mine = rank_cpu_plan(local_rank, local_world, cpus, near)
+    if compact and mine:
+        mine = compact_cpus(mine)
     if not mine or mine == cpus:
         return cpus
     os.sched_setaffinity(0, mine)
@@ -232,7 +262,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     n_dev = max(torch.cuda.device_count(), 1)
-    cpus = pin_rank_to_cpu_slice(local, local_world_size(world), device_of_rank=lambda r: r % n_dev)
+    cpus = pin_rank_to_cpu_slice(local, local_world_size(world), device_of_rank=lambda r: r % n_dev, compact=True)
     selftest = None
     if world > 1 or args.force_collectives:
         init_collectives("nccl", rank, world, dev)

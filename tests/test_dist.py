@@ -170,3 +170,17 @@ def test_rank_cpu_plan_keeps_a_rank_on_its_gpus_numa_node():
     assert rank_cpu_plan(0, 1, list(range(16)), None, core_of=core_of) == list(range(16))
     # the job may only use node 0's CPUs (a cgroup): a GPU on node 1 has nothing local to offer -> topology-blind slices of what is allowed
     assert rank_cpu_plan(0, 2, node_cpus[0], near, core_of=core_of) == [0, 1, 8, 9]
+
+
+def test_compact_cpus_is_one_cache_domain_one_thread_per_core():
+    """16 logical CPUs: 8 cores x 2 threads (c and c + 8), two L3 domains of 4 cores.  A slice of whole cores shrinks to the first
+    domain's cores, first hardware thread of each; a domain with too few cores is passed over; unreadable topology changes nothing."""
+    from instantsplat_amd.launch import compact_cpus
+    core_of = lambda c: (0, c % 8)
+    l3_of = lambda c: tuple(sorted([x for x in range(16) if (x % 8) // 4 == (c % 8) // 4]))
+    assert compact_cpus(list(range(16)), core_of, l3_of) == [0, 1, 2, 3]
+    assert compact_cpus([4, 5, 6, 7, 12, 13, 14, 15], core_of, l3_of) == [4, 5, 6, 7]
+    assert compact_cpus([3, 11, 4, 5, 6, 7, 12, 13, 14, 15], core_of, l3_of) == [4, 5, 6, 7]     # one core of domain 0: too few
+    assert compact_cpus([2, 3, 10, 11], core_of, l3_of, min_cores=2) == [2, 3]
+    assert compact_cpus([0, 1, 2], core_of, lambda c: None) == [0, 1, 2]
+    assert compact_cpus([0, 8], core_of, l3_of) == [0, 8]                                            # nothing qualifies: unchanged
