@@ -125,6 +125,18 @@ def compact_cpus(cpus: list, core_of=_physical_core_of, l3_of=_l3_domain_of, min
     return sorted(cpus)
 
 
+def pin_mode() -> str:
+    """MI355GS_PIN = "node" (default) | "compact" | "off": how far the launcher / bench narrow a rank's CPUs.
+    node: whole physical cores of the NUMA node of the rank's GPU (the ranks of that node split its cores).
+    compact: on top of that ONE last-level-cache domain, a core per thread — the fastest host loop on a quiet box (the drop-in
+        loop + 5 % over "node"), but a hard pin to eight particular CPUs cannot dodge another tenant's load on them the way the
+        scheduler does for a wider mask: on a shared box a run pinned like this once took more than ten times its usual time.
+        For a node that is the job's own.
+    off: leave the affinity alone."""
+    m = os.environ.get("MI355GS_PIN", "node").strip().lower()
+    return m if m in ("node", "compact", "off") else "node"
+
+
 def pin_rank_to_cpu_slice(local_rank: int, local_world: int, device_of_rank=None, compact: bool = False) -> list:
     """One process per GPU means N Python hosts on one box: give each rank its own slice of the CPUs this job may use
     (sched_setaffinity) — whole physical cores, on the NUMA node of its GPU when `device_of_rank(r)` (rank -> device index)
@@ -262,7 +274,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     n_dev = max(torch.cuda.device_count(), 1)
-    cpus = pin_rank_to_cpu_slice(local, local_world_size(world), device_of_rank=lambda r: r % n_dev, compact=True)
+    cpus = (pin_rank_to_cpu_slice(local, local_world_size(world), device_of_rank=lambda r: r % n_dev, compact=pin_mode() == "compact")
+            if pin_mode() != "off" else sorted(os.sched_getaffinity(0)))
     selftest = None
     if world > 1 or args.force_collectives:
         init_collectives("nccl", rank, world, dev)

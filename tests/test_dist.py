@@ -118,6 +118,19 @@ def test_bench_force_collectives_at_world_size_one(emu_lib_path):
     m = out["multi_gpu"]
     assert m["ranks_seen"] == m["world_size"] == 1 and m["per_rank"][0]["host"]
     assert m["collective_selftest"]["checked"] == ["barrier", "all_reduce SUM", "all_reduce MAX", "all_gather_object"]
+    assert out["attempts"] == 1 and out["attempt_seconds"] > 0   # a single-process run goes through the supervising parent
+
+
+def test_bench_kills_a_stalled_attempt_and_tries_once_more(emu_lib_path):
+    """A run that produces no line within --attempt-seconds is killed and repeated once (unpinned); when
+    that stalls too the command fails instead of hanging — and leaves no process behind."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MI355GS_BENCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--pointmap", "6", "--res", "32",
+                        "--cpu-iters", "0", "--emulated-kernels", emu_lib_path, "--attempt-seconds", "0.5"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and r.stdout.strip() == ""
+    assert r.stderr.count("was killed") == 2 and "attempt 2" in r.stderr
 
 
 def test_launch_report_carries_the_host_and_multi_node_is_not_sliced(monkeypatch):

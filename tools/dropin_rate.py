@@ -9,6 +9,14 @@ from instantsplat_amd.arguments import OptimizationParams
 from instantsplat_amd.synthetic import syn_pointmap
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 dev = torch.device("cuda:0")
+if os.environ.get("GS_PIN", "1") == "1":   # what bench.py and the launcher do: one cache domain of the GPU's NUMA node
+    from instantsplat_amd.launch import pin_rank_to_cpu_slice
+    pin_rank_to_cpu_slice(0, 1, device_of_rank=lambda r: 0, compact=True)
+import gc
+if os.environ.get("GS_GC") == "off":
+    gc.disable()
+elif os.environ.get("GS_GC") == "freeze":
+    gc.collect(); gc.freeze()
 out = []
 for name, kw in (("drop-in", {}), ("drop-in train.py loss", {"fused_loss": False}), ("one-call synced", {"fused_step": True})):
     st = train.setup_training(syn_pointmap(3, 256, 256, 512, 512, seed=0), dev, opt=OptimizationParams(iterations=10 ** 9, pp_optimizer=True, optim_pose=True))

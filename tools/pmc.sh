@@ -2,6 +2,7 @@
 # usage: tools_pmc.sh <name> <counter> <cmd...>  -> gpurun_out/<name>_<counter>.csv (per-kernel mean of the counter)
 name=$1; ctr=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
+export MI355GS_BENCH_CHILD=1   # bench.py measures in this process (no supervising parent): rocprofv3 sees the process that launches the kernels
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_${name}_${ctr//,/_}
 mkdir -p $out

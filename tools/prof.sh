@@ -2,6 +2,7 @@
 # usage: tools_prof.sh <name> <cmd...>   -> gpurun_out/<name>_kernel_stats.csv (+ trace)
 name=$1; shift
 cd /tmp && export TMPDIR=/tmp
+export MI355GS_BENCH_CHILD=1   # bench.py measures in this process (no supervising parent): rocprofv3 sees the process that launches the kernels
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$name
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$name -o $name -- "$@" > gpurun_out/$name.log 2>&1 < /dev/null
