@@ -25,6 +25,9 @@ Synthetic, seeded (no MASt3R / datasets offline).  N > 1: one independent scene 
 collective in the data path; RCCL is used only for the barrier, the max-over-ranks time and the final
 metric reduction ("weak" scaling).
 
+A single-process run (no launcher) measures in a child process under --attempt-seconds and is repeated once, unpinned, if it
+stalls (`supervise`); every rank keeps to the NUMA node of its GPU (MI355GS_PIN = node | compact | off, instantsplat_amd/launch.py).
+
 python bench.py [--gpus N] [--steps K] [--warmup W]
 """
 import argparse
