@@ -674,9 +674,13 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
         scene = load_init_scene(os.fspath(scene), n_views, resolution=resolution, device=device, model_path=model_path)
     if model_path:   # reference train.py:233-246 (prepare_output_and_logger): the run's arguments next to its outputs
         os.makedirs(model_path, exist_ok=True)
-        with open(os.path.join(model_path, "cfg_args"), "w") as f:
-            f.write(repr(dict(dataclasses.asdict(opt), model_path=model_path, source_path=getattr(scene, "source_path", None),
-                              n_views=getattr(scene, "n_views", n_views), sh_degree=(model or ModelParams()).sh_degree)))
+        from .arguments import cfg_args_text
+        mp = dataclasses.replace(model or ModelParams(), model_path=os.fspath(model_path), source_path=getattr(scene, "source_path", None) or "",
+                                 n_views=int(getattr(scene, "n_views", n_views) or 0), resolution=resolution)
+        saves = sorted(set(int(i) for i in saving_iterations) | {int(iterations)})
+        with open(os.path.join(model_path, "cfg_args"), "w") as f:   # a Namespace(...) text: what the reference's render.py evaluates
+            f.write(cfg_args_text(mp, opt, PipelineParams(), save_iterations=saves, checkpoint_iterations=sorted(int(i) for i in checkpoint_iterations),
+                                  start_checkpoint=start_checkpoint))
     st = setup_training(scene, device, opt=opt, model=model)
     if after_setup is not None:
         after_setup(st)

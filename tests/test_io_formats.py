@@ -76,3 +76,20 @@ def test_save_pose_matches_reference_function(tmp_path):
     ours = np.load(tmp_path / "pose_optimized.npy")
     assert ours.shape == G["save_pose_out"].shape and ours.dtype == G["save_pose_out"].dtype
     assert np.allclose(ours, G["save_pose_out"], rtol=0, atol=1e-7)
+
+
+def test_cfg_args_is_the_text_the_references_own_parser_writes():
+    """<model_path>/cfg_args (reference train.py:245-246): character for character what the reference's argument classes and
+    train.py's parser produce for its scripts' command line (tests/golden/make_golden_cfg_args.py), so that the reference's
+    get_combined_args — render.py, metrics.py — finds source_path / n_views / resolution / sh_degree of a model trained here."""
+    import json
+    from argparse import Namespace
+    from instantsplat_amd.arguments import ModelParams, OptimizationParams, PipelineParams, cfg_args_text
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg_args_reference.json")))
+    text = cfg_args_text(ModelParams(source_path="/data/scene", model_path="/out/scene_3_views", resolution=1, n_views=3),
+                         OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True), PipelineParams(), save_iterations=[1000])
+    assert text == g["cfg_args_text"]
+    ns = eval(text)
+    assert isinstance(ns, Namespace)
+    for k, v in g["render_dataset"].items():   # what the reference's render.py extracts from it
+        assert getattr(ns, k) == v, k

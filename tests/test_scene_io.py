@@ -133,6 +133,12 @@ def test_training_from_directory_matches_reference_training(emu, tmp_path, loop)
     # the files
     outs = sorted(os.path.relpath(os.path.join(d, f), tmp_path) for d, _, fs in os.walk(tmp_path) for f in fs)
     assert outs == list(G["initdir_loop_outputs"]), outs
+    # cfg_args is the text the reference's render.py / metrics.py evaluate (arguments/__init__.py:96-116) to find the scene again
+    from argparse import Namespace   # noqa: F401  (the name the text refers to)
+    cfg = eval((tmp_path / "cfg_args").read_text())
+    assert isinstance(cfg, Namespace) and cfg.source_path == SCENE and cfg.n_views == V and cfg.resolution == 2 and cfg.images == "images"
+    assert cfg.model_path == str(tmp_path) and cfg.iterations == ITERS and cfg.save_iterations == [ITERS] and cfg.sh_degree == 3 and not cfg.eval
+    assert cfg.pp_optimizer and cfg.optim_pose
     assert np.allclose(np.load(tmp_path / "pose" / f"ours_{ITERS}" / "pose_org.npy"), G["initdir_loop_pose_org"], rtol=0, atol=1e-7)
     assert np.allclose(np.load(tmp_path / "pose" / f"ours_{ITERS}" / "pose_optimized.npy"), G["initdir_loop_pose_optimized"], rtol=0, atol=2e-6)
     v = iof.read_ply_vertices(tmp_path / "point_cloud" / f"iteration_{ITERS}" / "point_cloud.ply")
