@@ -40,6 +40,7 @@ class GaussianModel:
         self.optimizer = None
         self.spatial_lr_scale = 0
         self.P = None
+        self.test_P = None   # (reference: only ever read, by get_RT_test)
         # densification statistics of the reference's model (scene/gaussian_model.py:55-57).  Densification is disabled in
         # InstantSplat (train.py:195-206), so they only exist to keep capture() / restore() tuples interchangeable.
         self.max_radii2D = self.xyz_gradient_accum = self.denom = e
@@ -125,6 +126,11 @@ class GaussianModel:
             if ext is not None:
                 return ext.pose_row(self.P, idx)
         return self.P[idx]
+
+    def get_RT_test(self, idx):
+        """reference :138-140 (read by train.py:276 for the test cameras of `training_report`): row `idx` of `test_P`, a table the
+        reference never fills itself — whoever evaluates test views assigns it first (render.py optimises its own copy)."""
+        return self.test_P[idx]
 
     # ---- initialisation from a point cloud (reference :146-172)
     def create_from_pcd(self, points: torch.Tensor, colors: torch.Tensor, spatial_lr_scale: float, device, scale_gaussian=None):
