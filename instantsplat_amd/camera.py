@@ -46,6 +46,8 @@ class Camera:
         self.FoVx, self.FoVy = fovx, fovy
         self.image_width, self.image_height = width, height
         self.znear, self.zfar = ZNEAR, ZFAR
+        self.trans, self.scale = (0.0, 0.0, 0.0), 1.0   # reference :19,42-43 (`getWorld2View2`'s recentring: never used by InstantSplat)
+        self.data_device = torch.device(device)          # reference :33-38
         w2c = w2c.to(torch.float32)
         self.world_view_transform = w2c.t().contiguous().to(device)
         self.projection_matrix = projection_matrix(ZNEAR, ZFAR, fovx, fovy).t().contiguous().to(device)
