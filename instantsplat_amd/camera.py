@@ -61,4 +61,5 @@ class Camera:
             t = getattr(self, name)
             if t is not None:
                 setattr(self, name, t.to(device))
+        self.data_device = torch.device(device)
         return self
