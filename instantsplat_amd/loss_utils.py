@@ -5,6 +5,8 @@
     ssim(img1, img2, window_size=11, size_average=True) -> mean SSIM, 11x11 Gaussian window   (reference :55-85; what train.py:175
                                                          falls back to without the fused_ssim package)
     l1_loss_mask(network_output, gt, mask)            (reference :17-23, pose tracking)
+    ssim_loss_mask(img1, img2, mask, ...)             (reference :25-37; render.py:30 imports it)
+    gaussian, create_window, _ssim                    (reference :45-53, :65-85: the window and the conv2d formula, as helpers)
 
 `l1_loss` is ONE autograd node over `mi355gs_l1_loss_forward / _backward` (two launches forward, one backward) where the
 reference's expression is three eager kernels forward and four backward — the loop an unmodified train.py runs is bound by the
@@ -83,15 +85,22 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return _ssim_conv2d(img1, img2, window_size, size_average)
 
 
-def _ssim_conv2d(img1, img2, window_size, size_average):
-    """SSIM as the reference spells it in PyTorch (:45-85): a (window_size x window_size) Gaussian of sigma 1.5, built from
-    float64 values rounded to float32 and normalised in float32, applied per channel with zero padding; C1 = 0.01^2, C2 = 0.03^2."""
+def gaussian(window_size, sigma):
+    """reference :45-47: the normalised 1-D window — float64 values rounded to float32, normalised in float32"""
     import math
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)], dtype=torch.float32)
+    return g / g.sum()
+
+
+def create_window(window_size, channel):
+    """reference :49-53: [channel, 1, window_size, window_size], the outer product of the sigma-1.5 window with itself"""
+    g = gaussian(window_size, 1.5).unsqueeze(1)
+    return g.mm(g.t()).float().unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous()
+
+
+def _ssim(img1, img2, window, window_size, channel, size_average=True):
+    """reference :65-85: SSIM with a given window, applied per channel with zero padding; C1 = 0.01^2, C2 = 0.03^2"""
     import torch.nn.functional as F
-    channel = img1.size(-3)
-    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / (2 * 1.5 ** 2)) for x in range(window_size)], dtype=torch.float32)
-    g = (g / g.sum()).unsqueeze(1)
-    window = g.mm(g.t()).unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous().to(img1.device).type_as(img1)
     blur = lambda x: F.conv2d(x, window, padding=window_size // 2, groups=channel)
     mu1, mu2 = blur(img1), blur(img2)
     mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
@@ -99,3 +108,16 @@ def _ssim_conv2d(img1, img2, window_size, size_average):
     c1, c2 = 0.01 ** 2, 0.03 ** 2
     ssim_map = ((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
     return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+
+
+def ssim_loss_mask(img1, img2, mask, window_size=11, size_average=True):
+    """reference :25-37 (imported by render.py:30): SSIM of the two images with the mask multiplied in — the fused kernel for the
+    default window, like `ssim`."""
+    return ssim(img1 * mask, img2 * mask, window_size, size_average)
+
+
+def _ssim_conv2d(img1, img2, window_size, size_average):
+    """SSIM as the reference spells it in PyTorch (:55-63): its window on the images' device and dtype, then `_ssim`."""
+    channel = img1.size(-3)
+    window = create_window(window_size, channel).to(img1.device).type_as(img1)
+    return _ssim(img1, img2, window, window_size, channel, size_average)

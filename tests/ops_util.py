@@ -1371,3 +1371,10 @@ def check_loss_utils_against_the_references_own(dev):
     bound("loss_utils/ssim_7", abs(float(loss_utils.ssim(x, y, window_size=7)) - float(G["ssim_7"])), 2e-6)
     bound("loss_utils/ssim_per_image", float((loss_utils.ssim(x, y, size_average=False).cpu() - torch.from_numpy(G["ssim_11_per_image"])).abs().max()), 2e-6)
     bound("loss_utils/l1_mask", abs(float(loss_utils.l1_loss_mask(x, y, mask)) - float(G["l1_mask"])), 1e-6)
+    # every name the reference's module defines is here (render.py:30 imports ssim_loss_mask next to the others), with its results
+    assert all(callable(getattr(loss_utils, str(n), None)) for n in G["names"]), [str(n) for n in G["names"] if not hasattr(loss_utils, str(n))]
+    assert torch.equal(loss_utils.gaussian(11, 1.5), torch.from_numpy(G["gaussian_11"])) and torch.equal(loss_utils.create_window(7, 3), torch.from_numpy(G["window_7_3"]))
+    bound("loss_utils/_ssim_7", abs(float(loss_utils._ssim(x, y, loss_utils.create_window(7, 3).to(dev), 7, 3, True)) - float(G["ssim_core_7"])), 2e-6)
+    bound("loss_utils/ssim_mask_11", abs(float(loss_utils.ssim_loss_mask(x, y, mask)) - float(G["ssim_mask_11"])), 2e-6 if cuda else 1e-6)
+    bound("loss_utils/ssim_mask_7_per_image", float((loss_utils.ssim_loss_mask(x, y, mask, window_size=7, size_average=False).cpu()
+                                                       - torch.from_numpy(G["ssim_mask_7_per_image"])).abs().max()), 2e-6)
