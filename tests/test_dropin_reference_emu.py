@@ -87,7 +87,7 @@ def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_mo
         import instantsplat_amd.gaussian_renderer as our_gr
         import instantsplat_amd.optim as our_optim
         gm.PerPointAdam = our_optim.PerPointAdam     # `import scene.per_point_adam as ppa; ppa.PerPointAdam = opt.PerPointAdam`
-        gr.render = our_gr.render                    # `sys.modules["gaussian_renderer"] = instantsplat_amd.gaussian_renderer`
+        gr.render = our_gr.render                    # INTEGRATION.md section 1, second block: the function replaced on the reference's package
 
     tsrc = open(os.path.join(REF, "train.py")).read()
     fns = {n.name: n for n in ast.parse(tsrc).body if isinstance(n, ast.FunctionDef)}
