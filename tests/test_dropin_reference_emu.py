@@ -86,7 +86,7 @@ def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_mo
     if fused_glue:
         import instantsplat_amd.gaussian_renderer as our_gr
         import instantsplat_amd.optim as our_optim
-        gm.PerPointAdam = our_optim.PerPointAdam     # `import scene.per_point_adam as ppa; ppa.PerPointAdam = opt.PerPointAdam`
+        gm.PerPointAdam = our_optim.PerPointAdam     # `import scene.gaussian_model as gm; gm.PerPointAdam = opt.PerPointAdam`
         gr.render = our_gr.render                    # INTEGRATION.md section 1, second block: the function replaced on the reference's package
 
     tsrc = open(os.path.join(REF, "train.py")).read()
