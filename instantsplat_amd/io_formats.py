@@ -13,6 +13,7 @@ implemented without `plyfile` (not installed):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
@@ -225,3 +226,12 @@ def save_pose(path, quat_pose: torch.Tensor, colmap_ids: List[int]):
     w2c = [get_camera_from_tensor(q) for q in quat_pose.detach().cpu()]
     ordered = [w2c[colmap_ids.index(i + 1)] for i in range(len(colmap_ids))]
     np.save(path, torch.stack(ordered).numpy())
+
+
+def save_time(model_path, process_name: str, seconds: float):
+    """One line of the stage log the reference's pipeline keeps next to a model (utils/sfm_utils.py:43-50; train.py:217,231 append
+    '[2] train_joint_TrainTime' and '[2] train_joint'): `<name>: <m> min <s> sec`, appended to <model_path>/train_time.txt."""
+    os.makedirs(model_path, exist_ok=True)
+    minutes, secs = divmod(seconds, 60)
+    with open(os.path.join(model_path, "train_time.txt"), "a") as f:
+        f.write(f"{process_name}: {int(minutes)} min {int(secs)} sec\n")

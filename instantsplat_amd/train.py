@@ -664,7 +664,7 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
     iteration, chkpnt<it>.pth = torch.save((gaussians.capture(), it)) at every checkpoint iteration, and a run started from
     such a file continues at its iteration with its optimizer state."""
     import os
-    from .io_formats import save_pose
+    from .io_formats import save_pose, save_time
     import dataclasses
     opt = dataclasses.replace(opt, iterations=iterations) if opt is not None else OptimizationParams(iterations=iterations, pp_optimizer=True, optim_pose=True)
     if isinstance(scene, (str, os.PathLike)):
@@ -725,6 +725,8 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
             if log_every and (i + 1) % log_every == 0:
                 print(f"[iter {i + 1}] loss {last:.6f}")
         it = i + 1
+        if it == iterations and model_path:   # reference train.py:213-217: the time of the loop itself, before the last save
+            save_time(model_path, "[2] train_joint_TrainTime", time.perf_counter() - t0)
         if it in saving or it in checkpoints:
             cancel_prepared(st)
             if ra is not None:
@@ -741,6 +743,8 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
     if is_cuda:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if model_path:   # reference train.py:229-231
+        save_time(model_path, "[2] train_joint", dt)
     n_done = max(iterations - int(first_iter), 1)
     return dict(seconds=dt, iters_per_sec=n_done / dt, first_loss=first, last_loss=last, psnr_before=psnr0,
                 psnr_after=evaluate_psnr(st), state=st)

@@ -1,7 +1,8 @@
 """Generates tests/golden/cfg_args_reference.json: the text the reference's train.py leaves in <model_path>/cfg_args
 (train.py:245-246, `str(Namespace(**vars(args)))`) for the command line of its scripts, produced by the reference's OWN argument
 classes (arguments/__init__.py, loaded from /root/reference) and the parser set-up of train.py:298-314 — and what the reference's own
-`get_combined_args` (arguments/__init__.py:96-116) makes of it for render.py.  Run in the build container only."""
+`get_combined_args` (arguments/__init__.py:96-116) makes of it for render.py; and the lines the reference's `save_time`
+(utils/sfm_utils.py:43-50) appends to <model_path>/train_time.txt.  Run in the build container only."""
 import importlib.util, json, os, sys
 from argparse import ArgumentParser, Namespace
 
@@ -39,7 +40,20 @@ try:
 finally:
     sys.argv = old
 ds = model.extract(merged)
-json.dump({"argv": argv, "cfg_args_text": text, "train_dataset_source_path": dataset.source_path,
+# utils/sfm_utils.py:43-50 `save_time` (the module itself needs cv2 / roma / open3d: the function definition is taken from the file)
+import ast, tempfile
+from pathlib import Path
+src = open(os.path.join(REF, "utils", "sfm_utils.py")).read()
+fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "save_time")
+ns = {"Path": Path}
+exec(compile(ast.Module(body=[fn], type_ignores=[]), "sfm_utils.py", "exec"), ns)
+td = tempfile.mkdtemp()
+calls = [["[2] train_joint_TrainTime", 83.74], ["[2] train_joint", 125.2], ["[4] render", 3.9]]
+for name, sec in calls:
+    ns["save_time"](os.path.join(td, "model"), name, sec)
+train_time_text = open(os.path.join(td, "model", "train_time.txt")).read()
+
+json.dump({"argv": argv, "cfg_args_text": text, "save_time_calls": calls, "train_time_txt": train_time_text, "train_dataset_source_path": dataset.source_path,
            "render_dataset": {k: getattr(ds, k) for k in ("sh_degree", "source_path", "images", "resolution", "white_background", "data_device", "eval", "n_views",
                                                           "init_scale_from_view_depth")},
            "render_iterations": merged.iterations},

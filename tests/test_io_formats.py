@@ -93,3 +93,13 @@ def test_cfg_args_is_the_text_the_references_own_parser_writes():
     assert isinstance(ns, Namespace)
     for k, v in g["render_dataset"].items():   # what the reference's render.py extracts from it
         assert getattr(ns, k) == v, k
+
+
+def test_save_time_appends_the_references_lines(tmp_path):
+    """<model_path>/train_time.txt: the reference's `save_time` (utils/sfm_utils.py:43-50), pinned by what the function itself wrote
+    for the same calls (tests/golden/make_golden_cfg_args.py)."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg_args_reference.json")))
+    for name, sec in g["save_time_calls"]:
+        io.save_time(str(tmp_path / "model"), name, sec)
+    assert (tmp_path / "model" / "train_time.txt").read_text() == g["train_time_txt"]

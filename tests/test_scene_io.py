@@ -132,7 +132,12 @@ def test_training_from_directory_matches_reference_training(emu, tmp_path, loop)
     assert [g.optimizer.state[grp["params"][0]]["step"] for grp in g.optimizer.param_groups] == list(G["initdir_loop_final_steps"])
     # the files
     outs = sorted(os.path.relpath(os.path.join(d, f), tmp_path) for d, _, fs in os.walk(tmp_path) for f in fs)
-    assert outs == list(G["initdir_loop_outputs"]), outs
+    # (the recorded run had the reference's `save_time` stubbed out — utils/sfm_utils.py needs cv2 / open3d —: its real runs also leave
+    # train_time.txt, whose lines are pinned by the function's own output below)
+    assert outs == sorted(list(G["initdir_loop_outputs"]) + ["train_time.txt"]), outs
+    import re
+    lines = (tmp_path / "train_time.txt").read_text().splitlines()
+    assert len(lines) == 2 and re.fullmatch(r"\[2\] train_joint_TrainTime: \d+ min \d+ sec", lines[0]) and re.fullmatch(r"\[2\] train_joint: \d+ min \d+ sec", lines[1]), lines
     # cfg_args is the text the reference's render.py / metrics.py evaluate (arguments/__init__.py:96-116) to find the scene again
     from argparse import Namespace   # noqa: F401  (the name the text refers to)
     cfg = eval((tmp_path / "cfg_args").read_text())
