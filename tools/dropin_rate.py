@@ -9,9 +9,9 @@ from instantsplat_amd.arguments import OptimizationParams
 from instantsplat_amd.synthetic import syn_pointmap
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 dev = torch.device("cuda:0")
-if os.environ.get("GS_PIN", "1") == "1":   # what bench.py and the launcher do: one cache domain of the GPU's NUMA node
-    from instantsplat_amd.launch import pin_rank_to_cpu_slice
-    pin_rank_to_cpu_slice(0, 1, device_of_rank=lambda r: 0, compact=True)
+from instantsplat_amd.launch import pin_mode, pin_rank_to_cpu_slice
+if pin_mode() != "off":   # what bench.py and the launcher do (MI355GS_PIN = node | compact | off)
+    pin_rank_to_cpu_slice(0, 1, device_of_rank=lambda r: 0, compact=pin_mode() == "compact")
 import gc
 if os.environ.get("GS_GC") == "off":
     gc.disable()
