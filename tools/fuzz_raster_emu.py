@@ -6,7 +6,7 @@ import sys, time, random, traceback
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from instantsplat_amd import _lib
-_lib._use_library_for_testing(__import__('os').path.join(sys.path[0], 'tests', 'emu', 'libmi355gs_emu.so'))
+_lib._use_library_for_testing(__import__('os').environ.get('MI355GS_EMU_LIB') or __import__('os').path.join(sys.path[0], 'tests', 'emu', 'libmi355gs_emu.so'))
 from tests.util import assert_raster_parity, run_blob_case
 dev = torch.device('cpu')
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
