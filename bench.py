@@ -58,7 +58,7 @@ def supervise(args):
 
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     for attempt in (1, 2):
-        env = dict(os.environ, MI355GS_BENCH_CHILD="1")
+        env = dict(os.environ, MI355GS_BENCH_CHILD="1", MI355GS_BENCH_LIMIT=str(args.attempt_seconds))
         if attempt == 2:
             env["MI355GS_PIN"] = "off"
         t0 = time.perf_counter()
@@ -124,6 +124,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and os.environ.get("MI355GS_BENCH_CHILD") != "1" and args.attempt_seconds > 0:
         return supervise(args)
 
+    if os.environ.get("MI355GS_BENCH_LIMIT"):   # a supervised child: should it stall, say WHERE before the parent kills it
+        import faulthandler
+        faulthandler.dump_traceback_later(max(float(os.environ["MI355GS_BENCH_LIMIT"]) - 15.0, 0.2), exit=False, file=sys.stderr)
     global torch, dist   # (imported here: the supervising parent above never pays for it)
     import torch
     import torch.distributed as dist

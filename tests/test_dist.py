@@ -131,6 +131,7 @@ def test_bench_kills_a_stalled_attempt_and_tries_once_more(emu_lib_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and r.stdout.strip() == ""
     assert r.stderr.count("was killed") == 2 and "attempt 2" in r.stderr
+    assert "most recent call first" in r.stderr   # the stalled child said where it stood (faulthandler) before it was killed
 
 
 def test_launch_report_carries_the_host_and_multi_node_is_not_sliced(monkeypatch):
