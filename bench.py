@@ -124,9 +124,11 @@ def main():
     if "WORLD_SIZE" not in os.environ and os.environ.get("MI355GS_BENCH_CHILD") != "1" and args.attempt_seconds > 0:
         return supervise(args)
 
+    import faulthandler
     if os.environ.get("MI355GS_BENCH_LIMIT"):   # a supervised child: should it stall, say WHERE before the parent kills it
-        import faulthandler
         faulthandler.dump_traceback_later(max(float(os.environ["MI355GS_BENCH_LIMIT"]) - 15.0, 0.2), exit=False, file=sys.stderr)
+    elif "WORLD_SIZE" in os.environ:            # a rank under a launcher: nobody supervises it, but a run still going after 15 minutes
+        faulthandler.dump_traceback_later(900.0, exit=False, file=sys.stderr)   # (it takes two or three) leaves its stacks in the log
     global torch, dist   # (imported here: the supervising parent above never pays for it)
     import torch
     import torch.distributed as dist
