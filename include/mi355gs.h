@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 8
+#define MI355GS_ABI_VERSION 9
 
 /* error codes */
 #define MI355GS_OK 0
@@ -135,6 +135,16 @@ int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, in
  * before sizing a frame's buffers and keep it until that frame's backward has been enqueued; a trainer handle takes a
  * snapshot of it at mi355gs_trainer_create and uses that for all its calls. */
 int mi355gs_tune_min_units(int min_units);
+
+/* Convention of dL_dscales under scale_modifier != 1 (ABI v9).  The covariance is built from s = scale_modifier * scale
+ * (reference gaussian_renderer/__init__.py:29,66 is the only place the modifier comes from; it trains with 1.0).
+ *   mode 0 (default): dL_dscales = dL/ds, the gradient with respect to the MODIFIED scale — what the published operator's
+ *     backward returns (its computeCov3D backward forms s = mod * scale first and writes dL/ds into dL_dscale; recalled, the
+ *     operator is an un-vendored submodule: reference .gitmodules:4-6).  "Results identical to the reference's" is the bar.
+ *   mode 1: dL_dscales = scale_modifier * dL/ds, the true derivative with respect to `scales`.
+ * The two are the same number at scale_modifier = 1.  Rotation gradients are not affected.  Returns the previous mode;
+ * mode < 0 only queries.  Process-wide, read when a backward is enqueued. */
+int mi355gs_tune_scale_grad(int mode);
 
 /* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that
  * cannot see the kernels (they are enqueued inside this library) can still attribute time to them.

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "mi355gs_raster_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),
     "mi355gs_tune_min_units": (c_int, [c_int]),
+    "mi355gs_tune_scale_grad": (c_int, [c_int]),
     "mi355gs_profile_begin": (c_int, []),
     "mi355gs_profile_set_period": (c_int, [c_int]),
     "mi355gs_profile_work_counters": (c_int, [_P]),
@@ -70,7 +71,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 8   # include/mi355gs.h MI355GS_ABI_VERSION the signatures above were written for
+ABI_VERSION = 9   # include/mi355gs.h MI355GS_ABI_VERSION the signatures above were written for
 
 
 def _bind(path: str):

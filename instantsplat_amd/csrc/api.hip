@@ -59,6 +59,8 @@ thread_local GsFusedStepHooks g_fused;
 
 void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
 
+static int g_scale_grad_exact = 0;   // mi355gs_tune_scale_grad
+
 static CamParams make_cam(const float* view, const float* proj, const float* campos, float tanfovx, float tanfovy,
                           float scale_modifier, int W, int H) {
   CamParams cp;
@@ -66,6 +68,7 @@ static CamParams make_cam(const float* view, const float* proj, const float* cam
   cp.tanfovx = tanfovx; cp.tanfovy = tanfovy;
   cp.focal_x = W / (2.0f * tanfovx); cp.focal_y = H / (2.0f * tanfovy);
   cp.scale_modifier = scale_modifier;
+  cp.scale_grad_factor = g_scale_grad_exact ? scale_modifier : 1.0f;
   cp.W = W; cp.H = H;
   cp.gx = (W + GS_TILE - 1) / GS_TILE; cp.gy = (H + GS_TILE - 1) / GS_TILE;
   return cp;
@@ -222,6 +225,12 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                            (g_fused.gate && g_fused.gate_sh_rest >= 0) ? g_fused.gate + g_fused.gate_sh_rest : nullptr);
   GS_CHECK_LAUNCH("preprocess_bwd");
   return MI355GS_OK;
+}
+
+int mi355gs_tune_scale_grad(int mode) {
+  const int old = g_scale_grad_exact;
+  if (mode >= 0) g_scale_grad_exact = mode ? 1 : 0;
+  return old;
 }
 
 int mi355gs_raster_frame_stats(void* stream_, int W, int H, const void* tiles, int64_t* stats) {

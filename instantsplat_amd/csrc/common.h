@@ -147,6 +147,8 @@ struct CamParams {  // passed by value (kernarg): wave-uniform, lives in SGPRs
   const float* proj;
   const float* campos;
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  float scale_grad_factor;   // backward only: dL/dscale = factor x dL/d(scale_modifier * scale) — 1 (the published operator's
+                             // convention, default) or scale_modifier (the true derivative), mi355gs_tune_scale_grad
   int W, H, gx, gy;
 };
 

@@ -446,7 +446,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       float Rp[9];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        gs[k] = mod * (R[k] * gL[k] + R[3 + k] * gL[3 + k] + R[6 + k] * gL[6 + k]);
+        // the gradient with respect to the MODIFIED scale, times cp.scale_grad_factor: 1 by default — the published operator's
+        // computeCov3D backward forms s = mod * scale first and returns dL/ds as dL/dscale — or mod (the true derivative) after
+        // mi355gs_tune_scale_grad(1).  The same number at mod = 1, the only value the reference trains with.
+        gs[k] = cp.scale_grad_factor * (R[k] * gL[k] + R[3 + k] * gL[3 + k] + R[6 + k] * gL[6 + k]);
 #pragma unroll
         for (int r = 0; r < 3; ++r) Rp[3 * r + k] = gL[3 * r + k] * s[k];
       }

@@ -9,14 +9,13 @@
  * SURVEY.md Appendix A.1-A.5 and is cross-checked against oracle/raster_torch.py (autograd, fp64)
  * in tests/test_oracle.py.  No golden output of the CUDA operator exists: "parity unpinned".
  *
- * One point where the published operator may differ and that cannot be settled here: dL/dscale under scale_modifier != 1.
- * This file (and the HIP kernel, which agrees with it: tests/edge_cases.py::check_scale_modifier_and_init_opacity at mod = 1.7)
- * returns the true derivative, d/dscale of Sigma(mod * scale) = mod x the derivative with respect to the modified scale
- * (the `c->mod *` factor at the `gs[k] =` line below; SURVEY.md A.4-5 describes upstream that way).  Two independent
- * recollections of upstream's computeCov3D backward (`dL_dscale->x = glm::dot(Rt[0], dL_dMt[0])`, with `s = mod * scale` formed
- * earlier) have NO such factor, i.e. upstream would return dL/d(mod * scale).  At mod = 1 — the only value the reference ever
- * trains with (gaussian_renderer/__init__.py:29, scaling_modifier=1.0; viewers change it for rendering only) — the two are the
- * same number; for mod != 1 the gradient with respect to scales is UNPINNED in both directions.
+ * dL/dscale under scale_modifier != 1: the covariance is built from s = mod * scale, and the published operator's computeCov3D
+ * backward (recalled: `glm::vec3 s = mod * scale` formed first, then `dL_dscale->x = glm::dot(Rt[0], dL_dMt[0])`) returns dL/ds —
+ * the gradient with respect to the MODIFIED scale — as dL_dscale.  That is the default here (and in the HIP kernel,
+ * csrc/preprocess.hip): "results identical to the reference's" is the bar.  gsref_set_scale_grad_exact(1) switches both
+ * precisions to the true derivative, mod x dL/ds (what autograd of oracle/raster_torch.py gives with SCALE_GRAD_EXACT = True);
+ * tests/edge_cases.py runs mod = 1.7 in both modes.  At mod = 1 — the only value the reference trains with
+ * (gaussian_renderer/__init__.py:29, scaling_modifier=1.0; viewers change it for rendering only) — the two are the same number.
  *
  * Compiled twice (oracle/Makefile): -DGSREF_DOUBLE=0 -> symbols *_f32, =1 -> *_f64.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library.
@@ -46,6 +45,7 @@ typedef float real;
 #endif
 
 #define TILE 16
+extern int gsref_scale_grad_exact;   /* defined once, in the f32 object (gsref_set_scale_grad_exact) */
 
 static const real SH_C0 = (real)0.28209479177387814;
 static const real SH_C1 = (real)0.4886025119029199;
@@ -495,7 +495,7 @@ void SUF(gsref_backward)(void* c_, const real* means3D, const real* shs, const r
       real* gs = dL_dscales + 3 * (size_t)i;
       real Rp[9];
       for (int k = 0; k < 3; ++k) {
-        gs[k] = c->mod * (Rm[k] * gL[k] + Rm[3 + k] * gL[3 + k] + Rm[6 + k] * gL[6 + k]);
+        gs[k] = (gsref_scale_grad_exact ? c->mod : (real)1) * (Rm[k] * gL[k] + Rm[3 + k] * gL[3 + k] + Rm[6 + k] * gL[6 + k]);
         for (int r = 0; r < 3; ++r) Rp[r * 3 + k] = gL[r * 3 + k] * c->mod * s[k];
       }
       real r_ = q[0], x = q[1], y = q[2], z = q[3];
@@ -512,6 +512,9 @@ void SUF(gsref_backward)(void* c_, const real* means3D, const real* shs, const r
 }
 
 #if !GSREF_DOUBLE
+/* dL/dscale convention of both precisions (see the header): 0 = dL/d(mod * scale) as the published operator, 1 = true derivative */
+int gsref_scale_grad_exact = 0;
+int gsref_set_scale_grad_exact(int on) { const int old = gsref_scale_grad_exact; if (on >= 0) gsref_scale_grad_exact = on ? 1 : 0; return old; }
 /* thread count used by both precisions (bench.py's cpu_baseline reports it as `cores`) */
 int gsref_set_threads(int n) {
 #ifdef _OPENMP

@@ -87,11 +87,16 @@ def quat_to_rot_raw(q: torch.Tensor) -> torch.Tensor:
     return R.reshape(-1, 3, 3)
 
 
+SCALE_GRAD_EXACT = False   # True: autograd's own d/dscale of Sigma(mod * scale); False: the published operator's dL/d(mod * scale)
+
+
 def cov3d_from_scale_rot(scales, mod, rots):
     """Sigma = R S S^T R^T packed [xx,xy,xz,yy,yz,zz] (layout of reference
-    utils/general_utils.py:64-76)."""
+    utils/general_utils.py:64-76).  The gradient that reaches `scales` follows the published operator unless SCALE_GRAD_EXACT:
+    value mod * scale, derivative 1 (the operator hands back dL/d(mod * scale) as dL/dscale; see oracle/gs_ref.c)."""
     R = quat_to_rot_raw(rots)
-    L = R * (mod * scales)[:, None, :]
+    s = mod * scales if (SCALE_GRAD_EXACT or mod == 1.0) else (mod * scales).detach() + (scales - scales.detach())
+    L = R * s[:, None, :]
     S = L @ L.transpose(1, 2)
     return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=-1)
 

@@ -153,7 +153,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.mi355gs_abi_version.restype = ctypes.c_int
-    assert lib.mi355gs_abi_version() == 8
+    assert lib.mi355gs_abi_version() == 9
 
 
 def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):

@@ -100,6 +100,27 @@ def test_c_oracle_equals_autograd_restatement_f64(case):
         assert _rel(c_g[k], t_g[k]) <= 1e-10, (k, _rel(c_g[k], t_g[k]))
 
 
+def test_c_oracle_scale_grad_conventions_f64():
+    """scale_modifier = 0.7 in both conventions of dL/dscale: the default (the published operator's dL/d(mod * scale), checked
+    against the restatement above through CASES[2]) and the true derivative (autograd's own), which is mod times the default."""
+    P, W, H, deg, sm, seed, pc, pcov, mod = CASES[2]
+    cam, inp = _blob_inputs(P, W, H, seed, sm, F64)
+    torch.manual_seed(seed + 50)
+    wgt = torch.randn(3, H, W, dtype=F64)
+    _, _, g_default = _run("c", cam, inp, deg, F64, wgt, pc, pcov, mod)
+    assert gs_ref.lib().gsref_set_scale_grad_exact(1) == 0
+    rt.SCALE_GRAD_EXACT = True
+    try:
+        _, _, g_c = _run("c", cam, inp, deg, F64, wgt, pc, pcov, mod)
+        _, _, g_t = _run("torch", cam, inp, deg, F64, wgt, pc, pcov, mod)
+    finally:
+        gs_ref.lib().gsref_set_scale_grad_exact(0)
+        rt.SCALE_GRAD_EXACT = False
+    for k in g_c:
+        assert _rel(g_c[k], g_t[k]) <= 1e-10, k
+        assert _rel(g_c[k], (mod if k == "scales" else 1.0) * g_default[k]) <= 1e-12, k
+
+
 @pytest.mark.parametrize("case", CASES[:3], ids=["sh0", "sh3", "sh2_mod"])
 def test_c_oracle_f32_vs_f64(case):
     """The fp32 build (what the device kernels are compared with) against the fp64 build of the same C source."""

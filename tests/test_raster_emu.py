@@ -18,7 +18,19 @@ def test_precomputed_color_and_cov(emu):
 
 
 def test_scale_modifier_and_init_opacity(emu):
-    assert_raster_parity(run_blob_case(emu, 300, 48, 48, 1, scale_mean=0.1, opacity="init", mod=1.7))
+    """mod = 1.7 in both conventions of dL/dscale (include/mi355gs.h, mi355gs_tune_scale_grad): the published operator's
+    dL/d(mod * scale) (default) and the true derivative, which is mod times that; nothing else may move."""
+    default = run_blob_case(emu, 300, 48, 48, 1, scale_mean=0.1, opacity="init", mod=1.7)
+    assert_raster_parity(default)
+    exact = run_blob_case(emu, 300, 48, 48, 1, scale_mean=0.1, opacity="init", mod=1.7, scale_grad_exact=True)
+    assert_raster_parity(exact)
+    for side in ("ref", "dut"):
+        a, b = default[side]["grads"], exact[side]["grads"]
+        assert float(a["scaling"].abs().max()) > 0
+        assert torch.allclose(b["scaling"], 1.7 * a["scaling"], rtol=1e-5, atol=0)
+        for k in a:
+            if k != "scaling":
+                assert torch.equal(a[k], b[k]), k
 
 
 def test_empty_and_all_culled(emu):

@@ -22,7 +22,16 @@ def test_precomputed_color_and_cov(gpu):
 
 
 def test_scale_modifier_and_init_opacity(gpu):
-    assert_raster_parity(run_blob_case(gpu, 3000, 128, 128, 1, scale_mean=0.1, opacity="init", mod=1.7))
+    """mod = 1.7 in both conventions of dL/dscale (include/mi355gs.h, mi355gs_tune_scale_grad): the published operator's
+    dL/d(mod * scale) (default) and the true derivative, which is mod times that."""
+    default = run_blob_case(gpu, 3000, 128, 128, 1, scale_mean=0.1, opacity="init", mod=1.7)
+    assert_raster_parity(default)
+    exact = run_blob_case(gpu, 3000, 128, 128, 1, scale_mean=0.1, opacity="init", mod=1.7, scale_grad_exact=True)
+    assert_raster_parity(exact)
+    for side in ("ref", "dut"):   # (the device's float atomics make two runs differ in the last bits: a norm, not equality)
+        a, b = default[side]["grads"]["scaling"], exact[side]["grads"]["scaling"]
+        assert float(a.abs().max()) > 0
+        assert float((b - 1.7 * a).norm() / a.norm()) <= 1e-4
 
 
 def test_empty(gpu):

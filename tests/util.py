@@ -20,8 +20,20 @@ def relerr(a, b):
 
 
 def run_blob_case(device, P, W, H, deg, scale_mean=0.05, seed=1, opacity="random", bg=(0.2, 0.5, 0.9), mod=1.0,
-                  precomp_color=False, precomp_cov=False, backward=True):
-    """Returns dict(ref=..., dut=...) each with color, radii, grads (dict)."""
+                  precomp_color=False, precomp_cov=False, backward=True, scale_grad_exact=False):
+    """Returns dict(ref=..., dut=...) each with color, radii, grads (dict).  scale_grad_exact: both sides return the true
+    derivative with respect to `scales` instead of the published operator's dL/d(mod * scale) (include/mi355gs.h,
+    mi355gs_tune_scale_grad; oracle/gs_ref.c header) — the two only differ at mod != 1."""
+    from instantsplat_amd import _lib
+    old = (gs_ref.lib().gsref_set_scale_grad_exact(int(scale_grad_exact)), _lib.lib().mi355gs_tune_scale_grad(int(scale_grad_exact)))
+    try:
+        return _run_blob_case(device, P, W, H, deg, scale_mean, seed, opacity, bg, mod, precomp_color, precomp_cov, backward)
+    finally:
+        gs_ref.lib().gsref_set_scale_grad_exact(old[0])
+        _lib.lib().mi355gs_tune_scale_grad(old[1])
+
+
+def _run_blob_case(device, P, W, H, deg, scale_mean, seed, opacity, bg, mod, precomp_color, precomp_cov, backward):
     sc = syn_blob(P, W, H, seed=seed, scale_mean=scale_mean, opacity=opacity)
     bg_t = torch.tensor(bg, dtype=torch.float32)
     torch.manual_seed(seed + 100)
