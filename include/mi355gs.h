@@ -95,6 +95,17 @@ int mi355gs_raster_forward_render(
     void* stream, int P, int W, int H, int64_t capacity, const float* bg,
     const void* geom, void* tiles, void* binning, float* out_color, int debug);
 
+/* Stage 2 for a frame NO BACKWARD WILL FOLLOW (ABI v9) — every render under torch.no_grad(): reference render.py:87,137,177
+ * (render_set, render_set_optimize's final renders, the FPS loop at :172-186), train.py:277 (training_report), evaluation.
+ * Same scatter, sort and compositing, bit-identical out_color / radii / per-pixel state in `tiles`; nothing is left behind for a
+ * backward: `binning` is only mi355gs_raster_binning_bytes_render_only() bytes (sort keys + the per-tile lists, 12 B per
+ * instance — the training layout adds 4 KiB per 64-instance unit), and the compositing kernel's render-only instantiation stores
+ * no boundary records, hit masks, unit table or quadrant maxima.  mi355gs_raster_backward must not be called on such a frame. */
+size_t mi355gs_raster_binning_bytes_render_only(int64_t num_instances, int W, int H);
+int mi355gs_raster_forward_render_only(
+    void* stream, int P, int W, int H, int64_t capacity, const float* bg,
+    const void* geom, void* tiles, void* binning, float* out_color, int debug);
+
 /* Backward of both stages.  dL_dpix[3,H,W] in; gradients out (all written, zero where unused):
  *   dL_dmeans3D[P,3] dL_dmeans2D[P,3] (x,y in the reference's NDC-scaled screen units, z = 0)
  *   dL_dshs[P,M,3] (split storage: dL_dshs[P,1,3] + dL_dshs_rest[P,M-1,3]) or dL_dcolors[P,3], dL_dopacities[P],
@@ -148,7 +159,8 @@ int mi355gs_tune_scale_grad(int mode);
 
 /* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that
  * cannot see the kernels (they are enqueued inside this library) can still attribute time to them.
- * kind: 0 = composite forward, 1 = composite backward.  profile_read synchronises the recorded events
+ * kind: 0 = composite forward (training instantiation), 1 = composite backward, 2 = composite forward, render-only
+ * instantiation.  profile_read synchronises the recorded events
  * and returns the summed milliseconds and launch count since profile_begin. */
 int mi355gs_profile_begin(void);
 /* Time only every `every`-th launch of a kind (default 1: all).  An event pair costs ~3.5 us of stream time, which matters when

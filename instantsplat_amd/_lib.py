@@ -29,6 +29,8 @@ _SIGNATURES = {
     "mi355gs_raster_forward_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P,
                                                   _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_forward_render": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int]),
+    "mi355gs_raster_binning_bytes_render_only": (c_size_t, [c_int64, c_int, c_int]),
+    "mi355gs_raster_forward_render_only": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_raster_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
                                         _P, c_float, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                         c_int, c_int]),
@@ -116,7 +118,7 @@ _EXT = None
 _EXT_BOUND_TO = None
 _EXT_SYMBOLS = ("mi355gs_raster_geom_bytes", "mi355gs_raster_tiles_bytes", "mi355gs_raster_binning_bytes",
                 "mi355gs_raster_grad_scratch_bytes", "mi355gs_raster_grad_gate_offset", "mi355gs_posed_forward_preprocess", "mi355gs_raster_forward_preprocess", "mi355gs_raster_backward",
-                "mi355gs_raster_forward_render", "mi355gs_posed_backward", "mi355gs_ssim_scratch_bytes", "mi355gs_l1_ssim_loss_fused", "mi355gs_ssim_forward", "mi355gs_ssim_backward",
+                "mi355gs_raster_forward_render", "mi355gs_raster_binning_bytes_render_only", "mi355gs_raster_forward_render_only", "mi355gs_posed_backward", "mi355gs_ssim_scratch_bytes", "mi355gs_l1_ssim_loss_fused", "mi355gs_ssim_forward", "mi355gs_ssim_backward",
                 "mi355gs_adam_multi_step", "mi355gs_error_string", "mi355gs_l1_scratch_bytes", "mi355gs_l1_loss_forward", "mi355gs_l1_loss_backward")
 
 

@@ -17,7 +17,7 @@ int gs_launch_binning(hipStream_t, int, int, int, const float*, const uint2*, co
                       const uint32_t*, const uint32_t*, const uint32_t*);
 int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             float*, float*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint4*, float4*, uint32_t,
-                            const uint32_t*, unsigned long long*, uint32_t, uint32_t*, unsigned long long*);
+                            const uint32_t*, unsigned long long*, uint32_t, uint32_t*, unsigned long long*, bool);
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint4*,
                             const float4*, const uint32_t*, uint32_t, bool, const unsigned long long*, uint32_t, const uint32_t*,
@@ -26,15 +26,15 @@ int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, cons
 
 // ---- optional per-kernel timing (HIP events on the launch stream)
 namespace {
-constexpr int PROF_KINDS = 2, PROF_MAX = 8192;
+constexpr int PROF_KINDS = 3, PROF_MAX = 8192;   // composite forward, composite backward, render-only composite forward
 struct ProfState {
   bool on = false;
   unsigned long long* work_counters = nullptr;   // device uint64[16] or null (mi355gs_profile_work_counters)
   hipEvent_t ev[PROF_KINDS][PROF_MAX][2];
-  int created[PROF_KINDS] = {0, 0};
-  int used[PROF_KINDS] = {0, 0};
+  int created[PROF_KINDS] = {0, 0, 0};
+  int used[PROF_KINDS] = {0, 0, 0};
   int period = 1;                   // events go around every period-th launch of a kind (mi355gs_profile_set_period)
-  int seen[PROF_KINDS] = {0, 0};   // launches of the kind since profile_begin
+  int seen[PROF_KINDS] = {0, 0, 0};   // launches of the kind since profile_begin
 } g_prof;
 struct ProfScope {
   hipStream_t s; hipEvent_t stop; bool active = false;
@@ -144,15 +144,17 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
   return MI355GS_OK;
 }
 
-int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t capacity, const float* bg, const void* geom,
-                                  void* tiles, void* binning, float* out_color, int debug) {
+// Stage 2 of the forward in its two forms: `train` leaves the backward's work units, boundary records, hit masks and quadrant
+// maxima in `binning` / `tiles`; render-only has a `binning` of keys + lists only and writes the image and the per-pixel state.
+static int forward_stage2(void* stream_, int P, int W, int H, int64_t capacity, const float* bg, const void* geom, void* tiles,
+                          void* binning, float* out_color, int debug, bool train) {
   hipStream_t stream = (hipStream_t)stream_;
   if (P < 0 || W <= 0 || H <= 0 || !geom || !tiles || !bg || !out_color) return MI355GS_EINVAL;
   const uint32_t cap = clamp_capacity(capacity);
   if (cap > 0 && !binning) return MI355GS_EINVAL;
   const GeomLayout gl(P);
   const TilesLayout tl(W, H);
-  const BinningLayout bl(capacity, tl.T);
+  const BinningLayout bl(capacity, tl.T);   // (keys and list come first in it: the render-only buffer is its head)
   const char* g = (const char*)geom;
   char* t = (char*)tiles;
   char* b = (char*)binning;
@@ -162,15 +164,31 @@ int mi355gs_raster_forward_render(void* stream_, int P, int W, int H, int64_t ca
                     (const uint32_t*)(g + gl.bin_n));
   GS_CHECK_LAUNCH("binning");
   {
-    ProfScope prof(0, stream);
+    ProfScope prof(train ? 0 : 2, stream);
     gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
                             (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.seg_first), (const uint32_t*)(t + tl.part_first),
-                            (uint4*)(b + bl.unit_tile), (float4*)(b + bl.bstate), bl.max_units, (const uint32_t*)(t + tl.meta),
-                            (unsigned long long*)(b + bl.hitmask), bl.max_chunks, (uint32_t*)(t + tl.qmax), g_prof.work_counters);
+                            train ? (uint4*)(b + bl.unit_tile) : nullptr, train ? (float4*)(b + bl.bstate) : nullptr, bl.max_units,
+                            (const uint32_t*)(t + tl.meta), train ? (unsigned long long*)(b + bl.hitmask) : nullptr, bl.max_chunks,
+                            (uint32_t*)(t + tl.qmax), train ? g_prof.work_counters : nullptr, train);
   }
   GS_CHECK_LAUNCH("composite_fwd");
   return MI355GS_OK;
+}
+
+int mi355gs_raster_forward_render(void* stream, int P, int W, int H, int64_t capacity, const float* bg, const void* geom,
+                                  void* tiles, void* binning, float* out_color, int debug) {
+  return forward_stage2(stream, P, W, H, capacity, bg, geom, tiles, binning, out_color, debug, true);
+}
+
+size_t mi355gs_raster_binning_bytes_render_only(int64_t n, int W, int H) {
+  if (W <= 0 || H <= 0) return 0;
+  return BinningLayout(n, TilesLayout(W, H).T).unit_tile;   // keys + list: everything in front of the backward's tables
+}
+
+int mi355gs_raster_forward_render_only(void* stream, int P, int W, int H, int64_t capacity, const float* bg, const void* geom,
+                                       void* tiles, void* binning, float* out_color, int debug) {
+  return forward_stage2(stream, P, W, H, capacity, bg, geom, tiles, binning, out_color, debug, false);
 }
 
 int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, const float* bg, const float* means3D,
@@ -247,8 +265,7 @@ int mi355gs_raster_frame_stats(void* stream_, int W, int H, const void* tiles, i
 
 int mi355gs_profile_begin(void) {
   g_prof.on = true;
-  g_prof.used[0] = g_prof.used[1] = 0;
-  g_prof.seen[0] = g_prof.seen[1] = 0;
+  for (int k = 0; k < PROF_KINDS; ++k) g_prof.used[k] = g_prof.seen[k] = 0;
   return MI355GS_OK;
 }
 

@@ -141,7 +141,12 @@ constexpr int FWD_GROUP = GS_FWD_GROUP;   // hits per walk step (A/B build switc
 // COUNT: the measurement instantiation (mi355gs_profile_work_counters, like the backward's): the same kernel also adds up, per
 // wave, its staged groups, hits, walk steps and the lanes of a hit that hold a blendable (pixel, Gaussian) pair — the inputs of
 // the forward's VALU-issue model in bench.py (counters[8 ..]).  The shipped launches use COUNT = false: no counters exist.
-template <int FWD_TILES, bool COUNT = false>
+// TRAIN = false: the render-only instantiation (mi355gs_raster_forward_render_only: every no-grad render — evaluation, the FPS
+// loop, reference render.py:87,137,177 under torch.no_grad()).  Nothing is left for a backward that will not come: no unit
+// table, no 16 B/pixel boundary record per 64-instance unit, no hit masks, no quadrant maxima (51 MB of stores per 512^2 frame
+// at C3 against 5 MB of image and per-pixel state, profiles/r04_pmc_c3_WRITE_SIZE.csv), and none of their address arithmetic.
+// The image, final_T and n_contrib are bit-identical to the training instantiation's: the walk is the same code.
+template <int FWD_TILES, bool COUNT = false, bool TRAIN = true>
 __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx, int W, int H, uint32_t capacity, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ list, const GsRec* __restrict__ recs,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
   const int pos = (j & 1) ? (j + 1) * nwg - 1 - (int)blockIdx.x : j * nwg + (int)blockIdx.x;
   if (pos >= T) return;   // (tile count not a multiple of FWD_TILES; no workgroup barrier below)
   const int tile = (int)order[pos];
-  const uint32_t seg_len = meta[2] * GS_SEG;    // instances per backward unit of this frame (k_scan_tiles)
+  const uint32_t seg_len = TRAIN ? meta[2] * GS_SEG : 0u;    // instances per backward unit of this frame (k_scan_tiles)
   float4 (*__restrict__ recl)[3] = s_rec[wave_wg];
   const Quad q = make_quad(tile, gx, W, H);
   const uint32_t start = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
@@ -176,12 +181,12 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
   [[maybe_unused]] unsigned long long pr_hits = 0, pr_groups = 0, pr_walk = 0;
   // Backward units of this tile (segments of seg_len instances, see common.h): publish them, and leave every pixel's
   // (transmittance after the last blended Gaussian, accumulated colour) at each segment boundary for the backward.
-  const uint32_t seg0 = seg_first[tile], nseg = seg_first[tile + 1] - seg0;
+  const uint32_t seg0 = TRAIN ? seg_first[tile] : 0u, nseg = TRAIN ? seg_first[tile + 1] - seg0 : 0u;
   // The table is written in the backward's LAUNCH order: every full-length unit of the frame first (tile by tile), then the
   // tiles' short last units.  The hardware hands out workgroups in index order, so the units that start last are the short ones
   // and the kernel's tail — the stretch where the SIMDs run out of waves — is made of half-length work.  A unit's boundary
   // record stays at its slot seg_first[tile] + segment; the entry carries it.
-  {
+  if constexpr (TRAIN) {
     const uint32_t p0 = part_first[tile], n_full = nseg - (part_first[tile + 1] - p0);
     const uint32_t full0 = seg0 - p0, all_full = meta[1] - meta[3];
     for (uint32_t sg = tid; sg < nseg; sg += 256) {
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
         unit_tile[pos] = make_uint4((uint32_t)(tile % gx) | ((uint32_t)(tile / gx) << 16), sg, seg0 + sg, 0u);
     }
   }
-  uint32_t next_boundary = 0;  // boundaries [0, next_boundary) of this tile have been stored by this wave
+  [[maybe_unused]] uint32_t next_boundary = 0;  // boundaries [0, next_boundary) of this tile have been stored by this wave
 
   // Tr: live transmittance while the pixel is still blending; once it is finished (T < 1e-4 would be reached) it holds MINUS
   // the transmittance after the last blended Gaussian, so |Tr| is always the value the reference stores as final_T and the
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
     __builtin_amdgcn_wave_barrier();
     const bool hit = lane < cnt && quad_hit(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r1[0], r1[1], r1[2], r1[3]), q);
     unsigned long long mask = __ballot(hit);
-    {
+    if constexpr (TRAIN) {
       // the backward's cull of this chunk for this quadrant, done: chunk index = first unit of the tile * chunks per unit + group
       const uint32_t chunk = seg0 * meta[2] + (base - start) / GS_SEG;
       if (lane == 0 && chunk < max_chunks) hitmask[(size_t)chunk * 4 + wave] = mask;
@@ -234,9 +239,11 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
     // the boundary in front of this group (the state after `base - start` instances) is stored here, not behind the walk
     // that produced it: the wait for the next group's records at the top of the loop also covers every older memory
     // operation, and a store issued just before it would be waited for at its full latency
-    if (base != start && (base - start) % seg_len == 0u) {
-      next_boundary = (base - start) / seg_len;
-      if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
+    if constexpr (TRAIN) {
+      if (base != start && (base - start) % seg_len == 0u) {
+        next_boundary = (base - start) / seg_len;
+        if (seg0 + next_boundary - 1u < max_units) bstate[(size_t)(seg0 + next_boundary - 1u) * 256 + tid] = make_float4(fabsf(Tr), C0, C1, C2);
+      }
     }
 #ifdef GS_PROBE
     pr_hits += __popcll(mask); pr_groups += 1;
@@ -294,9 +301,10 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
   }
   // boundaries this wave never reached (all its pixels were finished, or the tile ended): the state no longer changes
   const float Tfin = fabsf(Tr);
-  for (uint32_t sg = next_boundary; sg + 1u < nseg; ++sg)
-    if (seg0 + sg < max_units) bstate[(size_t)(seg0 + sg) * 256 + tid] = make_float4(Tfin, C0, C1, C2);
-  {
+  if constexpr (TRAIN)
+    for (uint32_t sg = next_boundary; sg + 1u < nseg; ++sg)
+      if (seg0 + sg < max_units) bstate[(size_t)(seg0 + sg) * 256 + tid] = make_float4(Tfin, C0, C1, C2);
+  if constexpr (TRAIN) {
     // the quadrant's largest contributor count: every backward unit of the tile needs it, and computed there it is a wave
     // reduction per unit and quadrant (4 x 11 k per C3 frame) instead of one per forward wave
     const uint32_t wmax = gs_wave_max_u32(last);
@@ -731,7 +739,7 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
                             const uint32_t* list, const GsRec* recs, const float* bg, float* out_color, float* final_T,
                             uint32_t* n_contrib, const uint32_t* order, const uint32_t* seg_first, const uint32_t* part_first,
                             uint4* unit_tile, float4* bstate, uint32_t max_units, const uint32_t* meta, unsigned long long* hitmask,
-                            uint32_t max_chunks, uint32_t* qmax, unsigned long long* counters) {
+                            uint32_t max_chunks, uint32_t* qmax, unsigned long long* counters, bool train) {
   // equal-weight workgroups of 4 (2) tiles while the whole frame is one resident round of at most one (two) workgroups per CU
   // (the count belongs to the device the launch goes to — the process's current one — not to whichever device was current
   // the first time: a process that drives two different GPUs gets each one's own; a device attribute read is host-only and cheap,
@@ -751,11 +759,12 @@ int gs_launch_composite_fwd(hipStream_t stream, int T, int gx, int W, int H, uin
 #ifndef GS_FWD_LDS_PAD
 #define GS_FWD_LDS_PAD 0
 #endif
-#define GS_FWD(N, CNT)                                                                                                              \
-  hipLaunchKernelGGL((k_composite_fwd<N, CNT>), dim3((T + N - 1) / N), dim3(256 * N), GS_FWD_LDS_PAD, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, \
+#define GS_FWD(N, CNT, TRN)                                                                                                         \
+  hipLaunchKernelGGL((k_composite_fwd<N, CNT, TRN>), dim3((T + N - 1) / N), dim3(256 * N), GS_FWD_LDS_PAD, stream, T, gx, W, H, capacity, tile_start, list, recs, bg, \
                      out_color, final_T, n_contrib, order, seg_first, part_first, unit_tile, bstate, max_units, meta, hitmask, max_chunks, qmax, counters)
-  if (counters) { if (per_wg == 4) GS_FWD(4, true); else if (per_wg == 2) GS_FWD(2, true); else GS_FWD(1, true); }
-  else { if (per_wg == 4) GS_FWD(4, false); else if (per_wg == 2) GS_FWD(2, false); else GS_FWD(1, false); }
+  if (!train) { if (per_wg == 4) GS_FWD(4, false, false); else if (per_wg == 2) GS_FWD(2, false, false); else GS_FWD(1, false, false); }
+  else if (counters) { if (per_wg == 4) GS_FWD(4, true, true); else if (per_wg == 2) GS_FWD(2, true, true); else GS_FWD(1, true, true); }
+  else { if (per_wg == 4) GS_FWD(4, false, true); else if (per_wg == 2) GS_FWD(2, false, true); else GS_FWD(1, false, true); }
 #undef GS_FWD
   return 0;
 }

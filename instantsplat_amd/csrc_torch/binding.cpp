@@ -39,6 +39,8 @@ struct Abi {
   decltype(&mi355gs_raster_forward_preprocess) forward_preprocess = nullptr;
   decltype(&mi355gs_raster_backward) raster_backward = nullptr;
   decltype(&mi355gs_raster_forward_render) forward_render = nullptr;
+  decltype(&mi355gs_raster_binning_bytes_render_only) binning_bytes_render_only = nullptr;
+  decltype(&mi355gs_raster_forward_render_only) forward_render_only = nullptr;
   decltype(&mi355gs_posed_backward) posed_backward = nullptr;
   decltype(&mi355gs_ssim_scratch_bytes) ssim_scratch_bytes = nullptr;
   decltype(&mi355gs_l1_ssim_loss_fused) l1_ssim_loss_fused = nullptr;
@@ -70,6 +72,8 @@ void bind_abi(const std::map<std::string, uintptr_t>& sym, bool allow_cpu_tensor
   GS_BIND(forward_preprocess, mi355gs_raster_forward_preprocess);
   GS_BIND(raster_backward, mi355gs_raster_backward);
   GS_BIND(forward_render, mi355gs_raster_forward_render);
+  GS_BIND(binning_bytes_render_only, mi355gs_raster_binning_bytes_render_only);
+  GS_BIND(forward_render_only, mi355gs_raster_forward_render_only);
   GS_BIND(posed_backward, mi355gs_posed_backward);
   GS_BIND(ssim_scratch_bytes, mi355gs_ssim_scratch_bytes);
   GS_BIND(l1_ssim_loss_fused, mi355gs_l1_ssim_loss_fused);
@@ -201,9 +205,10 @@ template <class... T> bool any_requires_grad(const T&... t) {
 // ... asked where the operator is CALLED: inside a custom function's forward() grad mode is off, so the question would always be
 // answered "no" there (round 4 shipped it that way for a while: the backward's memset stayed, profiles/r04_dropin_aten_ops.txt)
 thread_local bool t_backward_follows = false;
+bool g_render_only_when_no_grad = true;   // A/B switch (render_only): false = every forward runs the training instantiation of stage 2
 bool g_forward_owns_scratch = true;   // A/B switch (forward_owns_scratch): false = the backward allocates and memsets, as before ABI v7
 struct BackwardFollows {
-  explicit BackwardFollows(bool v) { t_backward_follows = v && g_forward_owns_scratch; }
+  explicit BackwardFollows(bool v) { t_backward_follows = v; }
   ~BackwardFollows() { t_backward_follows = false; }
 };
 
@@ -328,7 +333,7 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     Tensor geom = empty_bytes(g_abi.geom_bytes(P), xyz), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), xyz);
     // a backward will follow: its accumulator buffer is allocated now and cleared by the projection kernel on its way
     Tensor scratch;
-    if (t_backward_follows) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
+    if (t_backward_follows && g_forward_owns_scratch) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
     int32_t* count = count_slot.data_ptr<int32_t>();  // pinned host memory the tile-scan kernel stores into (a CPU word under emulation)
     auto preprocess = [&]() {
       *reinterpret_cast<volatile int32_t*>(count) = -1;   // "not written yet" for wait_for_count
@@ -340,11 +345,21 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
             "posed_forward_preprocess");
     };
     Tensor binning;
+    // no backward will follow (nothing requires a gradient, or grad mode is off where the operator was called): the render-only
+    // stage 2 — a binning buffer of keys + lists only, no boundary records / hit masks / unit table left for a backward
+    const bool train = t_backward_follows || !g_render_only_when_no_grad;
     auto stage2 = [&](int64_t cap) {
-      binning = empty_bytes(g_abi.binning_bytes(cap, (int)W, (int)H), xyz);
-      check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(),
-                                 fp(color), 0),
-            "raster_forward_render");
+      if (train) {
+        binning = empty_bytes(g_abi.binning_bytes(cap, (int)W, (int)H), xyz);
+        check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(),
+                                   fp(color), 0),
+              "raster_forward_render");
+      } else {
+        binning = empty_bytes(g_abi.binning_bytes_render_only(cap, (int)W, (int)H), xyz);
+        check(g_abi.forward_render_only(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(),
+                                        fp(color), 0),
+              "raster_forward_render_only");
+      }
     };
     preprocess();
     int64_t R = capacity;
@@ -493,7 +508,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     Tensor color = at::empty({3, H, W}, means3D.options());
     Tensor geom = empty_bytes(g_abi.geom_bytes(P), means3D), tiles = empty_bytes(g_abi.tiles_bytes((int)W, (int)H), means3D);
     Tensor scratch;   // see RenderPosedFn::forward
-    if (t_backward_follows) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
+    if (t_backward_follows && g_forward_owns_scratch) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
     int32_t* count = count_slot.data_ptr<int32_t>();
     auto preprocess = [&]() {
       *reinterpret_cast<volatile int32_t*>(count) = -1;
@@ -504,10 +519,18 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             "raster_forward_preprocess");
     };
     Tensor binning;
+    const bool train = t_backward_follows || !g_render_only_when_no_grad;   // see RenderPosedFn::forward
     auto stage2 = [&](int64_t cap) {
-      binning = empty_bytes(g_abi.binning_bytes(cap, (int)W, (int)H), means3D);
-      check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(), fp(color), 0),
-            "raster_forward_render");
+      if (train) {
+        binning = empty_bytes(g_abi.binning_bytes(cap, (int)W, (int)H), means3D);
+        check(g_abi.forward_render(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(), fp(color), 0),
+              "raster_forward_render");
+      } else {
+        binning = empty_bytes(g_abi.binning_bytes_render_only(cap, (int)W, (int)H), means3D);
+        check(g_abi.forward_render_only(dev.stream, P, (int)W, (int)H, cap, fp(bg), geom.data_ptr(), tiles.data_ptr(), binning.data_ptr(),
+                                        fp(color), 0),
+              "raster_forward_render_only");
+      }
     };
     preprocess();
     int64_t R = capacity;
@@ -827,6 +850,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("render_posed", &render_posed);
   m.def("forward_owns_scratch", [](bool on) { const bool was = g_forward_owns_scratch; g_forward_owns_scratch = on; return was; },
         "A/B switch: true (default) = a forward that a backward will follow allocates the backward's accumulators and has the projection kernel clear them");
+  m.def("render_only", [](bool on) { const bool was = g_render_only_when_no_grad; g_render_only_when_no_grad = on; return was; },
+        "A/B switch: true (default) = a forward no backward can follow takes the render-only stage 2 (mi355gs_raster_forward_render_only)");
   m.def("wait_for_words", &wait_for_words, "spin (GIL released) until no element of an int32 pinned host tensor holds the sentinel; stream wait after timeout_us");
   m.def("pose_row", &pose_row, "GaussianModel.get_RT: row `index` of the [views, 7] pose table as a node the render node's backward cooperates with");
   m.def("rasterize", &rasterize);

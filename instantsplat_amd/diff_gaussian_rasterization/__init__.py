@@ -164,10 +164,30 @@ class binning_hint:
         BinningPolicy.current_key, BinningPolicy.current_tag = self.prev
 
 
+RENDER_ONLY_WHEN_NO_GRAD = True   # A/B switch of this (ctypes) binding; the compiled one has ext.render_only(bool)
+_BACKWARD_FOLLOWS = [True]        # set by the callers of the Python nodes around apply(): inside forward() grad mode is off
+
+
+class backward_follows:
+    """with backward_follows(flag): the forward(s) inside know whether a backward can follow them — asked where the operator is
+    CALLED (grad mode on and an input requiring a gradient).  flag False selects the render-only stage 2."""
+
+    def __init__(self, *tensors):
+        self.flag = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+    def __enter__(self):
+        self.prev = _BACKWARD_FOLLOWS[0]
+        _BACKWARD_FOLLOWS[0] = self.flag
+
+    def __exit__(self, *a):
+        _BACKWARD_FOLLOWS[0] = self.prev
+
+
 def size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, color, debug):
     """Stage 2 of the forward for both bindings (operator-level and posed): size the instance buffers according to the
     BinningPolicy — the reference operator's own blocking 4-byte read-back, or a verified bound with no host sync — allocate
-    them and enqueue binning + composite.  Returns (capacity handed to the library, binning scratch)."""
+    them and enqueue binning + composite.  Returns (capacity handed to the library, binning scratch).  A frame no backward
+    can follow (`backward_follows`) takes the render-only stage 2: a binning buffer of keys + lists only."""
     key = BinningPolicy.current_key
     on_gpu = dev.type == "cuda"   # then `num_rendered` is a slot of pinned host memory the tile-scan kernel stores into (count_slot)
     R = BinningPolicy.deferred_capacity()
@@ -181,9 +201,14 @@ def size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, colo
         R = int(num_rendered[0])
         if key is not None:
             BinningPolicy.known[key] = R
-    binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R, W, H), dev)
-    _lib.check(L.mi355gs_raster_forward_render(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
-                                               _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render")
+    if _BACKWARD_FOLLOWS[0] or not RENDER_ONLY_WHEN_NO_GRAD:
+        binning = _empty_bytes(L.mi355gs_raster_binning_bytes(R, W, H), dev)
+        _lib.check(L.mi355gs_raster_forward_render(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
+                                                   _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render")
+    else:
+        binning = _empty_bytes(L.mi355gs_raster_binning_bytes_render_only(R, W, H), dev)
+        _lib.check(L.mi355gs_raster_forward_render_only(stream, P, W, H, R, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(tiles),
+                                                        _lib.ptr(binning), _lib.ptr(color), debug), "raster_forward_render_only")
     return R, binning
 
 
@@ -396,8 +421,9 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     s = raster_settings
     ext = None if (s.debug or _KEEP_LAST_FRAME) else _lib.compiled()
     if ext is None:   # the ctypes / Python autograd.Function binding (also: the operator's debug mode with its snapshot dumps)
-        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                         raster_settings, sh_rest)
+        with backward_follows(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest):
+            return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                             raster_settings, sh_rest)
     # the compiled node (csrc_torch/binding.cpp::RasterizeFn): the same three C-ABI calls, with size_and_render's bookkeeping here
     opt = lambda t: None if (t is None or t.numel() == 0) else t
     dev = means3D.device

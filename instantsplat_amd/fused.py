@@ -171,8 +171,9 @@ def render_posed(pc, pose, means2D, settings):
     s = settings
     ext = None if (s.debug or dgr._KEEP_LAST_FRAME) else _lib.compiled()
     if ext is None:
-        return _RenderPosed.apply(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
-                                  settings)
+        with dgr.backward_follows(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D):
+            return _RenderPosed.apply(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest, pose, means2D,
+                                      settings)
     return render_posed_compiled(ext, pc, pose, means2D, s.bg, s.viewmatrix, s.projmatrix, s.campos, int(s.image_height),
                                  int(s.image_width), float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), int(s.sh_degree))[:2]
 

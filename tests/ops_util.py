@@ -1378,3 +1378,78 @@ def check_loss_utils_against_the_references_own(dev):
     bound("loss_utils/ssim_mask_11", abs(float(loss_utils.ssim_loss_mask(x, y, mask)) - float(G["ssim_mask_11"])), 2e-6 if cuda else 1e-6)
     bound("loss_utils/ssim_mask_7_per_image", float((loss_utils.ssim_loss_mask(x, y, mask, window_size=7, size_average=False).cpu()
                                                        - torch.from_numpy(G["ssim_mask_7_per_image"])).abs().max()), 2e-6)
+
+
+def check_render_only_forward(dev, Wm=20, W=80, H=48):
+    """A render no backward can follow (torch.no_grad(), or nothing requiring a gradient) takes the render-only stage 2
+    (mi355gs_raster_forward_render_only: keys + lists only in `binning`, no boundary records / hit masks / unit table / quadrant
+    maxima stored).  Image, radii and the per-pixel state (final_T, n_contrib -> frame statistics) must be bit-identical to the
+    training instantiation's — through render() on both bindings, through the operator, and with the switch off."""
+    import instantsplat_amd.diff_gaussian_rasterization as dgr
+    from instantsplat_amd import _lib
+    from instantsplat_amd.gaussian_renderer import render
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import setup_training
+    from tests.util import run_blob_case
+    L = _lib.lib()
+    sc = syn_pointmap(3, Wm, Wm, W, H, seed=9)
+    st = generic_start(setup_training(sc, dev))
+    g, cam = st.gaussians, st.cameras[1]
+    pose = g.get_RT(cam.uid)
+
+    def frame(no_grad):
+        """render() through the Python node with the frame's buffers kept: image, radii, stats, binning bytes"""
+        dgr.keep_last_frame(True)
+        try:
+            if no_grad:
+                with torch.no_grad():
+                    pkg = render(cam, g, st.pipe, st.background, camera_pose=pose)
+            else:
+                pkg = render(cam, g, st.pipe, st.background, camera_pose=pose)
+            stats = dgr.last_frame_stats()
+            lf = dgr._LAST_FRAME
+            return (pkg["render"].detach().cpu().clone(), pkg["radii"].cpu().clone(), stats, int(lf["binning"].numel()), int(lf["capacity"]),
+                    lf["tiles"].cpu().clone())
+        finally:
+            dgr.keep_last_frame(False)
+
+    img_t, rad_t, stats_t, bytes_t, cap_t, tiles_t = frame(no_grad=False)
+    img_r, rad_r, stats_r, bytes_r, cap_r, tiles_r = frame(no_grad=True)
+    assert cap_t == cap_r and stats_t == stats_r and stats_t[0] > 0
+    assert bytes_t == int(L.mi355gs_raster_binning_bytes(cap_t, W, H))
+    assert bytes_r == max(int(L.mi355gs_raster_binning_bytes_render_only(cap_r, W, H)), 1) < bytes_t
+    assert torch.equal(img_t, img_r) and torch.equal(rad_t, rad_r)
+    # the per-pixel state the two instantiations share (final_T, n_contrib: include/mi355gs.h `tiles`) — the words in front of
+    # the backward-only tables are the same bits
+    npix_words = W * H
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    al = lambda n: (n + 255) // 256 * 256
+    off_final_T = 2 * al(nt * 4) + al((nt + 1) * 4)   # behind count, cursor and start (csrc/common.h TilesLayout)
+    a = tiles_t[off_final_T: off_final_T + 8 * npix_words]
+    b = tiles_r[off_final_T: off_final_T + 8 * npix_words]
+    assert torch.equal(a, b)
+    # render() on the compiled binding, the switch on and off, under no_grad and with requires_grad inputs
+    ext = _lib.compiled()
+    if ext is not None:
+        with torch.no_grad():
+            i1 = render(cam, g, st.pipe, st.background, camera_pose=pose)["render"].cpu()
+            was = ext.render_only(False)
+            try:
+                i2 = render(cam, g, st.pipe, st.background, camera_pose=pose)["render"].cpu()
+            finally:
+                ext.render_only(was)
+        i3 = render(cam, g, st.pipe, st.background, camera_pose=pose)["render"].detach().cpu()
+        assert torch.equal(i1, img_t) and torch.equal(i2, img_t) and torch.equal(i3, img_t)
+    # a training render right after a render-only one of the same view still gives the gradients of the training path
+    for t in (g._xyz, g._opacity, g.P):
+        t.grad = None
+    with torch.no_grad():
+        render(cam, g, st.pipe, st.background, camera_pose=pose)
+    pkg = render(cam, g, st.pipe, st.background, camera_pose=g.get_RT(cam.uid))
+    (pkg["render"] * st.gt_images[cam.uid]).sum().backward()
+    assert float(g._xyz.grad.abs().max()) > 0 and float(g.P.grad.abs().max()) > 0
+    # the operator (all-in-camera-frame inputs): no_grad forward == the forward of a differentiated call
+    res = run_blob_case(dev, 600, 80, 48, 2)["dut"]
+    with torch.no_grad():
+        res_ng = run_blob_case(dev, 600, 80, 48, 2, backward=False)["dut"]
+    assert torch.equal(res["color"], res_ng["color"]) and torch.equal(res["radii"], res_ng["radii"])

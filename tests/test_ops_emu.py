@@ -260,3 +260,7 @@ def test_new_entry_points_reject_bad_arguments():
                                         p, p, p, rows, row, 0, 0)
     assert posed_backward(-1, 0) == EINVAL and posed_backward(3, 3) == EINVAL and posed_backward(3, -1) == EINVAL
     assert L.mi355gs_error_string(EINVAL)
+
+
+def test_render_only_forward_is_bit_identical(emu):
+    ops_util.check_render_only_forward(emu)

@@ -155,3 +155,11 @@ def test_l1_loss_at_1080p_equals_the_references_expression(gpu):
     (r * 0.8).backward()
     assert abs(float(v) - float(r)) <= 1e-6 * float(r), (float(v), float(r))
     assert torch.equal(mine, a.grad)
+
+
+def test_render_only_forward_is_bit_identical(gpu):
+    ops_util.check_render_only_forward(gpu)
+
+
+def test_render_only_forward_at_bench_size(gpu):
+    ops_util.check_render_only_forward(gpu, Wm=128, W=512, H=512)
