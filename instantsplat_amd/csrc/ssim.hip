@@ -515,6 +515,66 @@ __global__ __launch_bounds__(256) void k_l1_bwd(long long n, const float* __rest
   }
 }
 
+// ---- the reference's loss EXPRESSION as written (train.py:171-176): l1_loss(image, gt), fused_ssim(image, gt) and scalar
+// arithmetic between two 0-dim tensors.  mi355gs_l1_ssim_pair_forward leaves both means and d(ssim_mean)/dimg1 from the one
+// pass of k_l1_ssim_fused (ks = 1/N, kl = 0); the scalar arithmetic the host has recorded is evaluated by k_loss_program, and
+// the backward of the whole expression is ONE launch of k_loss_pair_bwd over the image:
+//   d_img1 = (gl * c_l1 / n) * sgn(a - b) + (gs * c_ssim) * dssim      (gl, gs: incoming gradients, device scalars or 1)
+// in autograd's own operation order for abs(a - b).mean() and for a scaled saved gradient.
+struct GsLossProgram {
+  int n;
+  signed char op[MI355GS_LOSS_PROGRAM_MAX];
+  float k[MI355GS_LOSS_PROGRAM_MAX];
+};
+
+__global__ __launch_bounds__(64) void k_loss_program(GsLossProgram p, const float* __restrict__ l1_mean, const float* __restrict__ ssim_mean,
+                                                    float* __restrict__ out) {
+#pragma clang fp contract(off)   // one rounding per recorded operation, as eager PyTorch's elementwise kernels
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float st[MI355GS_LOSS_PROGRAM_MAX];
+  int sp = 0;
+  for (int i = 0; i < p.n; ++i) {
+    const float k = p.k[i];
+    switch (p.op[i]) {
+      case MI355GS_LOSS_OP_L1: st[sp++] = *l1_mean; break;
+      case MI355GS_LOSS_OP_SSIM: st[sp++] = *ssim_mean; break;
+      case MI355GS_LOSS_OP_MULK: st[sp - 1] = st[sp - 1] * k; break;
+      case MI355GS_LOSS_OP_ADDK: st[sp - 1] = st[sp - 1] + k; break;
+      case MI355GS_LOSS_OP_RSUBK: st[sp - 1] = k - st[sp - 1]; break;
+      case MI355GS_LOSS_OP_DIVK: st[sp - 1] = st[sp - 1] * (1.0f / k); break;   // a tensor divided by a host scalar: x * (1 / k), as ATen's kernel
+      case MI355GS_LOSS_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
+      case MI355GS_LOSS_OP_ADD: st[sp - 2] = st[sp - 2] + st[sp - 1]; --sp; break;
+      case MI355GS_LOSS_OP_SUB: st[sp - 2] = st[sp - 2] - st[sp - 1]; --sp; break;
+      default: break;
+    }
+  }
+  *out = sp > 0 ? st[sp - 1] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_loss_pair_bwd(long long n, const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ dssim, const float* __restrict__ g_l1, float c_l1,
+                                                       const float* __restrict__ g_ssim, float c_ssim, float n_as_float,
+                                                       float* __restrict__ d_a) {
+#pragma clang fp contract(off)
+  const float sl = ((g_l1 ? *g_l1 : 1.0f) * c_l1) / n_as_float;
+  const float ss = (g_ssim ? *g_ssim : 1.0f) * c_ssim;
+  const bool use_l1 = c_l1 != 0.0f, use_ss = c_ssim != 0.0f && dssim != nullptr;   // (a term that was never asked for adds no 0 * inf)
+  auto one = [&](float x, float y, float ds) {
+    const float d = x - y;
+    const float tl = use_l1 ? (d > 0.f ? sl : (d < 0.f ? -sl : 0.f)) : 0.f;
+    return use_ss ? tl + ss * ds : tl;
+  };
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)d_a | (uintptr_t)(use_ss ? dssim : a);
+  if (((al & 15) == 0) && i0 + 4 <= n) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i0 >> 2], y = reinterpret_cast<const float4*>(b)[i0 >> 2];
+    const float4 s = use_ss ? reinterpret_cast<const float4*>(dssim)[i0 >> 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(d_a)[i0 >> 2] = make_float4(one(x.x, y.x, s.x), one(x.y, y.y, s.y), one(x.z, y.z, s.z), one(x.w, y.w, s.w));
+  } else {
+    for (long long i = i0; i < min(n, i0 + 4); ++i) d_a[i] = one(a[i], b[i], use_ss ? dssim[i] : 0.f);
+  }
+}
+
 }  // namespace
 
 static inline int l1_nblocks(long long n) { return (int)((n + L1_THREADS * L1_PER_THREAD - 1) / (L1_THREADS * L1_PER_THREAD)); }
@@ -609,6 +669,58 @@ int mi355gs_l1_ssim_loss_fused(void* stream_, int B, int C, int H, int W, const 
   hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, fused_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
                      l1_mean, loss, lambda_dssim);
   GS_CHECK_LAUNCH("ssim_finish");
+  return MI355GS_OK;
+}
+
+int mi355gs_l1_ssim_pair_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
+                                 float* ssim_mean, float* l1_mean, float* dssim_dimg1) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !ssim_mean || !l1_mean || !dssim_dimg1) return MI355GS_EINVAL;
+  if ((size_t)B * C > 65535) return MI355GS_EINVAL;
+  const double inv_n = 1.0 / ((double)B * C * H * W);
+  const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, B * C);
+  hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)inv_n, 0.0f, dssim_dimg1, (float*)scratch);
+  GS_CHECK_LAUNCH("l1_ssim_pair");
+  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, fused_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
+                     l1_mean, (float*)nullptr, 0.f);
+  GS_CHECK_LAUNCH("ssim_finish");
+  return MI355GS_OK;
+}
+
+int mi355gs_l1_ssim_pair_backward(void* stream_, int64_t n, const float* img1, const float* img2, const float* dssim_dimg1,
+                                  const float* g_l1, float c_l1, const float* g_ssim, float c_ssim, float* d_img1) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (n <= 0 || n > (int64_t)1 << 40 || !img1 || !img2 || !d_img1) return MI355GS_EINVAL;
+  if (c_ssim != 0.0f && !dssim_dimg1) return MI355GS_EINVAL;
+  hipLaunchKernelGGL(k_loss_pair_bwd, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, (long long)n, img1, img2, dssim_dimg1, g_l1,
+                     c_l1, g_ssim, c_ssim, (float)n, d_img1);
+  GS_CHECK_LAUNCH("loss_pair_bwd");
+  return MI355GS_OK;
+}
+
+int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, const float* consts, const float* l1_mean,
+                              const float* ssim_mean, float* out) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (n_ops <= 0 || n_ops > MI355GS_LOSS_PROGRAM_MAX || !ops || !consts || !l1_mean || !ssim_mean || !out) return MI355GS_EINVAL;
+  GsLossProgram p;
+  p.n = n_ops;
+  int depth = 0;   // a malformed program (stack underflow, two values left) is refused here, not executed
+  for (int i = 0; i < MI355GS_LOSS_PROGRAM_MAX; ++i) {
+    p.op[i] = 0; p.k[i] = 0.f;
+    if (i >= n_ops) continue;
+    const int op = ops[i];
+    if (op == MI355GS_LOSS_OP_L1 || op == MI355GS_LOSS_OP_SSIM) ++depth;
+    else if (op == MI355GS_LOSS_OP_ADD || op == MI355GS_LOSS_OP_SUB) { if (depth < 2) return MI355GS_EINVAL; --depth; }
+    else if (op >= MI355GS_LOSS_OP_MULK && op <= MI355GS_LOSS_OP_NEG) { if (depth < 1) return MI355GS_EINVAL; }
+    else return MI355GS_EINVAL;
+    p.op[i] = (signed char)op; p.k[i] = consts[i];
+  }
+  if (depth != 1) return MI355GS_EINVAL;
+  hipLaunchKernelGGL(k_loss_program, dim3(1), dim3(64), 0, stream, p, l1_mean, ssim_mean, out);
+  GS_CHECK_LAUNCH("loss_program");
   return MI355GS_OK;
 }
 

@@ -47,6 +47,9 @@ struct Abi {
   decltype(&mi355gs_l1_scratch_bytes) l1_scratch_bytes = nullptr;
   decltype(&mi355gs_l1_loss_forward) l1_loss_forward = nullptr;
   decltype(&mi355gs_l1_loss_backward) l1_loss_backward = nullptr;
+  decltype(&mi355gs_l1_ssim_pair_forward) pair_forward = nullptr;
+  decltype(&mi355gs_l1_ssim_pair_backward) pair_backward = nullptr;
+  decltype(&mi355gs_loss_program_eval) program_eval = nullptr;
   decltype(&mi355gs_ssim_forward) ssim_forward = nullptr;
   decltype(&mi355gs_ssim_backward) ssim_backward = nullptr;
   decltype(&mi355gs_adam_multi_step) adam_multi_step = nullptr;
@@ -80,6 +83,9 @@ void bind_abi(const std::map<std::string, uintptr_t>& sym, bool allow_cpu_tensor
   GS_BIND(l1_scratch_bytes, mi355gs_l1_scratch_bytes);
   GS_BIND(l1_loss_forward, mi355gs_l1_loss_forward);
   GS_BIND(l1_loss_backward, mi355gs_l1_loss_backward);
+  GS_BIND(pair_forward, mi355gs_l1_ssim_pair_forward);
+  GS_BIND(pair_backward, mi355gs_l1_ssim_pair_backward);
+  GS_BIND(program_eval, mi355gs_loss_program_eval);
   GS_BIND(ssim_forward, mi355gs_ssim_forward);
   GS_BIND(ssim_backward, mi355gs_ssim_backward);
   GS_BIND(adam_multi_step, mi355gs_adam_multi_step);
@@ -670,6 +676,65 @@ struct L1LossFn : public torch::autograd::Function<L1LossFn> {
 Tensor l1_loss(Tensor a, Tensor b) { return L1LossFn::apply(a, b); }
 
 // ------------------------------------------------------------------------------------------------
+// The reference's loss expression AS WRITTEN (train.py:171-176): l1_loss(image, gt), fused_ssim(image[None], gt[None]) and four
+// scalar operations between 0-dim tensors, then loss.backward().  instantsplat_amd/loss_utils.py serves that text with these two
+// functions: loss_pair_forward when l1_loss is called (both means and d(ssim_mean)/dimg1 from ONE pass; no autograd node — the
+// values are wrapped in lazy scalars on the Python side, which record the arithmetic), and loss_affine when the recorded
+// expression is needed as a tensor (backward(), item(), anything else): one node on `image`, one launch forward (the program),
+// one launch backward over the image.
+// ------------------------------------------------------------------------------------------------
+std::vector<Tensor> loss_pair_forward(Tensor img1, Tensor img2) {
+  TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+  HostClock clock(&g_host_us[2]);
+  const Tensor a = f32c(img1, "img1", img1), b = f32c(img2, "img2", a);
+  TORCH_CHECK((a.dim() == 3 || a.dim() == 4) && a.sizes() == b.sizes() && a.numel() > 0, "the loss pair expects two [C,H,W] or [B,C,H,W] tensors of equal shape");
+  const int64_t o = a.dim() == 4 ? 1 : 0;
+  const int B = o ? (int)a.size(0) : 1, C = (int)a.size(o), H = (int)a.size(o + 1), W = (int)a.size(o + 2);
+  const DeviceScope dev(a);
+  Tensor scratch = empty_bytes(g_abi.ssim_scratch_bytes(B, C, H, W), a);
+  Tensor l1 = at::empty({}, a.options()), ssim = at::empty({}, a.options());
+  Tensor dmap = at::empty_like(a);
+  check(g_abi.pair_forward(dev.stream, B, C, H, W, fp(a), fp(b), scratch.data_ptr(), fp(ssim), fp(l1), fp(dmap)), "l1_ssim_pair_forward");
+  return {l1, ssim, dmap, a, b};
+}
+
+struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
+  // image: the tensor the caller differentiates (what was handed to l1_loss); a / b / dmap / l1 / ssim: loss_pair_forward's results
+  static Tensor forward(AutogradContext* ctx, Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor l1, Tensor ssim,
+                        std::vector<int64_t> ops, std::vector<double> consts, double c_l1, double c_ssim) {
+    TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    TORCH_CHECK(ops.size() == consts.size() && !ops.empty() && ops.size() <= MI355GS_LOSS_PROGRAM_MAX, "loss_affine: 1..16 operations");
+    TORCH_CHECK(image.numel() == a.numel(), "loss_affine: image and its contiguous copy differ in size");
+    const DeviceScope dev(a);
+    int32_t op32[MI355GS_LOSS_PROGRAM_MAX]; float k32[MI355GS_LOSS_PROGRAM_MAX];
+    for (size_t i = 0; i < ops.size(); ++i) { op32[i] = (int32_t)ops[i]; k32[i] = (float)consts[i]; }
+    Tensor out = at::empty({}, a.options());
+    check(g_abi.program_eval(dev.stream, (int)ops.size(), op32, k32, fp(l1), fp(ssim), fp(out)), "loss_program_eval");
+    ctx->save_for_backward({a, b, dmap});
+    ctx->saved_data["c"] = std::vector<double>{c_l1, c_ssim};
+    ctx->saved_data["shape"] = image.sizes().vec();
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
+    HostClock clock(&g_host_us[3]);
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &a = saved[0], &b = saved[1], &dmap = saved[2];
+    const auto c = ctx->saved_data["c"].toDoubleVector();
+    const Tensor g = f32c(grad_out[0].reshape({1}), "grad", a);
+    const DeviceScope dev(a);
+    Tensor d = at::empty_like(a);
+    check(g_abi.pair_backward(dev.stream, a.numel(), fp(a), fp(b), fp(dmap), fp(g), (float)c[0], fp(g), (float)c[1], fp(d)), "l1_ssim_pair_backward");
+    Tensor none;
+    return {d.view(ctx->saved_data["shape"].toIntVector()), none, none, none, none, none, none, none, none, none};
+  }
+};
+
+Tensor loss_affine(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor l1, Tensor ssim, std::vector<int64_t> ops,
+                   std::vector<double> consts, double c_l1, double c_ssim) {
+  return LossAffineFn::apply(image, a, b, dmap, l1, ssim, ops, consts, c_l1, c_ssim);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused_ssim(img1, img2, padding, train): the operator the reference imports at train.py:39-43 and calls at :173
 // (Python twin: fused_ssim/__init__.py::_FusedSSIM).  Gradient with respect to img1 only, as upstream.
 // ------------------------------------------------------------------------------------------------
@@ -856,6 +921,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pose_row", &pose_row, "GaussianModel.get_RT: row `index` of the [views, 7] pose table as a node the render node's backward cooperates with");
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);
+  m.def("loss_pair_forward", &loss_pair_forward, "-> [l1_mean, ssim_mean, d(ssim_mean)/dimg1, img1, img2 (contiguous)]: one pass, no autograd node");
+  m.def("loss_affine", &loss_affine, "the recorded scalar expression over (l1_mean, ssim_mean) as ONE node on `image`");
   m.def("fused_ssim", &fused_ssim);
   m.def("host_times_us", [](bool reset) {
     std::vector<double> v(g_host_us, g_host_us + 6);

@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from .. import _lib
+from .. import lazy_loss
 
 
 def _run_forward(img1, img2, train, valid=False):
@@ -67,6 +68,11 @@ def fused_ssim(img1, img2, padding="same", train=True):
     mean (and the gradient) only covers the region where the 11x11 window lies inside the image."""
     if padding not in ("same", "valid"):
         raise ValueError(f'padding must be "same" or "valid", got {padding!r}')
+    if train and padding == "same" and lazy_loss._LAST[0] is not None and isinstance(img1, torch.Tensor) and isinstance(img2, torch.Tensor):
+        # the second half of train.py:171-176: `l1_loss(image, gt)` has just computed SSIM of these two tensors as well (lazy_loss.py)
+        half = lazy_loss.ssim_of_pair(img1, img2)
+        if half is not None:
+            return half
     ext = _lib.compiled()
     if ext is not None:   # the same two C-ABI calls from a C++ autograd node (csrc_torch/binding.cpp::SsimFn)
         return ext.fused_ssim(img1, img2, bool(train), padding == "valid")

@@ -8,9 +8,12 @@
     ssim_loss_mask(img1, img2, mask, ...)             (reference :25-37; render.py:30 imports it)
     gaussian, create_window, _ssim                    (reference :45-53, :65-85: the window and the conv2d formula, as helpers)
 
-`l1_loss` is ONE autograd node over `mi355gs_l1_loss_forward / _backward` (two launches forward, one backward) where the
-reference's expression is three eager kernels forward and four backward — the loop an unmodified train.py runs is bound by the
-host's launch rate, so launches are what count (bench.py `loops.dropin_reference_loop_torch_l1`).  Alias it like the operator
+`l1_loss` on an image that is being differentiated is the first half of the training loss (train.py:171-176): it runs one pass
+that computes L1 and SSIM together, the `fused_ssim` call on the same tensors takes its half from it, and the scalar arithmetic of
+train.py:176 is recorded on the host and evaluated in one launch (lazy_loss.py: four launches for the reference's sixteen, the
+source text unchanged — bench.py's headline loop).  Any other `l1_loss` call is ONE autograd node over
+`mi355gs_l1_loss_forward / _backward` (two launches forward, one backward) where the reference's expression is three eager
+kernels forward and four backward.  Alias it like the operator
 packages:  sys.modules["utils.loss_utils"] = instantsplat_amd.loss_utils
 Inputs the kernels do not take (other dtypes, a `gt` that requires a gradient, size_average=False, other window sizes) go
 through the reference's own PyTorch expressions, restated below.
@@ -20,6 +23,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from . import lazy_loss
 from .fused_ssim import fused_ssim
 
 
@@ -61,6 +65,10 @@ def _kernel_can_take(network_output, gt):
 def l1_loss(network_output, gt):
     if not _kernel_can_take(network_output, gt):
         return torch.abs((network_output - gt)).mean()
+    if lazy_loss.eligible(network_output, gt):
+        # the first half of the training loss (train.py:171-176): one pass computes L1 AND SSIM of the two images; the fused_ssim
+        # call that follows takes its half from it, and the scalar arithmetic between the two is recorded, not launched (lazy_loss.py)
+        return lazy_loss.l1_of_pair(network_output, gt)
     ext = _lib.compiled()
     if ext is not None:
         return ext.l1_loss(network_output, gt)

@@ -895,7 +895,17 @@ def check_teacher_forced_gradients_match_reference_function(dev, run="loop", fus
         uid = int(G[run + "_view_uids"][it])
         pkg = render(st.cameras[uid], g, st.pipe, st.background, camera_pose=g.get_RT(uid))
         image, gt = pkg["render"], st.gt_images[uid]
-        if fused_loss:
+        if fused_loss == "train_py":
+            # train.py:171-176 as written, on the drop-in modules (utils.loss_utils -> instantsplat_amd.loss_utils): the loss pair
+            # and the recorded scalar expression of instantsplat_amd/lazy_loss.py
+            from instantsplat_amd import lazy_loss
+            from instantsplat_amd.loss_utils import l1_loss
+            Ll1 = l1_loss(image, gt)
+            ssim_value = fused_ssim(image.unsqueeze(0), gt.unsqueeze(0))
+            assert isinstance(Ll1, lazy_loss.LazyScalar) and isinstance(ssim_value, lazy_loss.LazyScalar)
+            loss = (1.0 - st.opt.lambda_dssim) * Ll1 + st.opt.lambda_dssim * (1.0 - ssim_value)
+            assert isinstance(loss, lazy_loss.LazyScalar)
+        elif fused_loss:
             loss, _ = fused_l1_ssim_loss(image.unsqueeze(0), gt.unsqueeze(0), st.opt.lambda_dssim)
         else:
             loss = (1.0 - st.opt.lambda_dssim) * (image - gt).abs().mean() \
@@ -1347,12 +1357,18 @@ def check_loss_utils_against_the_references_own(dev):
     G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_utils_vectors.npz"))
     T = lambda k: torch.from_numpy(G[k]).to(dev)
     cuda = torch.device(dev).type == "cuda"
-    for binding in ("compiled", "ctypes"):
+    from instantsplat_amd import lazy_loss
+    for binding, lazy in (("compiled", True), ("compiled", False), ("ctypes", True), ("ctypes", False)):
+        lazy_was, lazy_loss.ENABLED = lazy_loss.ENABLED, lazy
         with _with_binding(binding):
             for k in range(5):
                 a, b = T(f"l1_{k}_a").requires_grad_(True), T(f"l1_{k}_b")
                 v = loss_utils.l1_loss(a, b)
-                assert v.dim() == 0 and v.grad_fn is not None and "L1Loss" in v.grad_fn.name(), v.grad_fn
+                # an image-shaped pair goes through the loss pair (lazy_loss.py: L1 and SSIM in one pass, one node for the
+                # whole scalar expression), everything else — and everything with the mechanism off — through the L1 node
+                paired = lazy and a.dim() in (3, 4)
+                assert isinstance(v, lazy_loss.LazyScalar) == paired, (binding, lazy, k, type(v), a.shape)
+                assert v.dim() == 0 and v.grad_fn is not None and ("LossAffine" if paired else "L1Loss") in v.grad_fn.name(), v.grad_fn
                 (v * 1.7).backward()
                 bound("loss_utils/l1_value", abs(float(v) - float(G[f"l1_{k}_value"])) / float(G[f"l1_{k}_value"]), 3e-7)
                 assert torch.equal(a.grad.cpu(), torch.from_numpy(G[f"l1_{k}_grad"])), (binding, k)
@@ -1365,6 +1381,8 @@ def check_loss_utils_against_the_references_own(dev):
             bg = b.clone().requires_grad_(True)
             loss_utils.l1_loss(a, bg).backward()
             assert bg.grad is not None and float(bg.grad.abs().sum()) > 0
+        lazy_loss.ENABLED = lazy_was
+        lazy_loss.forget()
     x, y, mask = T("ssim_x"), T("ssim_y"), T("ssim_mask")
     bound("loss_utils/ssim_11", abs(float(loss_utils.ssim(x, y)) - float(G["ssim_11"])), 2e-6 if cuda else 1e-6)
     bound("loss_utils/ssim_3d", abs(float(loss_utils.ssim(x[0], y[0])) - float(G["ssim_3d"])), 2e-6 if cuda else 1e-6)
@@ -1453,3 +1471,113 @@ def check_render_only_forward(dev, Wm=20, W=80, H=48):
     with torch.no_grad():
         res_ng = run_blob_case(dev, 600, 80, 48, 2, backward=False)["dut"]
     assert torch.equal(res["color"], res_ng["color"]) and torch.equal(res["radii"], res_ng["radii"])
+
+
+def check_lazy_loss_expression(dev, H=40, W=56):
+    """instantsplat_amd/lazy_loss.py: the reference's loss expression as written (train.py:171-176) served by the loss pair and a
+    recorded scalar program.  Against the same expression with the mechanism off (two independent nodes + eager scalar kernels):
+    the VALUE must be the bits float32 arithmetic gives for the recorded operations on the pair's two means, the gradient equal
+    to rounding; every way out of the recorded form (item, backward twice, mixing with real tensors, long programs, in-place
+    edits between the two calls, no_grad) must give what eager PyTorch gives."""
+    import numpy as np
+    import pytest
+    from instantsplat_amd import lazy_loss
+    from instantsplat_amd.fused_ssim import fused_ssim
+    from instantsplat_amd.loss_utils import l1_loss
+    Lz = lazy_loss.LazyScalar
+    gen = torch.Generator().manual_seed(4)
+    x0 = torch.rand(3, H, W, generator=gen).to(dev)
+    gt = (x0 + 0.1 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1).contiguous()
+    f32 = np.float32
+    cuda = torch.device(dev).type == "cuda"
+
+    def image():
+        leaf = x0.clone().requires_grad_(True)
+        return leaf, leaf * 1.0   # a non-leaf like a rendered image
+
+    def eager(expr):
+        was, lazy_loss.ENABLED = lazy_loss.ENABLED, False
+        try:
+            leaf, img = image()
+            a, b = l1_loss(img, gt), fused_ssim(img.unsqueeze(0), gt.unsqueeze(0))
+            assert type(a) is torch.Tensor and type(b) is torch.Tensor
+            v = expr(a, b)
+            v.backward()
+            return float(v.detach()), leaf.grad.detach().cpu().clone()
+        finally:
+            lazy_loss.ENABLED = was
+
+    lam = 0.2
+    exprs = {
+        "train_py": (lambda a, b: (1.0 - lam) * a + lam * (1.0 - b), lambda a, b: f32(f32(1.0 - lam) * a) + f32(f32(lam) * f32(f32(1.0) - b))),
+        "l1_only": (lambda a, b: a, lambda a, b: a),
+        "ssim_only": (lambda a, b: 1 - b, lambda a, b: f32(1.0) - b),
+        "mixed": (lambda a, b: -((a + b) / 2 - 0.1) + (b - a) * 3, lambda a, b: f32(-f32(f32(f32(a + b) * f32(f32(1.0) / f32(2.0))) + f32(-0.1))) + f32(f32(b - a) * f32(3))),
+        "twice_l1": (lambda a, b: a + a + 0.5 * b, lambda a, b: f32(f32(a + a) + f32(f32(0.5) * b))),
+    }
+    for name, (expr, np_expr) in exprs.items():
+        leaf, img = image()
+        a = l1_loss(img, gt)
+        b = fused_ssim(img.unsqueeze(0), gt.unsqueeze(0))
+        assert type(a) is Lz and type(b) is Lz, name
+        rec = a._rec
+        v = expr(a, b)
+        assert type(v) is Lz and v._real is None, name           # nothing has been launched for the arithmetic
+        v.backward()
+        val = v.item()                                            # (after backward, as train.py:188: the materialised tensor is reused)
+        assert v._real is not None and isinstance(val, float)
+        l1v, ssv = f32(float(rec.l1)), f32(float(rec.ssim))
+        assert val == float(np_expr(l1v, ssv)), (name, val, float(np_expr(l1v, ssv)))   # one float32 rounding per recorded operation
+        ref_val, ref_grad = eager(expr)
+        bound("lazy_loss/value[%s]" % name, abs(val - ref_val), 3e-7)
+        bound("lazy_loss/grad[%s]" % name, rel_l2(leaf.grad, ref_grad), 2e-6)
+    # ---- the ways out of the recorded form
+    leaf, img = image()
+    a, b = l1_loss(img, gt), fused_ssim(img.unsqueeze(0), gt.unsqueeze(0))
+    loss = 0.8 * a + 0.2 * (1.0 - b)
+    with torch.no_grad():
+        v0 = loss.item()                      # read before backward, under no_grad: must not spoil the later backward
+    assert "tensor(" in repr(loss) and loss.dim() == 0 and loss.dtype == torch.float32 and loss.device.type == torch.device(dev).type
+    loss.backward(retain_graph=True)
+    g1 = leaf.grad.clone()
+    loss.backward()
+    assert torch.allclose(leaf.grad, 2 * g1) and abs(loss.item() - v0) == 0.0
+    real = torch.tensor(2.0, device=dev)
+    leaf, img = image()
+    a, b = l1_loss(img, gt), fused_ssim(img.unsqueeze(0), gt.unsqueeze(0))
+    mix = a * real + torch.stack([a, b]).sum() + (a < 100)   # a real tensor operand / other functions: ordinary tensors from there on
+    assert type(mix) is torch.Tensor
+    mix.backward()
+    assert float(leaf.grad.abs().sum()) > 0
+    long = a
+    for _ in range(20):
+        long = long * 1.01 + 0.001
+    assert type(long) is torch.Tensor      # longer than a program may be (16 operations): ordinary tensors from there on
+    chk = f32(float(a._rec.l1))
+    for _ in range(20):
+        chk = f32(f32(chk * f32(1.01)) + f32(0.001))
+    assert float(long.detach()) == float(chk)
+    g = torch.autograd.grad(0.5 * a + b, img, retain_graph=True)[0]
+    assert g.shape == img.shape and float(g.abs().sum()) > 0
+    with pytest.raises(RuntimeError):     # the one entry point that does not consult __torch_function__: a loud failure, not a wrong number
+        torch.autograd.backward(0.5 * a)
+    # ---- when the second call is NOT the other half
+    leaf, img = image()
+    a = l1_loss(img, gt)
+    other = fused_ssim(img.unsqueeze(0), (gt * 0.5).unsqueeze(0))
+    assert type(other) is torch.Tensor          # another gt
+    img2 = img.clone()
+    a = l1_loss(img2, gt)
+    with torch.no_grad():
+        img2.mul_(0.5)                           # the image changed in place between the two calls: its version counter says so
+    changed = fused_ssim(img2.unsqueeze(0), gt.unsqueeze(0))
+    assert type(changed) is torch.Tensor
+    was, lazy_loss.ENABLED = lazy_loss.ENABLED, False
+    ssim_half = float(fused_ssim(img2.detach().unsqueeze(0), gt.unsqueeze(0)))
+    lazy_loss.ENABLED = was
+    bound("lazy_loss/ssim_after_inplace_edit", abs(float(changed) - ssim_half), 1e-6 if cuda else 0.0)
+    with torch.no_grad():                        # evaluation (train.py:277-284): no pair, no lazies
+        assert type(l1_loss(img, gt)) is torch.Tensor
+    assert type(l1_loss(img.detach(), gt)) is torch.Tensor
+    assert type(fused_ssim(img.unsqueeze(0), gt.unsqueeze(0), train=False)) is torch.Tensor
+    lazy_loss.forget()

@@ -187,9 +187,9 @@ def test_training_loop_matches_reference_function(emu, fused_step, run):
     ops_util.check_training_loop_matches_reference_function(emu, fused_step, run)
 
 
-@pytest.mark.parametrize("run", ["loop", "loopb"])
-def test_teacher_forced_gradients_match_reference_function(emu, run):
-    ops_util.check_teacher_forced_gradients_match_reference_function(emu, run)
+@pytest.mark.parametrize("run,fused_loss", [("loop", True), ("loopb", True), ("loop", "train_py")])
+def test_teacher_forced_gradients_match_reference_function(emu, run, fused_loss):
+    ops_util.check_teacher_forced_gradients_match_reference_function(emu, run, fused_loss)
 
 
 def test_oracle_trainer_matches_reference_function(emu):
@@ -264,3 +264,7 @@ def test_new_entry_points_reject_bad_arguments():
 
 def test_render_only_forward_is_bit_identical(emu):
     ops_util.check_render_only_forward(emu)
+
+
+def test_lazy_loss_expression(emu):
+    ops_util.check_lazy_loss_expression(emu)

@@ -163,3 +163,11 @@ def test_render_only_forward_is_bit_identical(gpu):
 
 def test_render_only_forward_at_bench_size(gpu):
     ops_util.check_render_only_forward(gpu, Wm=128, W=512, H=512)
+
+
+def test_lazy_loss_expression(gpu):
+    ops_util.check_lazy_loss_expression(gpu)
+
+
+def test_lazy_loss_expression_at_bench_size(gpu):
+    ops_util.check_lazy_loss_expression(gpu, H=512, W=512)

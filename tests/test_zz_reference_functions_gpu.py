@@ -17,7 +17,7 @@ def test_training_loop_plain_adam_fixed_poses_matches_reference_function(gpu):
     ops_util.check_training_loop_matches_reference_function(gpu, False, run="loopb")
 
 
-@pytest.mark.parametrize("run,fused_loss", [("loop", True), ("loop", False), ("loopb", True)])
+@pytest.mark.parametrize("run,fused_loss", [("loop", True), ("loop", False), ("loop", "train_py"), ("loopb", True)])
 def test_teacher_forced_gradients_match_reference_function(gpu, run, fused_loss):
     ops_util.check_teacher_forced_gradients_match_reference_function(gpu, run, fused_loss)
 
