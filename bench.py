@@ -5,10 +5,13 @@ A step = ONE full training iteration of reference train.py:140-211 on the HIP pa
 LR schedule, random view, render (pose transform + rasterizer forward), fused L1+SSIM loss, backward
 (SSIM bwd, rasterizer bwd, autograd glue), loss.item(), PerPointAdam step over all 7 parameter groups.
 
-`value` is the loop `north_star` names: the reference's train.py loop shape on the drop-in operators — `render()` /
-`GaussianRasterizer` / `fused_ssim` / `PerPointAdam` through the compiled binding, autograd, and BOTH of the reference's blocking
-host read-backs per iteration (the operator's instance count, `loss.item()` at train.py:188).  Measured next to it under the same
-protocol and reported as siblings (`loops`): the same iteration behind one library call with the loss read back every iteration
+`value` is the loop an UNMODIFIED reference train.py executes with the operator packages aliased: its loop
+shape on the drop-in operators — `render()` / `GaussianRasterizer` / `l1_loss` / `fused_ssim` / `PerPointAdam` through the compiled
+binding —, the loss formed exactly as train.py:171-176 writes it (l1_loss + fused_ssim + scalar arithmetic, served by
+instantsplat_amd/lazy_loss.py), autograd, and BOTH of the reference's blocking host read-backs per iteration (the operator's
+instance count, `loss.item()` at train.py:188).  Measured next to it under the same protocol and reported as siblings (`loops`):
+the same loop with the loss as ONE fused call (`dropin_reference_loop_fused_loss`: what a caller who may edit train.py would
+write), with torch's own l1_loss, and with the lazy loss mechanism switched off (the expression's sixteen eager launches); the same iteration behind one library call with the loss read back every iteration
 (`one_call_synced`: the library's two-part step — forward + backward of iteration t + 1 are enqueued before the host reads
 iteration t's loss, its optimizer launch, gated on the device, after: the device never waits for the host) and without that
 read-back (`one_call_run_ahead`: identical results, the loss EMA is evaluated every 10, the queue drains at every window).
@@ -283,14 +286,25 @@ def main():
                 "block_seconds": blocks, "timed_seconds": sum(blocks), "first_timed_iteration": PIN_ITER + args.warmup + 1,
                 "iters_per_sec_own_clock": args.steps / sorted(own)[len(own) // 2]}, st_
 
-    def dropin_loop(st_):      # the reference's loop on the drop-in operators: autograd, loss.item(), optimizer.step(), zero_grad
+    def dropin_loop(st_):      # the reference's loop on the drop-in operators, the loss as ONE fused call (a caller who edits train.py)
         return (lambda: train_iteration(st_)), (lambda: None), (lambda: None)
 
     def dropin_loop_reference_loss(st_):   # ... with the loss formed exactly as train.py:171-176 does: torch l1_loss + fused_ssim + scalar arithmetic
         return (lambda: train_iteration(st_, fused_loss="torch")), (lambda: None), (lambda: None)
 
-    def dropin_loop_train_py_loss(st_):    # ... the same expression with utils/loss_utils.l1_loss aliased to this package's drop-in (one HIP node)
+    def dropin_loop_train_py_loss(st_):    # THE HEADLINE: train.py:171-176 as written, utils/loss_utils aliased to this package's drop-in
         return (lambda: train_iteration(st_, fused_loss=False)), (lambda: None), (lambda: None)
+
+    def dropin_loop_train_py_loss_eager(st_):   # ... with lazy_loss switched off: l1_loss and fused_ssim as two nodes, four eager scalar kernels
+        from instantsplat_amd import lazy_loss
+
+        def step():
+            was, lazy_loss.ENABLED = lazy_loss.ENABLED, False
+            try:
+                return train_iteration(st_, fused_loss=False)
+            finally:
+                lazy_loss.ENABLED = was
+        return step, (lambda: None), (lambda: None)
 
     def one_call_synced(st_):  # the same iteration behind ONE library call, loss read back every iteration
         return (lambda: train_iteration(st_, fused_step=True)), (lambda: None), (lambda: release_trainer(st_))
@@ -312,22 +326,23 @@ def main():
     if world > 1:
         st_solo = fresh_state()
         for _ in range(args.warmup):
-            train_iteration(st_solo)
+            train_iteration(st_solo, fused_loss=False)
         sync()
         if rank == 0:
             dev_sync()
             ts = time.perf_counter()
             for _ in range(args.steps):
-                train_iteration(st_solo)
+                train_iteration(st_solo, fused_loss=False)
             dev_sync()
             solo_its = args.steps / (time.perf_counter() - ts)
         sync()
         del st_solo
 
     # ---- the timed region.  NO instrumentation runs inside it (round 3 sampled kernel events there: ~1 % of ms_per_step).
-    headline, st = measure(dropin_loop)
+    headline, st = measure(dropin_loop_train_py_loss)
+    fused_sib, _ = measure(dropin_loop)
     strict, _ = measure(dropin_loop_reference_loss)
-    train_py, _ = measure(dropin_loop_train_py_loss)
+    eager_sib, _ = measure(dropin_loop_train_py_loss_eager)
     synced, _ = measure(one_call_synced)
     run_ahead, _ = measure(one_call_run_ahead)
     elapsed = headline["ms_per_step"] * 1e-3 * args.steps
@@ -367,6 +382,20 @@ def main():
             render(cam, stp.gaussians, stp.pipe, stp.background, camera_pose=stp.gaussians.get_RT(cam.uid))
         dev_sync()
         raster_ms = 1e3 * (time.perf_counter() - tr) / nfr
+
+    # ---- the render-only forward (every no-grad render: evaluation, render.py's callers, the FPS loop): HIP events around the
+    # TRAIN = false instantiation of k_composite_fwd (profile kind 2) over the training views of the profiled state
+    ro_ms, ro_n = 0.0, 0
+    with torch.no_grad():
+        L.mi355gs_profile_set_period(1)
+        L.mi355gs_profile_begin()
+        for i in range(60 if not emulated else 1):
+            cam = stp.cameras[i % len(stp.cameras)]
+            render(cam, stp.gaussians, stp.pipe, stp.background, camera_pose=stp.gaussians.get_RT(cam.uid))
+        dev_sync()
+        _lib.check(L.mi355gs_profile_read(2, ctypes.byref(tot_ms), ctypes.byref(n)), "profile_read")
+        ro_ms, ro_n = tot_ms.value / max(n.value, 1), n.value
+        L.mi355gs_profile_end()
 
     # ---- instance statistics of the state the kernels were timed on (algorithmic bytes of the composite kernels)
     keep_last_frame(True)
@@ -515,9 +544,10 @@ def main():
         fps = {"fps": f["fps"], "ms_per_frame": f["ms_per_frame"],
                "method": "reference render.py:172-186 (1000 renders of one view, sorted, middle 80 % averaged) with an explicit synchronize per frame"}
 
-    def pmc_rows(name):
+    def pmc_rows(name, render_only=False):
         """per-kernel means of one committed PMC pass; template arguments and the `void ` prefix are dropped from the kernel
-        names and the counting instantiation (<.., true>) is ignored"""
+        names; the counting instantiation of the backward (<.., true>) is ignored, and of k_composite_fwd<tiles, count, train>
+        only the training instantiation is taken (render_only=True: only the render-only one)"""
         import csv
         out = {}
         with open(os.path.join(ROOT, "profiles", name)) as fh:
@@ -525,13 +555,15 @@ def main():
                 k = row["kernel"]
                 if k.endswith("true>") and "k_composite_bwd" in k:
                     continue
+                if "k_composite_fwd" in k and k.count(",") >= 2 and (k.replace(" ", "").endswith(",false>") != render_only):
+                    continue
                 out.setdefault(k.replace("void ", "").split("<")[0], row)
         return out
 
     traffic, traffic_src, fwd_traffic = None, None, None
     try:  # HBM-side bytes per launch: rocprofv3 --pmc passes of this command, collected separately (counters cannot run inside a
         # timed bench) and committed under profiles/; the newest round present is used and named
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 fr, wr = pmc_rows(f"{rnd}_pmc_c3_FETCH_SIZE.csv"), pmc_rows(f"{rnd}_pmc_c3_WRITE_SIZE.csv")
                 f_, w_ = fr["k_composite_bwd"], wr["k_composite_bwd"]
@@ -546,9 +578,19 @@ def main():
     except Exception:
         traffic = None
 
+    ro_traffic, ro_traffic_src = None, None
+    try:   # the render-only instantiation has its own PMC pass (tools/pmc.sh over tools/render_only_loop.py)
+        fr, wr = pmc_rows("r05_pmc_render_only_FETCH_SIZE.csv", True), pmc_rows("r05_pmc_render_only_WRITE_SIZE.csv", True)
+        f_, w_ = fr["k_composite_fwd"], wr["k_composite_fwd"]
+        ro_traffic = {"bytes": (2.0 * float(f_["mean_FETCH_SIZE"]) + float(w_["mean_WRITE_SIZE"])) * 1024.0,
+                      "write_bytes": float(w_["mean_WRITE_SIZE"]) * 1024.0}
+        ro_traffic_src = "profiles/r05_pmc_render_only_FETCH_SIZE.csv + r05_pmc_render_only_WRITE_SIZE.csv"
+    except Exception:
+        ro_traffic = None
+
     valu = None
     try:  # SQ counter pass of the same command (separate run)
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 row = pmc_rows(f"{rnd}_pmc_c3_SQ_counters.csv")["k_composite_bwd"]
             except (OSError, KeyError):
@@ -591,7 +633,13 @@ def main():
                 "iters_per_sec_median_block_own_clock": headline["iters_per_sec_own_clock"],            # the headline (drop-in) loop
                 "ms_per_step_dropin_own_clock": 1e3 / headline["iters_per_sec_own_clock"],
                 "iters_per_sec_one_call_synced_own_clock": synced["iters_per_sec_own_clock"],
-                "iters_per_sec_one_call_run_ahead_own_clock": run_ahead["iters_per_sec_own_clock"], "psnr_after": psnr_after}
+                "iters_per_sec_one_call_run_ahead_own_clock": run_ahead["iters_per_sec_own_clock"], "psnr_after": psnr_after,
+                # the roofline half of the north-star at N > 1: every rank's own kernel times (HIP events of its untimed pass) and box tag
+                "composite_bwd_avg_ms": kern["composite_bwd"][0], "composite_fwd_avg_ms": kern["composite_fwd"][0],
+                "composite_fwd_render_only_avg_ms": ro_ms, "R_eff": R_eff,
+                "composite_bwd_frac_hbm": (112.0 * R_eff + 20.0 * res * res) / (kern["composite_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kern["composite_bwd"][0] > 0 else None,
+                "composite_fwd_frac_hbm": (40.0 * R_eff + 20.0 * res * res + 8.0 * ((res + 15) // 16) ** 2) / (kern["composite_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kern["composite_fwd"][0] > 0 else None,
+                "box": box}
         reports = gather_rank_reports(mine)
         if not emulated:
             assert_one_rank_per_device(reports, torch.cuda.device_count())
@@ -618,30 +666,38 @@ def main():
                                    f"), one scene per GPU", "views": V, "gaussians": P, "width": res, "height": res,
                        "parallelism": f"scene-per-gpu x{world}"},
             "rasterize_ms_per_frame": raster_ms, "box": box,
-            "value_path": "drop-in reference loop",
-            "loop": "the reference's train.py loop shape on the drop-in operators (render() / GaussianRasterizer / fused_ssim / PerPointAdam "
-                    "through the compiled binding): autograd, the operator's blocking instance-count read-back and the blocking "
-                    "loss.item() read-back (train.py:188) every iteration — the loop north_star names",
+            "value_path": "drop-in reference loop, train.py:171-176 loss as written",
+            "loop": "what an unmodified reference train.py executes with the operator packages aliased (INTEGRATION.md 1): render() / "
+                    "GaussianRasterizer / l1_loss / fused_ssim / PerPointAdam through the compiled binding, the loss formed as "
+                    "train.py:171-176 writes it (l1_loss + fused_ssim + four scalar operations: instantsplat_amd/lazy_loss.py), autograd, "
+                    "the operator's blocking instance-count read-back and the blocking loss.item() read-back (train.py:188) every iteration",
             "timed_blocks": headline["timed_blocks"], "block_seconds": headline["block_seconds"], "timed_seconds": headline["timed_seconds"],
             "timed_iterations": f"{headline['first_timed_iteration']} .. {headline['first_timed_iteration'] + n_blocks * args.steps - 1} of training "
                                 f"from seed {rank} (every loop on a fresh state fast-forwarded to iteration {PIN_ITER}); no instrumentation inside",
-            "loops": {"dropin_reference_loop": headline,
-                      "dropin_reference_loop_torch_l1": dict(strict, what="the same loop with the loss formed exactly as train.py:171-176 writes it: "
-                                                                          "torch's own l1_loss (abs / mean), the drop-in fused_ssim, scalar arithmetic in "
-                                                                          "eager PyTorch — the headline takes (1-l)*L1 + l*(1-SSIM) as one node, "
-                                                                          "instantsplat_amd.fused_ssim.fused_l1_ssim_loss"),
-                      "dropin_reference_loop_train_py_loss": dict(train_py, what="train.py:171-176 as written — l1_loss(image, gt), fused_ssim, scalar "
-                                                                                "arithmetic — with utils/loss_utils aliased to instantsplat_amd.loss_utils "
-                                                                                "like the operator packages (l1_loss = one HIP node: 3 launches for 7)"),
+            "loops": {"dropin_reference_loop_train_py_loss": dict(headline, what="THE HEADLINE — train.py:171-176 as written: l1_loss(image, gt), "
+                                                                               "fused_ssim(image[None], gt[None]), scalar arithmetic, loss.backward(); "
+                                                                               "utils/loss_utils aliased to instantsplat_amd.loss_utils like the operator "
+                                                                               "packages (lazy_loss.py: 4 launches for the expression's 16)"),
+                      "dropin_reference_loop_fused_loss": dict(fused_sib, what="the same loop with the loss as ONE call, "
+                                                                               "instantsplat_amd.fused_ssim.fused_l1_ssim_loss — needs an edit of train.py; "
+                                                                               "rounds 2-4 quoted this loop as `value`"),
+                      "dropin_reference_loop_torch_l1": dict(strict, what="torch's own l1_loss (abs / mean: utils/loss_utils NOT aliased), the drop-in "
+                                                                          "fused_ssim, scalar arithmetic in eager PyTorch"),
+                      "dropin_reference_loop_train_py_loss_eager": dict(eager_sib, what="the headline's source text with lazy_loss switched off "
+                                                                                        "(MI355GS_LAZY_LOSS=0): l1_loss and fused_ssim as two "
+                                                                                        "independent HIP nodes, four eager scalar kernels and their "
+                                                                                        "backward — round 4's `dropin_reference_loop_train_py_loss`"),
                       "one_call_synced": dict(synced, what="mi355gs_trainer_step + mi355gs_trainer_optimizer_step(commit_gate=1): loss and instance count of "
                                                            "EVERY iteration read back on the host; forward + backward of iteration t + 1 are enqueued "
                                                            "before that read, the (device-gated, sticky) optimizer launch after it — what "
                                                            "instantsplat_amd.train.training() runs by default"),
                       "one_call_run_ahead": dict(run_ahead, what="the one-call step without the per-iteration read-back (identical results; EMA "
                                                                  "evaluated and counts verified every 10 iterations, where the queue drains)", window_replays=sum(replays))},
-            "iters_per_sec_dropin_reference_loop": headline["iters_per_sec"], "iters_per_sec_autograd_path": headline["iters_per_sec"],
+            "iters_per_sec_dropin_reference_loop_train_py_loss": headline["iters_per_sec"], "iters_per_sec_autograd_path": headline["iters_per_sec"],
+            "iters_per_sec_dropin_reference_loop_fused_loss": fused_sib["iters_per_sec"],
+            "headline_over_fused_loss_sibling": headline["iters_per_sec"] / fused_sib["iters_per_sec"],
             "iters_per_sec_dropin_reference_loop_torch_l1": strict["iters_per_sec"],
-            "iters_per_sec_dropin_reference_loop_train_py_loss": train_py["iters_per_sec"],
+            "iters_per_sec_dropin_reference_loop_train_py_loss_eager": eager_sib["iters_per_sec"],
             "iters_per_sec_with_per_iteration_loss_readback": synced["iters_per_sec"], "iters_per_sec_one_call_synced": synced["iters_per_sec"],
             "iters_per_sec_run_ahead": run_ahead["iters_per_sec"], "run_ahead_window_replays": sum(replays),
             "binding": _lib.BINDING,
@@ -664,7 +720,16 @@ def main():
                                            "frac": (fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fwd_ms > 0 else 0.0,
                                            "traffic": fwd_traffic, "compute": fwd_compute,
                                            "note": "traffic above the algorithmic bytes: the forward leaves a 16 B/pixel boundary record per "
-                                                   "64-instance unit of every tile for the segmented backward (DESIGN.md 4.2b)"}},
+                                                   "64-instance unit of every tile for the segmented backward (DESIGN.md 4.2b)"},
+                         "render_only": {"kernel": "k_composite_fwd<.., TRAIN = false> (mi355gs_raster_forward_render_only: every no-grad render)",
+                                         "avg_kernel_ms": ro_ms, "launches": ro_n, "algorithmic_bytes_per_launch": fwd_bytes,
+                                         "achieved": fwd_bytes / (ro_ms * 1e-3) / 1e9 if ro_ms > 0 else 0.0,
+                                         "frac": (fwd_bytes / (ro_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ro_ms > 0 else 0.0,
+                                         "unit": "GB/s", "peak": HBM_PEAK_GBS, "bound": "valu-issue",
+                                         "traffic": (ro_traffic or {}).get("bytes"), "write_traffic": (ro_traffic or {}).get("write_bytes"),
+                                         "traffic_source": ro_traffic_src,
+                                         "timed_where": "60 no-grad renders of the training views of the profiled state, HIP events on the launch stream",
+                                         "rasterize_ms_per_frame_whole_render": raster_ms}},
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), file=line_out, flush=True)
