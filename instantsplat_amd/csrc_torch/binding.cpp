@@ -734,6 +734,29 @@ Tensor loss_affine(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor l1, Ten
   return LossAffineFn::apply(image, a, b, dmap, l1, ssim, ops, consts, c_l1, c_ssim);
 }
 
+// loss.backward() of a recorded expression (train.py:177) in one call: the node is created and the engine run from here — no
+// Python frames of torch.autograd.backward in between — with a cached 1 per device as the root gradient (autograd's own
+// ones_like(loss) is a fill launch per iteration; the node only reads the value).  Returns the materialised tensor.
+Tensor loss_affine_backward(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor l1, Tensor ssim, std::vector<int64_t> ops,
+                            std::vector<double> consts, double c_l1, double c_ssim) {
+  Tensor out = LossAffineFn::apply(image, a, b, dmap, l1, ssim, ops, consts, c_l1, c_ssim);
+  if (!out.requires_grad()) return out;
+  static std::mutex mu;
+  static std::map<std::string, Tensor> ones;
+  Tensor one;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    std::ostringstream key;
+    key << out.device();
+    Tensor& slot = ones[key.str()];
+    if (!slot.defined() || slot._version() != 0) slot = at::ones({}, out.options().requires_grad(false));   // (written to: a fresh one)
+    one = slot;
+  }
+  py::gil_scoped_release nogil;   // the engine's worker threads take the GIL themselves for Python-defined nodes
+  torch::autograd::backward({out}, {one}, /*retain_graph=*/false, /*create_graph=*/false);
+  return out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused_ssim(img1, img2, padding, train): the operator the reference imports at train.py:39-43 and calls at :173
 // (Python twin: fused_ssim/__init__.py::_FusedSSIM).  Gradient with respect to img1 only, as upstream.
@@ -922,6 +945,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);
   m.def("loss_pair_forward", &loss_pair_forward, "-> [l1_mean, ssim_mean, d(ssim_mean)/dimg1, img1, img2 (contiguous)]: one pass, no autograd node");
+  m.def("loss_affine_backward", &loss_affine_backward, "loss_affine + the engine run of loss.backward() in one call (root gradient: a cached 1)");
   m.def("loss_affine", &loss_affine, "the recorded scalar expression over (l1_mean, ssim_mean) as ONE node on `image`");
   m.def("fused_ssim", &fused_ssim);
   m.def("host_times_us", [](bool reset) {

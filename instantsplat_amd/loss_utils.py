@@ -63,12 +63,12 @@ def _kernel_can_take(network_output, gt):
 
 
 def l1_loss(network_output, gt):
-    if not _kernel_can_take(network_output, gt):
-        return torch.abs((network_output - gt)).mean()
-    if lazy_loss.eligible(network_output, gt):
+    if isinstance(network_output, torch.Tensor) and isinstance(gt, torch.Tensor) and lazy_loss.eligible(network_output, gt):
         # the first half of the training loss (train.py:171-176): one pass computes L1 AND SSIM of the two images; the fused_ssim
         # call that follows takes its half from it, and the scalar arithmetic between the two is recorded, not launched (lazy_loss.py)
         return lazy_loss.l1_of_pair(network_output, gt)
+    if not _kernel_can_take(network_output, gt):
+        return torch.abs((network_output - gt)).mean()
     ext = _lib.compiled()
     if ext is not None:
         return ext.l1_loss(network_output, gt)

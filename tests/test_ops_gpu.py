@@ -147,14 +147,22 @@ def test_l1_loss_at_1080p_equals_the_references_expression(gpu):
     a = torch.rand(3, 1080, 1920, generator=g).to(gpu).requires_grad_(True)
     b = torch.rand(3, 1080, 1920, generator=g).to(gpu)
     b.view(-1)[::5] = a.detach().view(-1)[::5]
-    v = loss_utils.l1_loss(a, b)
-    assert "L1Loss" in v.grad_fn.name()
-    (v * 0.8).backward()
-    mine, a.grad = a.grad.clone(), None
-    r = torch.abs((a - b)).mean()
-    (r * 0.8).backward()
-    assert abs(float(v) - float(r)) <= 1e-6 * float(r), (float(v), float(r))
-    assert torch.equal(mine, a.grad)
+    from instantsplat_amd import lazy_loss
+    for lazy in (True, False):   # through the loss pair's recorded expression (lazy_loss.py) and through the plain L1 node
+        was, lazy_loss.ENABLED = lazy_loss.ENABLED, lazy
+        try:
+            a.grad = None
+            v = loss_utils.l1_loss(a, b)
+            assert ("LossAffine" if lazy else "L1Loss") in v.grad_fn.name()
+            (v * 0.8).backward()
+            mine, a.grad = a.grad.clone(), None
+            r = torch.abs((a - b)).mean()
+            (r * 0.8).backward()
+            assert abs(float(v) - float(r)) <= 1e-6 * float(r), (lazy, float(v), float(r))
+            assert torch.equal(mine, a.grad), lazy
+        finally:
+            lazy_loss.ENABLED = was
+            lazy_loss.forget()
 
 
 def test_render_only_forward_is_bit_identical(gpu):
