@@ -147,6 +147,18 @@ int mi355gs_raster_frame_stats(void* stream, int W, int H, const void* tiles, in
  * snapshot of it at mi355gs_trainer_create and uses that for all its calls. */
 int mi355gs_tune_min_units(int min_units);
 
+/* Deterministic-backward mode (ABI v9; SURVEY.md 5 "determinism self-check").  The default backward adds the nine screen-space
+ * moments of a Gaussian from every (tile, unit) that replays it with float atomics, in whatever order the waves arrive: two runs
+ * of the same frame differ in the last bits, two runs of the same scene drift apart.  on = 1: every (Gaussian, tile) instance's
+ * moments are stored to a row of their own and summed per Gaussian in the order of its tile rectangle (y outer, x inner) —
+ * bit-identical gradients run to run, and with them bit-identical training.  Same arithmetic otherwise; costs six small
+ * launches, a memset and 52 bytes per instance per backward (measured: profiles/).
+ * It enters the buffer-size queries (mi355gs_raster_binning_bytes: + 52 B per instance; mi355gs_raster_grad_scratch_bytes:
+ * + ~8 B per Gaussian): set it before sizing a frame's buffers and keep it until that frame's backward has been enqueued; a
+ * trainer handle takes a snapshot at mi355gs_trainer_create.  The work-counting instantiation (mi355gs_profile_work_counters)
+ * is not available in this mode.  Returns the previous value; on < 0 only queries.  Process-wide. */
+int mi355gs_tune_deterministic(int on);
+
 /* Convention of dL_dscales under scale_modifier != 1 (ABI v9).  The covariance is built from s = scale_modifier * scale
  * (reference gaussian_renderer/__init__.py:29,66 is the only place the modifier comes from; it trains with 1.0).
  *   mode 0 (default): dL_dscales = dL/ds, the gradient with respect to the MODIFIED scale — what the published operator's

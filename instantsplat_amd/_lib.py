@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mi355gs_raster_frame_stats": (c_int, [_P, c_int, c_int, _P, _P]),
     "mi355gs_tune_min_units": (c_int, [c_int]),
     "mi355gs_tune_scale_grad": (c_int, [c_int]),
+    "mi355gs_tune_deterministic": (c_int, [c_int]),
     "mi355gs_profile_begin": (c_int, []),
     "mi355gs_profile_set_period": (c_int, [c_int]),
     "mi355gs_profile_work_counters": (c_int, [_P]),
@@ -99,6 +100,8 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). instantsplat_amd has no CPU or PyTorch fallback.")
         _LIB = _bind(LIB_PATH)
+        if os.environ.get("MI355GS_DETERMINISTIC", "0") == "1":   # the deterministic backward (include/mi355gs.h), process-wide
+            _LIB.mi355gs_tune_deterministic(1)
     return _LIB
 
 

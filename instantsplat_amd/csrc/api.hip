@@ -21,7 +21,9 @@ int gs_launch_composite_fwd(hipStream_t, int, int, int, int, uint32_t, const uin
 int gs_launch_composite_bwd(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const GsRec*, const float*,
                             const float*, const uint32_t*, const float*, GsGrad*, const float*, const uint4*,
                             const float4*, const uint32_t*, uint32_t, bool, const unsigned long long*, uint32_t, const uint32_t*,
-                            unsigned long long*);
+                            unsigned long long*, const uint32_t*, float*);
+int gs_launch_det_prepare(hipStream_t, int, int, int, uint32_t, const uint32_t*, const uint32_t*, const uint2*, char*, uint32_t*, float*);
+int gs_launch_det_gather(hipStream_t, int, uint32_t, const char*, const float*, GsGrad*);
 int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, const uint32_t*, int64_t*);
 
 // ---- optional per-kernel timing (HIP events on the launch stream)
@@ -60,6 +62,10 @@ thread_local GsFusedStepHooks g_fused;
 void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
 
 static int g_scale_grad_exact = 0;   // mi355gs_tune_scale_grad
+static int g_deterministic = 0;      // mi355gs_tune_deterministic
+thread_local int g_deterministic_pinned = -1;   // a trainer handle's snapshot, in force for the duration of its calls
+int gs_deterministic() { return g_deterministic_pinned >= 0 ? g_deterministic_pinned : g_deterministic; }
+void gs_pin_deterministic(int v) { g_deterministic_pinned = v; }
 
 static CamParams make_cam(const float* view, const float* proj, const float* campos, float tanfovx, float tanfovy,
                           float scale_modifier, int W, int H) {
@@ -97,7 +103,9 @@ size_t mi355gs_raster_binning_bytes(int64_t n, int W, int H) {
   return BinningLayout(n, TilesLayout(W, H).T).total;
 }
 size_t mi355gs_raster_grad_gate_offset(int P) { return gs_align((size_t)(P > 0 ? P : 1) * sizeof(GsGrad)); }
-size_t mi355gs_raster_grad_scratch_bytes(int P) { return mi355gs_raster_grad_gate_offset(P) + 256; }
+size_t mi355gs_raster_grad_scratch_bytes(int P) {
+  return mi355gs_raster_grad_gate_offset(P) + 256 + (gs_deterministic() ? DetScratchLayout(P).total : 0);
+}
 
 int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                                       const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
@@ -224,6 +232,17 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
   const size_t clear_bytes = g_fused.gate_tail ? mi355gs_raster_grad_gate_offset(P) + 8 * sizeof(float) : (size_t)P * sizeof(GsGrad);
   if (!g_fused.skip_memsets && !grad_scratch_is_clear && hipMemsetAsync(grads, 0, clear_bytes, stream) != hipSuccess) return MI355GS_ELAUNCH;
   if (cap > 0) {
+    // deterministic mode: every instance's moments go to a row of their own (binning: det_rows / det_rowidx) and are summed per
+    // Gaussian in rectangle order by k_det_gather, which writes every record — instead of meeting in float atomics
+    const bool det = gs_deterministic() != 0;
+    char* det_scratch = (char*)grad_scratch + mi355gs_raster_grad_gate_offset(P) + 256;
+    uint32_t* rowidx = det ? (uint32_t*)(const_cast<char*>(b) + bl.det_rowidx) : nullptr;
+    float* rows = det ? (float*)(const_cast<char*>(b) + bl.det_rows) : nullptr;
+    if (det) {
+      if (gs_launch_det_prepare(stream, P, tl.T, tl.gx, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
+                                (const uint2*)(g + gl.rect), det_scratch, rowidx, rows) != 0) return MI355GS_ELAUNCH;
+      GS_CHECK_LAUNCH("det_prepare");
+    }
     {
       ProfScope prof(1, stream);
       gs_launch_composite_bwd(stream, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
@@ -231,8 +250,9 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                               dL_dpix, grads, out_color, (const uint4*)(b + bl.unit_tile),
                               (const float4*)(b + bl.bstate), (const uint32_t*)(t + tl.meta), bl.max_units, bl.may_loop,
                               (const unsigned long long*)(b + bl.hitmask), bl.max_chunks, (const uint32_t*)(t + tl.qmax),
-                              g_prof.work_counters);
+                              det ? nullptr : g_prof.work_counters, rowidx, rows);
     }
+    if (det) gs_launch_det_gather(stream, P, cap, det_scratch, rows, grads);
     GS_CHECK_LAUNCH("composite_bwd");
   }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
@@ -243,6 +263,12 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                            (g_fused.gate && g_fused.gate_sh_rest >= 0) ? g_fused.gate + g_fused.gate_sh_rest : nullptr);
   GS_CHECK_LAUNCH("preprocess_bwd");
   return MI355GS_OK;
+}
+
+int mi355gs_tune_deterministic(int on) {
+  const int old = g_deterministic;
+  if (on >= 0) g_deterministic = on ? 1 : 0;
+  return old;
 }
 
 int mi355gs_tune_scale_grad(int mode) {

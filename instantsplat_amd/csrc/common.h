@@ -65,6 +65,22 @@ __host__ __device__ inline int gs_unit_level_for(long long instances, long long 
   while (level + 1 < GS_UNIT_LEVELS && (instances >> (7 + level)) >= min_units) ++level;   // instances / (2 * 64 << level), instances >= 0
   return level;
 }
+// Deterministic-backward mode (mi355gs_tune_deterministic, composite.hip): the moments of every (Gaussian, tile) instance go to a
+// row of their own and are summed per Gaussian in tile order instead of meeting in float atomics.  It enters the layouts below
+// (rows + row indices per instance in `binning`, the per-Gaussian row offsets behind the gate flags in the gradient scratch).
+int gs_deterministic();           // api.hip: the knob (or the value a trainer handle pinned for its calls)
+void gs_pin_deterministic(int v); // >= 0: this thread sizes and launches with v until it is reset to -1 (trainer.hip)
+struct DetScratchLayout {         // behind the 256 bytes of gate flags in the gradient scratch; all uint32
+  size_t area, off, block_sums, total;
+  __host__ explicit DetScratchLayout(int P) {
+    const size_t n = (size_t)(P > 0 ? P : 1) + 1;
+    size_t o = 0;
+    area = o; o += gs_align(n * 4);                  // tiles of every Gaussian's rectangle (+ one 0)
+    off = o; o += gs_align((n + 1) * 4);             // their exclusive prefix sums: first row of Gaussian g
+    block_sums = o; o += gs_align(((n + 4095) / 4096 + 2) * 4);
+    total = o;
+  }
+};
 int gs_min_units();               // binning.hip: the mi355gs_tune_min_units knob (or the value a trainer handle pinned for its calls)
 void gs_pin_min_units(int v);     // > 0: this thread sizes and launches with v until it is reset to 0 (trainer.hip)
 constexpr int GS_MIN_UNITS = 40960;  // lengthen units only while at least this many remain (6-7 rounds of the 6144 resident waves:
@@ -103,7 +119,7 @@ constexpr int GS_SEG = 64;
 // on the number of units for the buffers.
 
 struct BinningLayout {
-  size_t keys, list, unit_tile, bstate, hitmask, total;
+  size_t keys, list, unit_tile, bstate, hitmask, det_rows, det_rowidx, total;
   uint32_t max_chunks;  // 64-instance chunks the hit-mask table has room for
   uint32_t max_units;  // table / boundary slots available: an upper bound on the units of any frame with <= R instances
   bool may_loop;       // a frame with this capacity can have units longer than one chunk
@@ -127,6 +143,11 @@ struct BinningLayout {
     // below instances / 64 + 8 per tile at every unit length.
     max_chunks = (uint32_t)(by_chunks + 8 * (size_t)(T > 0 ? T : 1) + 8);
     hitmask = o; o += gs_align((size_t)max_chunks * 4 * sizeof(uint64_t));
+    det_rows = det_rowidx = o;
+    if (gs_deterministic()) {   // one row of twelve floats (a GsGrad) and one row index per instance
+      det_rows = o; o += gs_align(n * sizeof(GsGrad));
+      det_rowidx = o; o += gs_align(n * 4);
+    }
     total = o;
   }
 };

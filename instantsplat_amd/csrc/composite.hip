@@ -384,7 +384,11 @@ constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgro
 #else
 #define GS_BW_BOUNDS __launch_bounds__(64 * BW_UNITS)
 #endif
-template <int CHUNKS, bool COUNT = false>
+// DET: the deterministic instantiation (mi355gs_tune_deterministic): the staged record carries the instance's ROW index instead of
+// the Gaussian's, and the nine sums of a step are stored to that row (every (Gaussian, tile) instance is replayed by exactly one
+// unit, once) instead of being added to the Gaussian's record with float atomics; k_det_gather then sums a Gaussian's rows in
+// the order of its tile rectangle.  Same arithmetic up to that final order of additions — which no longer depends on timing.
+template <int CHUNKS, bool COUNT = false, bool DET = false>
 __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capacity,
                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ list,
                                                         const GsRec* __restrict__ recs, const float* __restrict__ bg,
@@ -395,7 +399,9 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
                                                         const uint32_t* __restrict__ meta, uint32_t max_units,
                                                         unsigned long long* __restrict__ counters,
                                                         const unsigned long long* __restrict__ hitmask, uint32_t max_chunks,
-                                                        const uint32_t* __restrict__ qmax) {
+                                                        const uint32_t* __restrict__ qmax, const uint32_t* __restrict__ det_rowidx,
+                                                        float* __restrict__ det_rows) {
+  static_assert(!DET || BW_REDUCE_LDS, "the deterministic instantiation is written for the LDS reduction");
   __shared__ float4 s_rec[BW_UNITS][GS_SEG][3];   // the staged chunk, record-major, at a scalar address (see k_composite_fwd)
   __shared__ __attribute__((aligned(16))) float s_red[BW_UNITS][BW_REDUCE_LDS ? 9 * RED_PITCH : 4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -591,7 +597,11 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
         }
         part += gs_dpp<0xB1>(part);   // quad_perm [1,0,3,2]
         part += gs_dpp<0x4E>(part);   // quad_perm [2,3,0,1]: every lane of the quad holds the moment's sum over the wave
-        if ((lane & 3) == 0 && lane < 36) atomicAdd(reinterpret_cast<float*>(grads + id) + (lane >> 2), part);
+        if constexpr (DET) {
+          if ((lane & 3) == 0 && lane < 36 && id < capacity) det_rows[(size_t)id * 12 + (lane >> 2)] = part;   // id: the instance's row
+        } else {
+          if ((lane & 3) == 0 && lane < 36) atomicAdd(reinterpret_cast<float*>(grads + id) + (lane >> 2), part);
+        }
       }
     } else if constexpr (BW_REDUCE_MFMA) {
       if (any_valid) {
@@ -650,7 +660,8 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
       const uint32_t id = list[start + cb + lane];
       const GsRec* r = recs + id;
       const float4 col = r->q2;  // (r, g, b, depth): depth is not used here, its slot carries the Gaussian's index
-      recl[lane][0] = r->q0; recl[lane][1] = r->q1; recl[lane][2] = make_float4(col.x, col.y, col.z, __uint_as_float(id));
+      recl[lane][0] = r->q0; recl[lane][1] = r->q1;
+      recl[lane][2] = make_float4(col.x, col.y, col.z, __uint_as_float(DET ? det_rowidx[start + cb + lane] : id));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -708,6 +719,44 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
   }
 }
 
+// ---- deterministic mode: rows of the instances and their per-Gaussian sums --------------------------------------------------
+// area[g] = tiles of Gaussian g's rectangle (the scatter walks exactly these: one instance each); area[P] = 0
+__global__ __launch_bounds__(256) void k_det_area(int P, const uint2* __restrict__ rects, uint32_t* __restrict__ area) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g > P) return;
+  uint32_t a = 0;
+  if (g < P) {
+    const uint2 r = rects[g];
+    const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
+    a = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
+  }
+  area[g] = a;
+}
+// one workgroup per tile: the row of list position p (Gaussian g in tile (tx, ty)) = off[g] + the tile's index in g's rectangle
+__global__ __launch_bounds__(256) void k_det_rowidx(int gx, uint32_t capacity, const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ list, const uint2* __restrict__ rects,
+                                                    const uint32_t* __restrict__ off, uint32_t* __restrict__ rowidx) {
+  const int tile = blockIdx.x, tx = tile % gx, ty = tile / gx;
+  const uint32_t s = min(tile_start[tile], capacity), e = min(tile_start[tile + 1], capacity);
+  for (uint32_t p = s + threadIdx.x; p < e; p += 256) {
+    const uint32_t g = list[p];
+    const uint2 r = rects[g];
+    const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
+    rowidx[p] = off[g] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+  }
+}
+// twelve lanes per Gaussian (one per float of its GsGrad record; nine carry sums): the rows of its instances, contiguous from
+// off[g], added in rectangle order (y outer, x inner) — a fixed order.  Rows the backward never wrote are the zeros the memset left.
+__global__ __launch_bounds__(192) void k_det_gather(int P, uint32_t capacity, const uint32_t* __restrict__ off, const float* __restrict__ rows,
+                                                    GsGrad* __restrict__ grads) {
+  const int g = blockIdx.x * 16 + threadIdx.x / 12, c = threadIdx.x % 12;
+  if (g >= P) return;
+  const uint32_t r0 = min(off[g], capacity), r1 = min(off[g + 1], capacity);
+  float acc = 0.f;
+  for (uint32_t r = r0; r < r1; ++r) acc += rows[(size_t)r * 12 + c];
+  reinterpret_cast<float*>(grads + g)[c] = acc;
+}
+
 // per-tile max of n_contrib -> R_eff (roofline accounting only)
 __global__ __launch_bounds__(256) void k_frame_stats(int T, int gx, int W, int H, const uint32_t* __restrict__ tile_start,
                                                       const uint32_t* __restrict__ n_contrib, int64_t* __restrict__ stats) {
@@ -728,6 +777,26 @@ __global__ __launch_bounds__(256) void k_frame_stats(int T, int gx, int W, int H
 }
 
 }  // namespace
+
+int gs_launch_scan_large(hipStream_t, int, const uint32_t*, uint32_t*, uint32_t*, int32_t*);
+// deterministic mode, in front of the composite backward: rectangle areas -> row offsets -> the row of every list position; the
+// rows cleared.  scratch: DetScratchLayout(P) (uint32 words behind the gradient scratch's gate flags).
+int gs_launch_det_prepare(hipStream_t stream, int P, int T, int gx, uint32_t capacity, const uint32_t* tile_start, const uint32_t* list,
+                          const uint2* rects, char* det_scratch, uint32_t* rowidx, float* rows) {
+  const DetScratchLayout dl(P);
+  uint32_t* area = (uint32_t*)(det_scratch + dl.area);
+  uint32_t* off = (uint32_t*)(det_scratch + dl.off);
+  hipLaunchKernelGGL(k_det_area, dim3((P + 1 + 255) / 256), dim3(256), 0, stream, P, rects, area);
+  gs_launch_scan_large(stream, P + 1, area, off, (uint32_t*)(det_scratch + dl.block_sums), (int32_t*)(off + P + 1));
+  hipLaunchKernelGGL(k_det_rowidx, dim3(T), dim3(256), 0, stream, gx, capacity, tile_start, list, rects, off, rowidx);
+  if (hipMemsetAsync(rows, 0, (size_t)capacity * sizeof(GsGrad), stream) != hipSuccess) return -1;
+  return 0;
+}
+int gs_launch_det_gather(hipStream_t stream, int P, uint32_t capacity, const char* det_scratch, const float* rows, GsGrad* grads) {
+  const DetScratchLayout dl(P);
+  hipLaunchKernelGGL(k_det_gather, dim3((P + 15) / 16), dim3(192), 0, stream, P, capacity, (const uint32_t*)(det_scratch + dl.off), rows, grads);
+  return 0;
+}
 
 int gs_launch_frame_stats(hipStream_t stream, int T, int gx, int W, int H, const uint32_t* tile_start, const uint32_t* n_contrib,
                           int64_t* stats) {
@@ -776,18 +845,19 @@ int gs_launch_composite_bwd(hipStream_t stream, int gx, int W, int H, uint32_t c
                             const uint32_t* n_contrib, const float* dL_dpix, GsGrad* grads, const float* out_color,
                             const uint4* unit_tile, const float4* bstate, const uint32_t* meta,
                             uint32_t max_units, bool may_loop, const unsigned long long* hitmask, uint32_t max_chunks,
-                            const uint32_t* qmax, unsigned long long* counters) {
+                            const uint32_t* qmax, unsigned long long* counters, const uint32_t* det_rowidx, float* det_rows) {
   // whole blocks of launch positions (see the index transposition in the kernel); with GS_BW_HALF the one-chunk instantiation
   // takes two positions per unit
   const uint32_t per_unit = (GS_BW_HALF != 0 && !may_loop) ? 2u : 1u;
   const uint32_t blk = 8u * BW_XCD_RUN * per_unit;
   const dim3 grid((max_units * per_unit + blk - 1u) / blk * blk);
   // may_loop == false: a frame that fits this capacity has one-chunk units (count <= capacity), so the lean instantiation is safe
-#define GS_BWD(CH, CNT)                                                                                                               \
-  hipLaunchKernelGGL((k_composite_bwd<CH, CNT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
-                     n_contrib, dL_dpix, grads, out_color, unit_tile, bstate, meta, max_units, counters, hitmask, max_chunks, qmax)
-  if (counters) { if (!may_loop) GS_BWD(1, true); else GS_BWD(0, true); }
-  else { if (!may_loop) GS_BWD(1, false); else GS_BWD(0, false); }
+#define GS_BWD(CH, CNT, DT)                                                                                                           \
+  hipLaunchKernelGGL((k_composite_bwd<CH, CNT, DT>), grid, dim3(64 * BW_UNITS), 0, stream, gx, W, H, capacity, tile_start, list, recs, bg, final_T,  \
+                     n_contrib, dL_dpix, grads, out_color, unit_tile, bstate, meta, max_units, counters, hitmask, max_chunks, qmax, det_rowidx, det_rows)
+  if (det_rows) { if (!may_loop) GS_BWD(1, false, true); else GS_BWD(0, false, true); }
+  else if (counters) { if (!may_loop) GS_BWD(1, true, false); else GS_BWD(0, true, false); }
+  else { if (!may_loop) GS_BWD(1, false, false); else GS_BWD(0, false, false); }
 #undef GS_BWD
   return 0;
 }

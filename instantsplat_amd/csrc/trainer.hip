@@ -41,6 +41,7 @@ struct Trainer {
   uint32_t* adam_live;  // see MultiAdamArgs::live
   uint32_t adam_seq;
   bool consts_ready;
+  int det;         // the deterministic-backward knob at the same moment (it enters the layouts too)
   int min_units;   // the unit-length knob as it stood when the workspace was carved: every later call of the handle sizes and
                    // launches with THIS value, whatever mi355gs_tune_min_units has been set to since (the buffers were laid
                    // out for it)
@@ -179,6 +180,7 @@ void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float
   }
   t->pplr = per_point_lr;
   t->min_units = gs_min_units();
+  t->det = gs_deterministic();
   carve(*t, workspace);
   t->consts_ready = false;
   return t;
@@ -212,12 +214,13 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     t->consts_ready = true;
   }
   struct HookScope {
-    HookScope(float* gate, const GsPrologue& pro, const GsPosed& posed, int min_units) {
+    HookScope(float* gate, const GsPrologue& pro, const GsPosed& posed, int min_units, int det) {
       gs_pin_min_units(min_units);
+      gs_pin_deterministic(det);
       g_fused.skip_memsets = true; g_fused.gate = gate; g_fused.prologue = pro; g_fused.posed = posed;
       g_fused.gate_xyz = 0; g_fused.gate_sh = 1; g_fused.gate_sh_rest = 2; g_fused.gate_opacity = 3; g_fused.gate_scaling = 4; g_fused.gate_rot = 5; g_fused.gate_pose = 6;
     }
-    ~HookScope() { g_fused = GsFusedStepHooks(); gs_pin_min_units(0); }
+    ~HookScope() { g_fused = GsFusedStepHooks(); gs_pin_min_units(0); gs_pin_deterministic(-1); }
   };
   GsPrologue pro;  // the step's accumulators are cleared by its first kernel (k_pose_fwd)
   {
@@ -228,7 +231,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   }
   GsPosed posed;
   posed.pose = t->poses + 7 * (size_t)view; posed.acc = t->pose_scratch; posed.partial = t->pose_partial;
-  HookScope hook_scope(t->adam_scratch, pro, posed, t->min_units);
+  HookScope hook_scope(t->adam_scratch, pro, posed, t->min_units, t->det);
   const float* view_m = t->consts;
   const float* campos = t->consts + 16;
   const float* pose = t->poses + 7 * (size_t)view;

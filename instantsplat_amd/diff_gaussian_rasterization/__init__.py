@@ -229,6 +229,17 @@ def grad_scratch_bytes(L, P):
     return n
 
 
+def set_deterministic(on: bool) -> bool:
+    """Deterministic-backward mode (include/mi355gs.h, mi355gs_tune_deterministic): the backward sums every Gaussian's moments in a
+    fixed order instead of with float atomics — bit-identical gradients, and with them bit-identical training runs, at the cost
+    of a few launches and 52 B per instance per backward.  Process-wide; it enters the scratch sizes, so frames in flight must be
+    finished first (call it between iterations) and a one-call trainer handle must be re-created (instantsplat_amd.train does
+    that: `release_trainer`).  Also switched on by MI355GS_DETERMINISTIC=1 in the environment.  Returns the previous setting."""
+    old = bool(_lib.lib().mi355gs_tune_deterministic(1 if on else 0))
+    _GRAD_SCRATCH.clear()
+    return old
+
+
 def frame_buffers(L, P, W, H, dev):
     """Per-frame outputs and workspaces of the forward: (radii, color, geom, tiles, num_rendered).  None is pre-filled: the
     projection kernel writes every radius (0 for a culled Gaussian) and the tile scan writes the instance count, so the two

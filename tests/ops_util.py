@@ -1581,3 +1581,51 @@ def check_lazy_loss_expression(dev, H=40, W=56):
     assert type(l1_loss(img.detach(), gt)) is torch.Tensor
     assert type(fused_ssim(img.unsqueeze(0), gt.unsqueeze(0), train=False)) is torch.Tensor
     lazy_loss.forget()
+
+
+def check_deterministic_backward(dev, iters=12, Wm=20, W=64, H=48, min_units=None):
+    """mi355gs_tune_deterministic(1): every Gaussian's moments are summed in the order of its tile rectangle instead of with float
+    atomics.  (1) The gradients of one frame equal the default path's to rounding, through the operator and through render();
+    (2) two backward passes of the same frame are BIT-identical (on the GPU the default path's are not); (3) two training runs
+    of the same scene — the drop-in loop and the one-call loop — are bit-identical after `iters` iterations."""
+    import instantsplat_amd.diff_gaussian_rasterization as dgr
+    from instantsplat_amd import _lib
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import release_trainer, setup_training, train_iteration
+    from tests.util import relerr, run_blob_case
+    L = _lib.lib()
+    old_units = L.mi355gs_tune_min_units(min_units) if min_units else None
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P")
+    try:
+        base = run_blob_case(dev, 900, 96, 64, 2)["dut"]
+        was = dgr.set_deterministic(True)
+        assert was is False
+        try:
+            a = run_blob_case(dev, 900, 96, 64, 2)["dut"]
+            b = run_blob_case(dev, 900, 96, 64, 2)["dut"]
+            assert torch.equal(a["color"], base["color"]) and torch.equal(a["radii"], base["radii"])
+            for k in base["grads"]:
+                assert torch.equal(a["grads"][k], b["grads"][k]), k                    # run to run: the same bits
+                bound("deterministic/grad_" + k, relerr(a["grads"][k], base["grads"][k]), 2e-6)   # against the atomics: rounding
+
+            def run(fused_step):
+                st = generic_start(setup_training(syn_pointmap(3, Wm, Wm, W, H, seed=2), dev))
+                losses = [train_iteration(st, fused_step=fused_step) for _ in range(iters)]
+                release_trainer(st)
+                dgr.BinningPolicy.reset("exact")
+                return losses, [getattr(st.gaussians, n).detach().cpu().clone() for n in names]
+            for fused_step in (False, True):
+                l1, p1 = run(fused_step)
+                l2, p2 = run(fused_step)
+                assert l1 == l2, (fused_step, l1, l2)
+                for n, x, y in zip(names, p1, p2):
+                    assert torch.equal(x, y), (fused_step, n)
+        finally:
+            dgr.set_deterministic(False)
+        # ... and the default path is back, untouched
+        c = run_blob_case(dev, 900, 96, 64, 2)["dut"]
+        for k in base["grads"]:
+            bound("deterministic/default_path_after/" + k, relerr(c["grads"][k], base["grads"][k]), 2e-6 if torch.device(dev).type == "cuda" else 0.0)
+    finally:
+        if old_units:
+            L.mi355gs_tune_min_units(old_units)

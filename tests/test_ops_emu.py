@@ -268,3 +268,11 @@ def test_render_only_forward_is_bit_identical(emu):
 
 def test_lazy_loss_expression(emu):
     ops_util.check_lazy_loss_expression(emu)
+
+
+def test_deterministic_backward(emu):
+    ops_util.check_deterministic_backward(emu, iters=3)
+
+
+def test_deterministic_backward_multi_chunk_units(emu):
+    ops_util.check_deterministic_backward(emu, iters=2, min_units=4)

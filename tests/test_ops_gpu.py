@@ -179,3 +179,11 @@ def test_lazy_loss_expression(gpu):
 
 def test_lazy_loss_expression_at_bench_size(gpu):
     ops_util.check_lazy_loss_expression(gpu, H=512, W=512)
+
+
+def test_deterministic_backward(gpu):
+    ops_util.check_deterministic_backward(gpu)
+
+
+def test_deterministic_backward_multi_chunk_units(gpu):
+    ops_util.check_deterministic_backward(gpu, iters=4, min_units=4)

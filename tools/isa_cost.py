@@ -36,7 +36,7 @@ def bwd_model(path):
     "init", everything else inside the loop = "step"; everything outside the loop = "wave" (prologue / epilogue, once per
     unit).  The loop is unrolled by two (ping-pong record registers): every part is averaged over its copies."""
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "k_composite_bwdILi1ELb0" in l and ":" in l and not l.startswith("\t"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "k_composite_bwdILi1ELb0ELb0" in l and ":" in l and not l.startswith("\t"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     blocks, cur = [], []
     for l in lines[start:end + 1]:
@@ -82,7 +82,7 @@ def bwd_model(path):
         1 for b in blocks[first:last + 1] if len(valu(b)) >= 8 and all(t.split()[0].startswith("v_mov_b32") for t in valu(b)))), "wave": 1}
     import json
     out = {"INS": {k: parts[k][0] / per[k] for k in parts}, "CYC": {k: parts[k][1] / per[k] for k in parts},
-           "loop_copies": copies, "source": "hipcc -S of instantsplat_amd/csrc/composite.hip, k_composite_bwd<1, false>; tools/isa_cost.py --bwd-model",
+           "loop_copies": copies, "source": "hipcc -S of instantsplat_amd/csrc/composite.hip, k_composite_bwd<1, false, false>; tools/isa_cost.py --bwd-model",
            "note": "init = the peeled initialisation of the nine moments: runs once per step in which the first quadrant body does not"}
     print(json.dumps(out))
 
@@ -95,7 +95,7 @@ def fwd_model(path):
     but the last group of a tile), "wave" = everything outside (prologue: unit table, first gather; epilogue: remaining boundary
     records, quadrant maximum, pixel stores)."""
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "k_composite_fwdILi4ELb0" in l and ":" in l and not l.startswith("\t"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "k_composite_fwdILi4ELb0ELb1" in l and ":" in l and not l.startswith("\t"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     blocks, cur, lab = [], [], "entry"
     for l in lines[start:end + 1]:
@@ -130,7 +130,7 @@ def fwd_model(path):
         parts[k][0] += len(v); parts[k][1] += sum(cost(t.split()[0], t)[0] for t in v)
     import json
     print(json.dumps({"INS": {k: parts[k][0] for k in parts}, "CYC": {k: parts[k][1] for k in parts}, "hits_per_step": 2,
-                      "source": "hipcc -S of instantsplat_amd/csrc/composite.hip, k_composite_fwd<4, false>; tools/isa_cost.py --fwd-model"}))
+                      "source": "hipcc -S of instantsplat_amd/csrc/composite.hip, k_composite_fwd<4, false, true>; tools/isa_cost.py --fwd-model"}))
 
 
 def main():
