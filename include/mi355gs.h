@@ -378,8 +378,9 @@ int mi355gs_posed_backward(void* stream, int P, int D, int W, int H, const float
  *   those of the truncated frame.  The gate is STICKY (ABI v8): once a step of a handle has discarded itself, every later
  *   do_optimizer_step = 1 step of that handle discards itself too, whatever its own count — so a caller that enqueues many steps
  *   ahead of its reads of the counts finds parameters and moments exactly as the last step BEFORE the first overflow left them,
- *   needs no snapshot to return to, and continues from there (with larger buffers, i.e. a new handle, or after
- *   mi355gs_trainer_rearm).  (mi355gs_trainer_optimizer_step, below, is gated only if asked to be.)
+ *   needs no snapshot to return to, and continues from there with larger buffers, i.e. a new handle (ABI v9 dropped
+ *   mi355gs_trainer_rearm: no caller keeps a handle whose buffers a frame has outgrown).  (mi355gs_trainer_optimizer_step, below,
+ *   is gated only if asked to be.)
  *   lr[7], step[7] (1-based Adam step of each group): host arrays.  loss_out: device float[1].
  * ---------------------------------------------------------------------------------------------- */
 size_t mi355gs_trainer_workspace_bytes(int P, int W, int H, int V, int64_t capacity);
@@ -389,8 +390,6 @@ void* mi355gs_trainer_create(int P, int W, int H, int V, int64_t capacity, float
 int mi355gs_trainer_step(void* trainer, void* stream, int view, int sh_degree, const float* gt_image, const float* projmatrix,
                          float tanfovx, float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
                          float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out);
-/* Re-arms the commit gate of a handle whose step overflowed (stream-ordered: steps enqueued after it commit again). */
-int mi355gs_trainer_rearm(void* trainer, void* stream);
 /* PerPointAdam over all 7 groups with the gradients left by the last mi355gs_trainer_step(..., do_optimizer_step = 0):
  * lets a caller inspect the loss / instance count of an iteration before committing its update (commit_gate = 0: the caller's
  * own decision, not gated) — or, commit_gate = 1 (ABI v8), split an iteration in two enqueues without having seen the count:

@@ -66,7 +66,6 @@ _SIGNATURES = {
     "mi355gs_l1_loss_forward": (c_int, [_P, c_int64, _P, _P, _P, _P]),
     "mi355gs_l1_loss_backward": (c_int, [_P, c_int64, _P, _P, _P, _P]),
     "mi355gs_trainer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
-    "mi355gs_trainer_rearm": (c_int, [_P, _P]),
     "mi355gs_trainer_create": (c_void_p, [c_int, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi355gs_trainer_step": (c_int, [_P, _P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_float, c_float, c_float, c_float,
                                      c_int, _P, _P]),

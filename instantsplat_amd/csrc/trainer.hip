@@ -263,12 +263,6 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
   return MI355GS_OK;
 }
 
-int mi355gs_trainer_rearm(void* handle, void* stream_) {
-  Trainer* t = (Trainer*)handle;
-  if (!t) return MI355GS_EINVAL;
-  return hipMemsetAsync(t->adam_live + 15, 0, sizeof(uint32_t), (hipStream_t)stream_) == hipSuccess ? MI355GS_OK : MI355GS_ELAUNCH;
-}
-
 int mi355gs_trainer_optimizer_step(void* handle, void* stream_, const float* lr, const int32_t* step, float beta1, float beta2,
                                    float eps, int commit_gate) {
   Trainer* t = (Trainer*)handle;

@@ -219,9 +219,9 @@ struct BackwardFollows {
 };
 
 // The all-zero gradient of `f_rest` below its SH degree (what the reference's cat(f_dc, f_rest) backward produces: 35 MB of
-// zeros per iteration at C3, filled by a kernel every backward).  ONE persistent zero buffer per (device, shape) is handed
+// zeros per iteration at C3, filled by a kernel every backward).  ONE persistent zero buffer per parameter (device, shape, address of its memory) is handed
 // to autograd instead, as a fresh alias each time: AccumulateGrad takes it over without a copy (use count 1, dense), the
-// optimizer reads zeros, zero_grad(set_to_none=True) drops the alias.  Aliases share the buffer's version counter, so any
+// optimizer reads zeros, zero_grad(set_to_none=True) drops the alias.  (Keyed on the parameter's own memory: see zero_grad_like.)  Aliases share the buffer's version counter, so any
 // in-place operation on such a `.grad` (accumulation over two backward passes, clipping, zero_grad(set_to_none=False), an
 // all-reduce) is seen here as a changed version and the buffer is zeroed again before its next use.  Writes BEHIND the
 // version counter (`.grad.data`, raw pointers) are the caller's to declare: mi355gs shared_zero_grad(false)
@@ -232,8 +232,10 @@ std::map<std::string, ZeroGrad> g_zero_pool;
 bool g_share_zero_grad = true;
 Tensor zero_grad_like(const Tensor& like) {
   if (!g_share_zero_grad) return at::zeros_like(like);
+  // one buffer per PARAMETER (its memory's address), not per shape: two models of the same size in one process — teacher and
+  // student, a deep copy, two scenes — must not find each other's writes in their `.grad`
   std::ostringstream key;
-  key << like.device() << ":" << like.sizes();
+  key << like.device() << ":" << like.sizes() << "@" << like.data_ptr();
   std::lock_guard<std::mutex> lock(g_zero_mutex);
   if (g_zero_pool.size() > 8 && !g_zero_pool.count(key.str())) g_zero_pool.clear();   // (shapes come and go: a handful of scenes at most)
   ZeroGrad& z = g_zero_pool[key.str()];

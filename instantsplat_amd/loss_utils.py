@@ -86,11 +86,20 @@ def l1_loss_mask(network_output, gt, mask):
 
 def ssim(img1, img2, window_size=11, size_average=True):
     """The reference's conv2d SSIM (zero padding, 11x11 Gaussian window of sigma 1.5) = fused_ssim(padding="same")."""
-    if window_size == 11 and size_average and img1.dtype == torch.float32:
+    if window_size == 11 and size_average and _fused_ssim_can_take(img1, img2):
         a = img1 if img1.dim() == 4 else img1.unsqueeze(0)
         b = img2 if img2.dim() == 4 else img2.unsqueeze(0)
         return fused_ssim(a, b)
     return _ssim_conv2d(img1, img2, window_size, size_average)
+
+
+def _fused_ssim_can_take(img1, img2):
+    """The fused kernel differentiates with respect to img1 only, takes float32 and has no CPU path: anything else (a second
+    image that wants a gradient, CPU tensors, other dtypes, mismatched shapes) goes through the reference's own conv2d
+    expression below — the same results as reference utils/loss_utils.py for every input it accepts."""
+    return (isinstance(img1, torch.Tensor) and isinstance(img2, torch.Tensor) and img1.dtype == torch.float32 and img2.dtype == torch.float32
+            and img1.shape == img2.shape and img1.dim() in (3, 4) and img1.device == img2.device and (img1.is_cuda or _lib._TEST_MODE)
+            and not (img2.requires_grad and torch.is_grad_enabled()))
 
 
 def gaussian(window_size, sigma):

@@ -224,10 +224,19 @@ def load_init_scene(source_path: str, n_views: int, images: Optional[str] = None
         shutil.copyfile(info.ply_path, os.path.join(model_path, "input.ply"))
         with open(os.path.join(model_path, "cameras.json"), "w") as f:
             json.dump([camera_to_json(i, c) for i, c in enumerate(list(info.test_cameras) + list(info.train_cameras))], f)
-    train_infos, test_infos = list(info.train_cameras), list(info.test_cameras)
-    if shuffle:
-        rng.shuffle(train_infos)
-        rng.shuffle(test_infos)
+    # reference scene/__init__.py:67-69 shuffles scene_info.train_cameras, then scene_info.test_cameras.  Under --eval the reader
+    # returns ONE list object as both (dataset_readers.py:343-346), so that list is shuffled twice and both camera lists are built
+    # from the twice-shuffled order (uid, the pose-table row and the view sampling follow it).
+    if info.test_cameras is info.train_cameras:
+        train_infos = test_infos = list(info.train_cameras)
+        if shuffle:
+            rng.shuffle(train_infos)
+            rng.shuffle(train_infos)
+    else:
+        train_infos, test_infos = list(info.train_cameras), list(info.test_cameras)
+        if shuffle:
+            rng.shuffle(train_infos)
+            rng.shuffle(test_infos)
     extent = float(info.nerf_normalization["radius"])
     cams = [load_cam(c, i, resolution, 1.0, device) for i, c in enumerate(train_infos)]
     test_cams = [load_cam(c, i, resolution, 1.0, device) for i, c in enumerate(test_infos)]
@@ -283,7 +292,7 @@ def rotmat2qvec(R: np.ndarray) -> np.ndarray:
 def write_init_scene(source_path: str, w2c: List[np.ndarray], fovs, images: List[torch.Tensor], points: torch.Tensor, colors: torch.Tensor,
                      confidence: Optional[torch.Tensor], names: Optional[List[str]] = None, subdir: str = "0") -> None:
     """The layout of Appendix F for V views: `w2c[v]` [4,4], `fovs[v]` = (FoVx, FoVy), `images[v]` float [3,H,W] in [0,1]
-    (stored as 8-bit PNG), points / colours [N,3], confidence [N,1] or None."""
+    (stored as 8-bit PNG) or the path of an image file (copied under `names[v]`), points / colours [N,3], confidence [N,1] or None."""
     from PIL import Image
     V = len(w2c)
     names = names or [f"{v:04d}.png" for v in range(V)]
@@ -292,10 +301,17 @@ def write_init_scene(source_path: str, w2c: List[np.ndarray], fovs, images: List
     os.makedirs(os.path.join(source_path, "images"), exist_ok=True)
     cams, imgs = {}, {}
     for v in range(V):
-        H, W = int(images[v].shape[1]), int(images[v].shape[2])
+        if isinstance(images[v], (str, os.PathLike)):   # an image FILE (a photograph, a video frame): copied as it is, decoded by the loader
+            with Image.open(images[v]) as im:
+                W, H = im.size
+        else:
+            H, W = int(images[v].shape[1]), int(images[v].shape[2])
         m = np.asarray(w2c[v], dtype=np.float64)
         cams[v + 1] = iof.ColmapCamera(v + 1, "PINHOLE", W, H, np.array([fov2focal(fovs[v][0], W), fov2focal(fovs[v][1], H), W / 2, H / 2]))
         imgs[v + 1] = iof.ColmapImage(v + 1, rotmat2qvec(m[:3, :3]), m[:3, 3].copy(), v + 1, names[v])
+        if isinstance(images[v], (str, os.PathLike)):
+            shutil.copyfile(images[v], os.path.join(source_path, "images", names[v]))
+            continue
         arr = (images[v].detach().cpu().clamp(0, 1).permute(1, 2, 0).numpy() * 255.0).round().astype(np.uint8)
         Image.fromarray(arr).save(os.path.join(source_path, "images", names[v]))
     iof.write_cameras_text(os.path.join(sparse, "cameras.txt"), cams)

@@ -202,6 +202,7 @@ def release_trainer(st: TrainState):
 
 
 WAIT_WITH_EVENT = False   # A/B switch: True = an event recorded behind every iteration's backward (the first form of the loop)
+_WAIT = {"timeout_us": 50_000, "ema_us": None}   # spin limit of _wait_for_words and the moving average of the waits it is scaled from
 _NOT_YET = -2   # as float32 a NaN with a payload no arithmetic produces; as a count impossible
 
 
@@ -212,7 +213,14 @@ def _wait_for_words(words: torch.Tensor, dev):
     synchronize would also wait for the NEXT iteration's forward + backward, which are already enqueued."""
     ext = _lib.compiled()
     if ext is not None:
-        ext.wait_for_words(words, _NOT_YET, _device_token(dev), 50_000)
+        # the spin is bounded by a few times what an iteration has been taking (a frame of 1 M Gaussians at 1080p takes milliseconds,
+        # a shared GPU more): past that the fallback — a stream synchronize, which also waits for iteration t + 1's forward and
+        # backward — is the exception it is meant to be, not a per-iteration cost
+        t0 = time.perf_counter()
+        ext.wait_for_words(words, _NOT_YET, _device_token(dev), _WAIT["timeout_us"])
+        dt_us = 1e6 * (time.perf_counter() - t0)
+        _WAIT["ema_us"] = dt_us if _WAIT["ema_us"] is None else 0.9 * _WAIT["ema_us"] + 0.1 * dt_us
+        _WAIT["timeout_us"] = int(min(max(50_000, 8 * _WAIT["ema_us"]), 5_000_000))
         return
     for spin in range(200_000):
         if int(words[0]) != _NOT_YET and int(words[1]) != _NOT_YET:
@@ -671,7 +679,14 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
         from .scene_io import load_init_scene
         if n_views is None:
             raise ValueError("training(<source_path>) needs n_views (the sparse_<n_views> directory to read)")
-        scene = load_init_scene(os.fspath(scene), n_views, resolution=resolution, device=device, model_path=model_path)
+        # the ModelParams fields that decide WHAT is read (reference arguments/__init__.py:47-62, scene/__init__.py:42-44) are
+        # honoured here, so that the cfg_args written below describes the scene that was actually loaded
+        mp_ = model or ModelParams()
+        if resolution == 1 and mp_.resolution not in (None, 1, -1):
+            resolution = mp_.resolution
+        scene = load_init_scene(os.fspath(scene), n_views, images=(None if mp_.images in (None, "", "images") else mp_.images), eval=bool(mp_.eval),
+                                resolution=resolution, device=device, model_path=model_path,
+                                init_scale_from_view_depth=bool(mp_.init_scale_from_view_depth))
     if model_path:   # reference train.py:233-246 (prepare_output_and_logger): the run's arguments next to its outputs
         os.makedirs(model_path, exist_ok=True)
         from .arguments import cfg_args_text

@@ -251,7 +251,6 @@ def test_new_entry_points_reject_bad_arguments():
     assert L.mi355gs_l1_loss_forward(None, 16, None, p, p, p) == EINVAL and L.mi355gs_l1_loss_forward(None, 16, p, p, None, p) == EINVAL
     assert L.mi355gs_l1_loss_backward(None, -3, p, p, p, p) == EINVAL and L.mi355gs_l1_loss_backward(None, 16, p, p, None, p) == EINVAL
     assert L.mi355gs_l1_scratch_bytes(0) >= 8 and L.mi355gs_l1_scratch_bytes(3 * 1080 * 1920) >= 8 * ((3 * 1080 * 1920 + 4095) // 4096)
-    assert L.mi355gs_trainer_rearm(None, None) == EINVAL
     F7, I7 = ctypes.c_float * 7, ctypes.c_int32 * 7
     assert L.mi355gs_trainer_optimizer_step(None, None, F7(), I7(), 0.9, 0.999, 1e-15, 1) == EINVAL
     # mi355gs_posed_backward(..., d_pose, pose_rows, pose_row, ...): a row outside its table, a negative table

@@ -36,6 +36,24 @@ def test_scene_info_matches_reference_reader():
     assert np.array_equal(np.stack(info.train_poses), G["initdir_info_poses"]) and info.test_cameras == [] and info.test_poses == []
 
 
+def test_eval_camera_order_matches_reference_scene(tmp_path):
+    """--eval: the reader hands back ONE list as train and test cameras, the reference's Scene shuffles it twice and builds both
+    camera lists from that order (tests/golden/make_golden_eval_order.py ran its Scene.__init__ on this directory)."""
+    import shutil
+    E = np.load(os.path.join(HERE, "golden", "eval_order_vectors.npz"))
+    src = tmp_path / "scene"
+    shutil.copytree(SCENE, src)
+    os.makedirs(src / f"sparse_{V}" / "1")
+    for f in ("cameras.txt", "images.txt"):
+        shutil.copyfile(src / f"sparse_{V}" / "0" / f, src / f"sparse_{V}" / "1" / f)
+    sc = scene_io.load_init_scene(str(src), V, eval=True, resolution=2, device="cpu")
+    for kind, cams in (("train", sc.cameras), ("test", sc.test_cameras)):
+        assert [c.image_name for c in cams] == list(E[f"eval_{kind}_names"]), kind
+        assert [[c.uid, c.colmap_id] for c in cams] == E[f"eval_{kind}_uid_colmap"].tolist(), kind
+    assert [sc.rng.randint(0, 10 ** 6) for _ in range(4)] == list(E["eval_rng_next"])
+    assert list(E["eval_train_names"]) != list(G["initdir_cam_r2_names"])   # (the twice-shuffled order is not the once-shuffled one)
+
+
 @pytest.mark.parametrize("res", [1, 2])
 def test_cameras_match_reference_scene(tmp_path, res):
     sc = scene_io.load_init_scene(SCENE, V, resolution=res, device="cpu", model_path=str(tmp_path))
