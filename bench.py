@@ -363,7 +363,7 @@ def main():
     dev_sync()
     tot_ms, n = ctypes.c_double(), ctypes.c_int()
     kern = {}
-    for kind, name in ((0, "composite_fwd"), (1, "composite_bwd")):
+    for kind, name in ((0, "composite_fwd"), (1, "composite_bwd"), (3, "l1_ssim_fused"), (4, "sort_tiles"), (5, "count_tiles_lds")):
         _lib.check(L.mi355gs_profile_read(kind, ctypes.byref(tot_ms), ctypes.byref(n)), "profile_read")
         kern[name] = (tot_ms.value / max(n.value, 1), n.value)
     L.mi355gs_profile_end()
@@ -601,6 +601,64 @@ def main():
     except Exception:
         valu = None
 
+    # ---- the three largest kernels of the small-kernel tail (a third of the iteration is nine kernels of 5-17 us): HBM roofline from
+    # this run's event times and each kernel's algorithmic bytes, and WHY it is not on that roofline from the SQ counters of a
+    # committed PMC pass of this command — SQ_WAIT_ANY (waves parked at s_waitcnt / a barrier) + SQ_WAIT_INST_ANY (issue stalls) +
+    # SQ_ACTIVE_INST_ANY (issuing) ~ SQ_WAVE_CYCLES (disjoint; MI355X_MICROARCH.md, PMC slots)
+    P_ = float(P)
+    R_ = sum(Rs) / len(Rs)
+    T_ = float(((res + 15) // 16) ** 2)
+    small_defs = (
+        ("k_l1_ssim_fused", "l1_ssim_fused", 36.0 * res * res,
+         "36 B per pixel: both images read once (2 x 3 channels x 4 B), dloss/dimage written once (3 x 4 B) — the fused single pass; "
+         "SURVEY.md 8d prices the two-kernel formulation it replaces at 72 + 84 + 36 = 192 B per pixel"),
+        ("k_sort_tiles", "sort_tiles", 12.0 * R_ + 8.0 * T_,
+         "12 B per instance (8 B key read, 4 B sorted index written) + 8 B per tile of ranges — the per-tile sort of this design; "
+         "SURVEY.md 8d prices the reference's device-wide radix sort at 152 B per instance"),
+        ("k_count_tiles_lds", "count_tiles_lds", 8.0 * P_ + 4.0 * T_,
+         "8 B per Gaussian (its tile rectangle) + 4 B per tile (the count): part of SURVEY.md 8d's K3 (20 B per Gaussian + 12 B per instance "
+         "for count + scatter together)"))
+    small = {}
+    sq_tab, sq_src, fr5, wr5 = {}, None, {}, {}
+    for rnd in ("r05", "r04"):
+        try:
+            sq_tab = pmc_rows(f"{rnd}_pmc_c3_SQ_wait_counters.csv")
+            sq_src = f"profiles/{rnd}_pmc_c3_SQ_wait_counters.csv"
+            break
+        except OSError:
+            continue
+    for rnd in ("r05", "r04", "r03"):
+        try:
+            fr5, wr5 = pmc_rows(f"{rnd}_pmc_c3_FETCH_SIZE.csv"), pmc_rows(f"{rnd}_pmc_c3_WRITE_SIZE.csv")
+            break
+        except OSError:
+            continue
+    for kname, key, abytes, what in small_defs:
+        ms, nl = kern.get(key, (0.0, 0))
+        ent = {"avg_kernel_ms": ms, "launches": nl, "algorithmic_bytes_per_launch": abytes, "algorithmic_bytes": what,
+               "achieved": abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+               "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0, "traffic": None, "counters": None, "bound": None}
+        try:
+            ent["traffic"] = (2.0 * float(fr5[kname]["mean_FETCH_SIZE"]) + float(wr5[kname]["mean_WRITE_SIZE"])) * 1024.0
+        except (KeyError, ValueError):
+            pass
+        row = sq_tab.get(kname)
+        if row:
+            try:
+                wc = float(row["mean_SQ_WAVE_CYCLES"])
+                parked, stalled, active = float(row["mean_SQ_WAIT_ANY"]) / wc, float(row["mean_SQ_WAIT_INST_ANY"]) / wc, float(row["mean_SQ_ACTIVE_INST_ANY"]) / wc
+                valu = float(row["mean_SQ_ACTIVE_INST_VALU"]) / wc
+                ent["counters"] = {"source": sq_src, "wave_cycles_parked_frac": parked, "wave_cycles_issue_stalled_frac": stalled,
+                                   "wave_cycles_issuing_frac": active, "wave_cycles_issuing_valu_frac": valu,
+                                   "valu_wave_instructions_per_launch": float(row["mean_SQ_INSTS_VALU"]),
+                                   "waves_per_launch": float(row["mean_SQ_WAVES"]),
+                                   "busy_cycles_per_launch": float(row["mean_SQ_BUSY_CYCLES"])}
+                ent["bound"] = ("latency: waves parked at s_waitcnt / barriers" if parked >= max(stalled, active) else
+                                ("issue stalls (LDS / dependent instructions)" if stalled >= active else "instruction issue"))
+            except (KeyError, ValueError, ZeroDivisionError):
+                pass
+        small[kname] = ent
+
     cpu_baseline = None
     if cpu_trainer is not None:
         from oracle import gs_ref
@@ -721,6 +779,7 @@ def main():
                                            "traffic": fwd_traffic, "compute": fwd_compute,
                                            "note": "traffic above the algorithmic bytes: the forward leaves a 16 B/pixel boundary record per "
                                                    "64-instance unit of every tile for the segmented backward (DESIGN.md 4.2b)"},
+                         "small_kernels": small,
                          "render_only": {"kernel": "k_composite_fwd<.., TRAIN = false> (mi355gs_raster_forward_render_only: every no-grad render)",
                                          "avg_kernel_ms": ro_ms, "launches": ro_n, "algorithmic_bytes_per_launch": fwd_bytes,
                                          "achieved": fwd_bytes / (ro_ms * 1e-3) / 1e9 if ro_ms > 0 else 0.0,

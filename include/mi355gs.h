@@ -172,7 +172,8 @@ int mi355gs_tune_scale_grad(int mode);
 /* Optional in-library kernel timing with HIP events recorded on the launch stream, so a caller that
  * cannot see the kernels (they are enqueued inside this library) can still attribute time to them.
  * kind: 0 = composite forward (training instantiation), 1 = composite backward, 2 = composite forward, render-only
- * instantiation.  profile_read synchronises the recorded events
+ * instantiation, 3 = the fused L1 + SSIM loss pass (k_l1_ssim_fused), 4 = the per-tile sort (k_sort_tiles), 5 = the per-tile
+ * instance count (k_count_tiles_lds).  profile_read synchronises the recorded events
  * and returns the summed milliseconds and launch count since profile_begin. */
 int mi355gs_profile_begin(void);
 /* Time only every `every`-th launch of a kind (default 1: all).  An event pair costs ~3.5 us of stream time, which matters when

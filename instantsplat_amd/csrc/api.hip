@@ -28,34 +28,34 @@ int gs_launch_frame_stats(hipStream_t, int, int, int, int, const uint32_t*, cons
 
 // ---- optional per-kernel timing (HIP events on the launch stream)
 namespace {
-constexpr int PROF_KINDS = 3, PROF_MAX = 8192;   // composite forward, composite backward, render-only composite forward
+constexpr int PROF_KINDS = 6, PROF_MAX = 8192;   // include/mi355gs.h, mi355gs_profile_read: composite forward / backward / render-only
+                                                 // forward, fused L1+SSIM loss pass, per-tile sort, per-tile count
 struct ProfState {
   bool on = false;
   unsigned long long* work_counters = nullptr;   // device uint64[16] or null (mi355gs_profile_work_counters)
   hipEvent_t ev[PROF_KINDS][PROF_MAX][2];
-  int created[PROF_KINDS] = {0, 0, 0};
-  int used[PROF_KINDS] = {0, 0, 0};
+  int created[PROF_KINDS] = {};
+  int used[PROF_KINDS] = {};
   int period = 1;                   // events go around every period-th launch of a kind (mi355gs_profile_set_period)
-  int seen[PROF_KINDS] = {0, 0, 0};   // launches of the kind since profile_begin
+  int seen[PROF_KINDS] = {};       // launches of the kind since profile_begin
 } g_prof;
-struct ProfScope {
-  hipStream_t s; hipEvent_t stop; bool active = false;
-  ProfScope(int kind, hipStream_t stream) : s(stream) {
-    if (!g_prof.on || g_prof.used[kind] >= PROF_MAX) return;
-    if (g_prof.seen[kind]++ % g_prof.period != 0) return;
-    const int i = g_prof.used[kind];
-    if (i >= g_prof.created[kind]) {
-      if (hipEventCreate(&g_prof.ev[kind][i][0]) != hipSuccess || hipEventCreate(&g_prof.ev[kind][i][1]) != hipSuccess) return;
-      g_prof.created[kind] = i + 1;
-    }
-    (void)hipEventRecord(g_prof.ev[kind][i][0], s);
-    stop = g_prof.ev[kind][i][1];
-    g_prof.used[kind] = i + 1;
-    active = true;
-  }
-  ~ProfScope() { if (active) (void)hipEventRecord(stop, s); }
-};
 }  // namespace
+
+GsProfScope::GsProfScope(int kind, hipStream_t stream) : s(stream) {
+  if (!g_prof.on || kind < 0 || kind >= PROF_KINDS || g_prof.used[kind] >= PROF_MAX) return;
+  if (g_prof.seen[kind]++ % g_prof.period != 0) return;
+  const int i = g_prof.used[kind];
+  if (i >= g_prof.created[kind]) {
+    if (hipEventCreate(&g_prof.ev[kind][i][0]) != hipSuccess || hipEventCreate(&g_prof.ev[kind][i][1]) != hipSuccess) return;
+    g_prof.created[kind] = i + 1;
+  }
+  (void)hipEventRecord(g_prof.ev[kind][i][0], s);
+  stop = g_prof.ev[kind][i][1];
+  g_prof.used[kind] = i + 1;
+  active = true;
+}
+GsProfScope::~GsProfScope() { if (active) (void)hipEventRecord(stop, s); }
+typedef GsProfScope ProfScope;
 
 thread_local GsFusedStepHooks g_fused;
 

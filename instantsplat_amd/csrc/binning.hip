@@ -791,9 +791,11 @@ int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t
 int gs_launch_count_tiles(hipStream_t stream, int P, int T, int gx, const uint2* rects, uint32_t* tile_count, uint32_t* entries,
                           uint32_t* entry_n) {
   if (P <= 0) return 0;
-  if (T <= BIN_MAX_LDS_TILES)
+  if (T <= BIN_MAX_LDS_TILES) {
+    GsProfScope prof(5, stream);
     hipLaunchKernelGGL(k_count_tiles_lds, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(256), (size_t)T * 4, stream, P, T, gx, rects, tile_count,
                        entries, entry_n);
+  }
   else
     hipLaunchKernelGGL(k_count_tiles_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, rects, tile_count);
   return 0;
@@ -808,6 +810,9 @@ int gs_launch_binning(hipStream_t stream, int P, int T, int gx, const float* dep
                        start, cursor, keys, capacity, entries, entry_n);
   else
     hipLaunchKernelGGL(k_scatter_direct, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, depths, rects, start, cursor, keys, capacity);
-  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order);
+  {
+    GsProfScope prof(4, stream);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(SORT_THREADS), 0, stream, T, start, keys, list, capacity, order);
+  }
   return 0;
 }

@@ -307,6 +307,14 @@ __device__ __forceinline__ uint32_t gs_physical_cu() {
 
 void gs_log_error(const char* where, const char* what);
 
+// Optional in-library kernel timing (mi355gs_profile_*, api.hip): an event pair around the launches made in its scope, on the
+// launch stream, when profiling is on and it is this launch's turn.  kind: include/mi355gs.h mi355gs_profile_read.
+struct GsProfScope {
+  hipStream_t s; hipEvent_t stop; bool active = false;
+  GsProfScope(int kind, hipStream_t stream);
+  ~GsProfScope();
+};
+
 // Set by the fused train step (trainer.hip) around its calls into the per-operator entry points: the trainer zeroes
 // every counter / accumulator of the iteration in ONE prologue launch and asks the operators to skip their own memsets,
 // and it collects the "gradient tensor has a non-zero" gate flags for PerPointAdam from the kernels that write the

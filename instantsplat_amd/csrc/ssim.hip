@@ -663,8 +663,11 @@ int mi355gs_l1_ssim_loss_fused(void* stream_, int B, int C, int H, int W, const 
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
   const double inv_n = 1.0 / ((double)B * C * H * W);
   const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, B * C);
-  hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
-                     (float)((1.0 - (double)lambda_dssim) * inv_n), dloss_dimg1, (float*)scratch);
+  {
+    GsProfScope prof(3, stream);
+    hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
+                       (float)((1.0 - (double)lambda_dssim) * inv_n), dloss_dimg1, (float*)scratch);
+  }
   GS_CHECK_LAUNCH("l1_ssim_fused");
   hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, fused_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
                      l1_mean, loss, lambda_dssim);
@@ -680,7 +683,10 @@ int mi355gs_l1_ssim_pair_forward(void* stream_, int B, int C, int H, int W, cons
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
   const double inv_n = 1.0 / ((double)B * C * H * W);
   const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, B * C);
-  hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)inv_n, 0.0f, dssim_dimg1, (float*)scratch);
+  {
+    GsProfScope prof(3, stream);
+    hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)inv_n, 0.0f, dssim_dimg1, (float*)scratch);
+  }
   GS_CHECK_LAUNCH("l1_ssim_pair");
   hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, fused_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
                      l1_mean, (float*)nullptr, 0.f);
@@ -733,8 +739,11 @@ int gs_loss_fused(hipStream_t stream, int C, int H, int W, const float* img1, co
   const int debug = 0;
   const double inv_n = 1.0 / ((double)C * H * W);
   const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, C);
-  hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
-                     (float)((1.0 - (double)lambda_dssim) * inv_n), dL_dimg1, (float*)scratch);
+  {
+    GsProfScope prof(3, stream);
+    hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
+                       (float)((1.0 - (double)lambda_dssim) * inv_n), dL_dimg1, (float*)scratch);
+  }
   GS_CHECK_LAUNCH("l1_ssim_fused");
   return MI355GS_OK;
 }

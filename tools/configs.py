@@ -4,6 +4,8 @@ output -> profiles/r<NN>_baseline_configs.txt.
   configs[0] -> C1'  3-view 128x128-pointmap scene (49,152 Gaussians, 256x256 images), 50 train iterations on the CPU path
                      (oracle/train_ref.py: the plumbing run; MASt3R init is impossible offline) — and the same 50
                      iterations on the device from the same start, loss by loss
+  configs[0] -> C1   the same plumbing run on the reference's own example frames (assets/sora/Art, 1280x720 JPEG) through the init-directory
+                     loader, device vs CPU oracle loss by loss (tests/sora_util.py: what replaces MASt3R)
   configs[1] -> C2   50k random Gaussians, one 512x512 camera, forward raster only: device ms/frame vs the CPU port, max |d|
   configs[2] -> C3   the bench line (bench.py)
   configs[3] -> C4   12-view pointmap, 995,328 Gaussians, 1920x1080: render + fused loss + backward per view
@@ -54,6 +56,29 @@ print(f"C1' 3 views / {g.get_xyz.shape[0]} Gaussians / 256^2, 50 train iteration
       f"device (drop-in loop) {t_dev * 1e3:.1f} ms ({50 / t_dev:.0f} it/s); loss {l_cpu[0]:.5f} -> {l_cpu[-1]:.5f} (CPU), "
       f"{l_dev[0]:.5f} -> {l_dev[-1]:.5f} (device); largest relative loss difference over the 50 iterations {worst:.2e}")
 del st, g, cpu
+
+# ---- C1 on the reference's own example frames (assets/sora/Art/images, committed as tests/golden/sora_art): 1280 x 720 JPEGs through the
+# init-directory loader; MASt3R (unobtainable offline) is replaced by a synthetic pointmap coloured from the frames + arc poses
+import tempfile
+from tests import sora_util
+from instantsplat_amd import scene_io
+from instantsplat_amd.train import evaluate_psnr
+with tempfile.TemporaryDirectory() as td:
+    sora_util.write_sora_init_dir(os.path.join(td, "Art"), Wm=160, Hm=90)
+    sc_ = scene_io.load_init_scene(os.path.join(td, "Art"), 3, resolution=1, device=dev)
+    t0 = time.perf_counter()
+    l_dev, l_cpu, st_ = sora_util.train_against_cpu_oracle(sc_, dev, iters=50)
+    t_both = time.perf_counter() - t0
+    worst = max(abs(a - b) / max(abs(b), 1e-2) for a, b in zip(l_dev, l_cpu))
+    from instantsplat_amd.train import train_iteration as _ti
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): _ti(st_, fused_loss=False)
+    torch.cuda.synchronize(); t_dev = time.perf_counter() - t0
+    print(f"C1 sora/Art: 3 JPEG frames 1280x720 (native, -r 1), {st_.gaussians.get_xyz.shape[0]} Gaussians (synthetic pointmap 160x90 per view, coloured "
+          f"from the frames; MASt3R replaced), 50 train iterations, train.py loss as written: loss {l_dev[0]:.5f} -> {l_dev[-1]:.5f} (device), "
+          f"{l_cpu[0]:.5f} -> {l_cpu[-1]:.5f} (CPU oracle), largest relative loss difference {worst:.2e}; device loop alone, next 50 iterations: "
+          f"{t_dev * 1e3:.1f} ms ({50 / t_dev:.0f} it/s); PSNR {evaluate_psnr(st_):.2f} dB")
+    del st_, sc_
 
 # ---- C2: 50k blob, 512^2, forward only, GPU vs CPU port
 sc = syn_blob(50000, 512, 512, seed=0)

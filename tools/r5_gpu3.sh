@@ -1,0 +1,24 @@
+# round 5, third GPU call: GPU tier, bench line, kernel stats + four PMC passes of the bench command, BASELINE configs record.
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+R=r05
+timeout 1200 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${R}_gputest_full_v3.txt; tail -8 gpurun_out/${R}_gputest_full_v3.txt
+timeout 600 python bench.py > gpurun_out/${R}_bench_default_run_v3.json 2> gpurun_out/bench_default.err; tail -c 400 gpurun_out/bench_default.err
+bash tools/prof.sh ${R}_bench_c3 python bench.py --steps 200 --warmup 20 --cpu-iters 0 --no-long-run > /dev/null 2>&1
+A=SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES
+B=SQ_WAVE_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_INSTS_VALU,SQ_BUSY_CYCLES,SQ_WAVES
+for c in FETCH_SIZE WRITE_SIZE $A $B; do
+  bash tools/pmc.sh c3 $c python bench.py --steps 20 --warmup 5 --cpu-iters 0 --no-long-run > /dev/null 2>&1
+done
+cp gpurun_out/pmc_c3_FETCH_SIZE.csv gpurun_out/${R}_pmc_c3_FETCH_SIZE.csv; cp gpurun_out/pmc_c3_WRITE_SIZE.csv gpurun_out/${R}_pmc_c3_WRITE_SIZE.csv
+cp gpurun_out/pmc_c3_${A//,/_}.csv gpurun_out/${R}_pmc_c3_SQ_counters.csv; cp gpurun_out/pmc_c3_${B//,/_}.csv gpurun_out/${R}_pmc_c3_SQ_wait_counters.csv
+head -14 gpurun_out/${R}_pmc_c3_SQ_wait_counters.csv | cut -c1-200
+timeout 900 python tools/configs.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_baseline_configs_c1_c2_c4.txt; cat gpurun_out/${R}_baseline_configs_c1_c2_c4.txt
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r05_bench_default_run_v3.json"))
+r = d["roofline"]
+print("value %.0f | loops %s" % (d["value"], {k: round(v["iters_per_sec"]) for k, v in d["loops"].items()}))
+print({k: (round(v["avg_kernel_ms"] * 1e3, 1), round(v["frac"], 3)) for k, v in r["small_kernels"].items()})
+PY
+ls gpurun_out | grep ${R}_
