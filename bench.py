@@ -552,10 +552,15 @@ def main():
         out = {}
         with open(os.path.join(ROOT, "profiles", name)) as fh:
             for row in csv.DictReader(fh):
-                k = row["kernel"]
-                if k.endswith("true>") and "k_composite_bwd" in k:
+                k = row["kernel"].replace(";", ",")   # (tools/pmc.sh writes the template arguments' commas as semicolons: the file is a CSV)
+                args_ = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",") if "<" in k and ">" in k else []
+                if "k_composite_bwd" in k and len(args_) >= 2 and args_[1] == "true":     # <chunks, COUNT, det>: the counting instantiation
                     continue
-                if "k_composite_fwd" in k and k.count(",") >= 2 and (k.replace(" ", "").endswith(",false>") != render_only):
+                if "k_composite_bwd" in k and len(args_) >= 3 and args_[2] == "true":     # the deterministic instantiation
+                    continue
+                if "k_composite_fwd" in k and len(args_) >= 3 and ((args_[2] == "false") != render_only):   # <tiles, COUNT, TRAIN>
+                    continue
+                if "k_composite_fwd" in k and len(args_) >= 2 and args_[1] == "true":
                     continue
                 out.setdefault(k.replace("void ", "").split("<")[0], row)
         return out
@@ -633,11 +638,28 @@ def main():
             break
         except OSError:
             continue
+    rocprof_us, rocprof_src = {}, None
+    for rnd in ("r05", "r04"):
+        try:   # rocprofv3 --kernel-trace --stats summary of this command (tools/prof.sh): the average duration the event times must agree with
+            import csv
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_bench_c3_kernel_stats.csv")) as fh:
+                for row in csv.DictReader(fh):
+                    nm = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+                    if nm not in rocprof_us or int(row["Calls"]) > rocprof_us[nm][1]:
+                        rocprof_us[nm] = (float(row["AverageNs"]) / 1e3, int(row["Calls"]))
+            rocprof_src = f"profiles/{rnd}_bench_c3_kernel_stats.csv"
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     for kname, key, abytes, what in small_defs:
         ms, nl = kern.get(key, (0.0, 0))
         ent = {"avg_kernel_ms": ms, "launches": nl, "algorithmic_bytes_per_launch": abytes, "algorithmic_bytes": what,
                "achieved": abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "unit": "GB/s", "peak": HBM_PEAK_GBS,
-               "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0, "traffic": None, "counters": None, "bound": None}
+               "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0, "traffic": None, "counters": None, "bound": None,
+               "avg_kernel_us_rocprof": (rocprof_us.get(kname) or (None,))[0], "rocprof_source": rocprof_src,
+               "frac_at_rocprof_duration": (abytes / (rocprof_us[kname][0] * 1e-6) / 1e9 / HBM_PEAK_GBS) if kname in rocprof_us else None,
+               "note": "an event pair around a 6-17 us kernel adds ~2-3 us to what it brackets (the pair is two marker packets on the queue); "
+                       "the rocprofv3 duration is the kernel alone"}
         try:
             ent["traffic"] = (2.0 * float(fr5[kname]["mean_FETCH_SIZE"]) + float(wr5[kname]["mean_WRITE_SIZE"])) * 1024.0
         except (KeyError, ValueError):
