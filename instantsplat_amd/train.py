@@ -48,6 +48,7 @@ class TrainState:
     viewpoint_stack: list = field(default_factory=list)
     rng: random.Random = field(default_factory=lambda: random.Random(0))
     last_loss: Optional[torch.Tensor] = None
+    test_cameras: list = field(default_factory=list)   # scene.getTestCameras() (only an --eval init directory has any)
     _trainer: object = None
     _prepared: object = None   # the NEXT iteration, host half done and forward + backward enqueued: (saved host state, arguments,
                                # result slot, event, camera), see _fused_synced_iteration
@@ -74,6 +75,7 @@ def setup_training_from_init(scene, device, opt: OptimizationParams | None = Non
     else:
         g.training_setup(opt)
     st = TrainState(g, cams, [c.original_image.to(dev).contiguous() for c in cams], bg, opt, pipe)
+    st.test_cameras = [c.to(dev) for c in getattr(scene, "test_cameras", [])]
     st.rng = scene.rng   # the view sampling continues on the stream the camera shuffle drew from (one `random` module in the reference)
     return st
 
@@ -642,6 +644,35 @@ def evaluate_psnr(st: TrainState) -> float:
     return float(torch.stack(vals).mean())
 
 
+@torch.no_grad()
+def training_report(st: TrainState, iteration: int, testing_iterations=(), quiet: bool = False) -> dict:
+    """reference train.py:253-295 (called at the run's last iteration, :218): at a testing iteration (or every 5000th) mean L1 and
+    PSNR of the clamped renders over the test cameras and over the training cameras, printed in the reference's words.
+    -> {"test": (l1, psnr), "train": (l1, psnr)} (an empty dict at any other iteration).  No tensorboard writer: the reference
+    makes one only when the package is installed, and logs the same numbers to it.  Like the reference, the test cameras' poses
+    come from `gaussians.get_RT_test`, which nothing in the reference ever fills (scene/gaussian_model.py:138-140 reads
+    `test_P`): with --eval test cameras this raises the reference's own TypeError."""
+    out = {}
+    if not (iteration in set(int(i) for i in testing_iterations) or iteration % 5000 == 0):
+        return out
+    g = st.gaussians
+    for name, cams in (("test", st.test_cameras), ("train", [st.cameras[i % len(st.cameras)] for i in range(len(st.cameras))])):
+        if not cams:
+            continue
+        l1_test = psnr_test = 0.0
+        for cam in cams:
+            pose = g.get_RT(cam.uid) if name == "train" else g.get_RT_test(cam.uid)
+            image = torch.clamp(render(cam, g, st.pipe, st.background, camera_pose=pose)["render"], 0.0, 1.0)
+            gt_image = st.gt_images[cam.uid] if name == "train" else cam.original_image   # (a camera's own `original_image`, as loaded)
+            gt = torch.clamp(gt_image.to(image.device), 0.0, 1.0)
+            l1_test += l1_loss(image, gt).mean().double()
+            psnr_test += psnr(image, gt).mean().double()
+        out[name] = (float(l1_test / len(cams)), float(psnr_test / len(cams)))
+        if not quiet:
+            print("\n[ITER {}] Evaluating {}: L1 {} PSNR {}".format(iteration, name, out[name][0], out[name][1]))
+    return out
+
+
 def _save_outputs(st: TrainState, iteration: int, model_path: str, colmap_ids):
     """What the reference writes at a saving iteration (train.py:220-223, scene/__init__.py:97-99): the Gaussians as
     point_cloud/iteration_<it>/point_cloud.ply and the optimised poses as pose/ours_<it>/pose_optimized.npy."""
@@ -655,7 +686,7 @@ def _save_outputs(st: TrainState, iteration: int, model_path: str, colmap_ids):
 def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahead: bool = True,
              fused_loss: bool = True, model_path: str | None = None, saving_iterations=(), checkpoint_iterations=(),
              start_checkpoint: str | None = None, opt: OptimizationParams | None = None, n_views: int | None = None,
-             model: ModelParams | None = None, after_setup=None, resolution=1) -> dict:
+             model: ModelParams | None = None, after_setup=None, resolution=1, testing_iterations=()) -> dict:
     """Train one scene.  run_ahead=True (default): the fastest loop with the reference's results — the one-call step with every
     iteration's loss read back while the device already works on the next iteration (`train_iteration(fused_step=True)`,
     _fused_synced_iteration) for the configuration the reference's scripts run, the window-verified RunAhead driver on the
@@ -667,6 +698,8 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
     `model_path` like the reference's Scene).  opt: the optimisation parameters (default: the scripts' `--pp_optimizer --optim_pose`); its
     `iterations` is overridden by the argument.  after_setup(state): hook between set-up and the first iteration (tests).
 
+    testing_iterations: reference --test_iterations; `training_report` runs at the LAST iteration if it is one of them (train.py:218)
+    and its numbers come back under "report".
     model_path / saving_iterations / checkpoint_iterations / start_checkpoint: the reference's outputs and resume
     (train.py:103-110,220-227): pose/ours_<it>/pose_org.npy before training, point_cloud.ply + pose_optimized.npy at every saving
     iteration, chkpnt<it>.pth = torch.save((gaussians.capture(), it)) at every checkpoint iteration, and a run started from
@@ -721,6 +754,7 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
     one_call = bool(run_ahead and fused_loss and FusedTrainer.supported(st))
     ra = RunAhead(st, fused_loss=fused_loss) if run_ahead and not one_call else None
     ema = 0.0
+    report = {}
     for i in range(int(first_iter), iterations):
         if one_call:
             last = train_iteration(st, fused_step=True)
@@ -742,6 +776,11 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
         it = i + 1
         if it == iterations and model_path:   # reference train.py:213-217: the time of the loop itself, before the last save
             save_time(model_path, "[2] train_joint_TrainTime", time.perf_counter() - t0)
+        if it == iterations and (it in set(int(i) for i in testing_iterations) or it % 5000 == 0):   # train.py:218 (training_report)
+            cancel_prepared(st)
+            if ra is not None:
+                ra.flush()
+            report = training_report(st, it, testing_iterations, quiet=not log_every)
         if it in saving or it in checkpoints:
             cancel_prepared(st)
             if ra is not None:
@@ -762,4 +801,4 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
         save_time(model_path, "[2] train_joint", dt)
     n_done = max(iterations - int(first_iter), 1)
     return dict(seconds=dt, iters_per_sec=n_done / dt, first_loss=first, last_loss=last, psnr_before=psnr0,
-                psnr_after=evaluate_psnr(st), state=st)
+                psnr_after=evaluate_psnr(st), state=st, report=report)

@@ -279,3 +279,25 @@ def test_simple_pinhole_cameras(tmp_path):
         f.write("1 OPENCV 8 6 7.5 7.5 4.0 3.0 0 0 0 0\n")
     with pytest.raises(ValueError):
         iof.read_cameras_text(tmp_path / "bad.txt")
+
+
+def test_training_report_at_the_last_iteration(emu, tmp_path, capsys):
+    """reference train.py:218,253-295: at the run's last iteration, if it is a testing iteration, mean L1 / PSNR of the clamped
+    renders over the training cameras (and the test cameras of an --eval scene) — printed in the reference's words, returned under
+    "report"; silent at other iterations; with --eval test cameras the reference's own TypeError (get_RT_test reads a table nothing
+    fills, scene/gaussian_model.py:138-140)."""
+    import dataclasses
+    from instantsplat_amd.arguments import ModelParams
+    from instantsplat_amd.train import training
+    r = training(SCENE, emu, iterations=3, n_views=V, resolution=2, testing_iterations=[3], log_every=1)
+    assert set(r["report"]) == {"train"} and abs(r["report"]["train"][1] - r["psnr_after"]) < 1e-3 and 0 < r["report"]["train"][0] < 1
+    assert "[ITER 3] Evaluating train: L1 " in capsys.readouterr().out
+    assert training(SCENE, emu, iterations=3, n_views=V, resolution=2, testing_iterations=[7])["report"] == {}
+    import shutil
+    src = tmp_path / "scene"
+    shutil.copytree(SCENE, src)
+    os.makedirs(src / f"sparse_{V}" / "1")
+    for f in ("cameras.txt", "images.txt"):
+        shutil.copyfile(src / f"sparse_{V}" / "0" / f, src / f"sparse_{V}" / "1" / f)
+    with pytest.raises(TypeError):
+        training(str(src), emu, iterations=2, n_views=V, resolution=2, testing_iterations=[2], model=dataclasses.replace(ModelParams(), eval=True))
