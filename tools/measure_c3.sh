@@ -1,4 +1,4 @@
-# the C3 part of tools/measure_all.sh (bench line, kernel stats, three counter passes)      usage: bash tools/measure_c3.sh r03
+# the C3 part of tools/measure_round.sh (bench line, kernel stats, three counter passes)      usage: bash tools/measure_c3.sh r03
 R=${1:-rXX}
 cd "$GRAFT_REPO_ROOT"
 timeout 600 python bench.py > gpurun_out/${R}_bench_default_run.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.err
