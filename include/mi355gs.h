@@ -151,8 +151,8 @@ int mi355gs_tune_min_units(int min_units);
  * moments of a Gaussian from every (tile, unit) that replays it with float atomics, in whatever order the waves arrive: two runs
  * of the same frame differ in the last bits, two runs of the same scene drift apart.  on = 1: every (Gaussian, tile) instance's
  * moments are stored to a row of their own and summed per Gaussian in the order of its tile rectangle (y outer, x inner) —
- * bit-identical gradients run to run, and with them bit-identical training.  Same arithmetic otherwise; costs six small
- * launches, a memset and 52 bytes per instance per backward (measured: profiles/).
+ * bit-identical gradients run to run, and with them bit-identical training.  Same arithmetic otherwise; costs five small
+ * launches, a memset and 52 bytes per instance per backward (measured at C3: 0.84-0.87 x the default rate).
  * It enters the buffer-size queries (mi355gs_raster_binning_bytes: + 52 B per instance; mi355gs_raster_grad_scratch_bytes:
  * + ~8 B per Gaussian): set it before sizing a frame's buffers and keep it until that frame's backward has been enqueued; a
  * trainer handle takes a snapshot at mi355gs_trainer_create.  The work-counting instantiation (mi355gs_profile_work_counters)

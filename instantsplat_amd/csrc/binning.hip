@@ -186,11 +186,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(int T, const uint32
 // k_scan_tiles -> per-block rescan with offset.  SCAN_CHUNK consecutive elements per workgroup, coalesced.
 constexpr int SCAN_CHUNK = 4096;
 
+// RECT: the input is not an array of counters but the Gaussians' packed tile rectangles, and element i counts the tiles of
+// rectangle i (element n - 1 = 0, so that out[n - 1] is the total): the deterministic backward's row offsets (composite.hip),
+// without a kernel and an array for the areas.
+template <bool RECT>
+__device__ __forceinline__ uint32_t scan_input(const uint32_t* __restrict__ in, int i, int n) {
+  if (i >= n) return 0u;
+  if constexpr (!RECT) return in[i];
+  else {
+    if (i == n - 1) return 0u;
+    const uint2 r = reinterpret_cast<const uint2*>(in)[i];
+    const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
+    return (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
+  }
+}
+
+template <bool RECT>
 __global__ __launch_bounds__(256) void k_scan_block_sums(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ sums) {
   __shared__ uint32_t s_red[4];
   const int base = blockIdx.x * SCAN_CHUNK;
   uint32_t acc = 0;
-  for (int i = threadIdx.x; i < SCAN_CHUNK; i += 256) acc += (base + i < n) ? in[base + i] : 0u;
+  for (int i = threadIdx.x; i < SCAN_CHUNK; i += 256) acc += scan_input<RECT>(in, base + i, n);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
@@ -198,6 +214,7 @@ __global__ __launch_bounds__(256) void k_scan_block_sums(int n, const uint32_t* 
   if (threadIdx.x == 0) sums[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+template <bool RECT>
 __global__ __launch_bounds__(256) void k_scan_apply(int n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ block_off,
                                                     uint32_t* __restrict__ out) {
   __shared__ uint32_t s_wave[4];
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(int n, const uint32_t* __res
   uint32_t run = block_off[blockIdx.x];
   for (int it = 0; it < SCAN_CHUNK / 256; ++it) {
     const int i = blockIdx.x * SCAN_CHUNK + it * 256 + tid;
-    const uint32_t v = i < n ? in[i] : 0u;
+    const uint32_t v = scan_input<RECT>(in, i, n);
     const uint32_t incl = gs_wave_scan_incl_u32(v);
     __syncthreads();
     if (lane == 63) s_wave[wave] = incl;
@@ -779,13 +796,21 @@ int gs_launch_scan_tiles(hipStream_t stream, int T, const uint32_t* count, uint3
 }
 
 // exclusive scan of n counters into out[0..n] (out[n] = total); block_sums: ceil(n / 4096) + 2 uint32 of scratch
-int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t* out, uint32_t* block_sums, int32_t* total) {
+template <bool RECT>
+static int scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t* out, uint32_t* block_sums, int32_t* total) {
   const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
+  hipLaunchKernelGGL(k_scan_block_sums<RECT>, dim3(nb), dim3(256), 0, stream, n, in, block_sums);
   hipLaunchKernelGGL(k_scan_tiles<false>, dim3(1), dim3(SCAN_THREADS), 0, stream, nb, (const uint32_t*)block_sums, block_sums, total,
                      (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);  // in place
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
+  hipLaunchKernelGGL(k_scan_apply<RECT>, dim3(nb), dim3(256), 0, stream, n, in, (const uint32_t*)block_sums, out);
   return 0;
+}
+int gs_launch_scan_large(hipStream_t stream, int n, const uint32_t* in, uint32_t* out, uint32_t* block_sums, int32_t* total) {
+  return scan_large<false>(stream, n, in, out, block_sums, total);
+}
+// off[g] = tiles of the rectangles of Gaussians 0 .. g - 1, g = 0 .. P (off[P] = all instances); *total receives it as well
+int gs_launch_scan_rect_areas(hipStream_t stream, int P, const uint2* rects, uint32_t* off, uint32_t* block_sums, int32_t* total) {
+  return scan_large<true>(stream, P + 1, reinterpret_cast<const uint32_t*>(rects), off, block_sums, total);
 }
 
 int gs_launch_count_tiles(hipStream_t stream, int P, int T, int gx, const uint2* rects, uint32_t* tile_count, uint32_t* entries,

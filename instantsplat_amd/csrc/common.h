@@ -71,12 +71,11 @@ __host__ __device__ inline int gs_unit_level_for(long long instances, long long 
 int gs_deterministic();           // api.hip: the knob (or the value a trainer handle pinned for its calls)
 void gs_pin_deterministic(int v); // >= 0: this thread sizes and launches with v until it is reset to -1 (trainer.hip)
 struct DetScratchLayout {         // behind the 256 bytes of gate flags in the gradient scratch; all uint32
-  size_t area, off, block_sums, total;
+  size_t off, block_sums, total;
   __host__ explicit DetScratchLayout(int P) {
     const size_t n = (size_t)(P > 0 ? P : 1) + 1;
     size_t o = 0;
-    area = o; o += gs_align(n * 4);                  // tiles of every Gaussian's rectangle (+ one 0)
-    off = o; o += gs_align((n + 1) * 4);             // their exclusive prefix sums: first row of Gaussian g
+    off = o; o += gs_align((n + 1) * 4);             // exclusive prefix sums of the rectangles' tile counts: first row of Gaussian g
     block_sums = o; o += gs_align(((n + 4095) / 4096 + 2) * 4);
     total = o;
   }

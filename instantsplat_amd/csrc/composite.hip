@@ -720,18 +720,6 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
 }
 
 // ---- deterministic mode: rows of the instances and their per-Gaussian sums --------------------------------------------------
-// area[g] = tiles of Gaussian g's rectangle (the scatter walks exactly these: one instance each); area[P] = 0
-__global__ __launch_bounds__(256) void k_det_area(int P, const uint2* __restrict__ rects, uint32_t* __restrict__ area) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g > P) return;
-  uint32_t a = 0;
-  if (g < P) {
-    const uint2 r = rects[g];
-    const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
-    a = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
-  }
-  area[g] = a;
-}
 // one workgroup per tile: the row of list position p (Gaussian g in tile (tx, ty)) = off[g] + the tile's index in g's rectangle
 __global__ __launch_bounds__(256) void k_det_rowidx(int gx, uint32_t capacity, const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ list, const uint2* __restrict__ rects,
@@ -752,8 +740,15 @@ __global__ __launch_bounds__(192) void k_det_gather(int P, uint32_t capacity, co
   const int g = blockIdx.x * 16 + threadIdx.x / 12, c = threadIdx.x % 12;
   if (g >= P) return;
   const uint32_t r0 = min(off[g], capacity), r1 = min(off[g + 1], capacity);
+  const float* __restrict__ src = rows + (size_t)r0 * 12 + c;
   float acc = 0.f;
-  for (uint32_t r = r0; r < r1; ++r) acc += rows[(size_t)r * 12 + c];
+  uint32_t n = r1 - r0;
+  // eight rows in flight, added in row order (the ORDER is what the mode is about; the loads may run ahead)
+  for (; n >= 8u; n -= 8u, src += 96) {
+    const float a0 = src[0], a1 = src[12], a2 = src[24], a3 = src[36], a4 = src[48], a5 = src[60], a6 = src[72], a7 = src[84];
+    acc = (((((((acc + a0) + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+  }
+  for (; n > 0u; --n, src += 12) acc += *src;
   reinterpret_cast<float*>(grads + g)[c] = acc;
 }
 
@@ -778,16 +773,14 @@ __global__ __launch_bounds__(256) void k_frame_stats(int T, int gx, int W, int H
 
 }  // namespace
 
-int gs_launch_scan_large(hipStream_t, int, const uint32_t*, uint32_t*, uint32_t*, int32_t*);
-// deterministic mode, in front of the composite backward: rectangle areas -> row offsets -> the row of every list position; the
-// rows cleared.  scratch: DetScratchLayout(P) (uint32 words behind the gradient scratch's gate flags).
+int gs_launch_scan_rect_areas(hipStream_t, int, const uint2*, uint32_t*, uint32_t*, int32_t*);
+// deterministic mode, in front of the composite backward: row offsets (a scan over the rectangles' tile counts) -> the row of
+// every list position; the rows cleared.  scratch: DetScratchLayout(P) (uint32 words behind the gradient scratch's gate flags).
 int gs_launch_det_prepare(hipStream_t stream, int P, int T, int gx, uint32_t capacity, const uint32_t* tile_start, const uint32_t* list,
                           const uint2* rects, char* det_scratch, uint32_t* rowidx, float* rows) {
   const DetScratchLayout dl(P);
-  uint32_t* area = (uint32_t*)(det_scratch + dl.area);
   uint32_t* off = (uint32_t*)(det_scratch + dl.off);
-  hipLaunchKernelGGL(k_det_area, dim3((P + 1 + 255) / 256), dim3(256), 0, stream, P, rects, area);
-  gs_launch_scan_large(stream, P + 1, area, off, (uint32_t*)(det_scratch + dl.block_sums), (int32_t*)(off + P + 1));
+  gs_launch_scan_rect_areas(stream, P, rects, off, (uint32_t*)(det_scratch + dl.block_sums), (int32_t*)(off + P + 1));
   hipLaunchKernelGGL(k_det_rowidx, dim3(T), dim3(256), 0, stream, gx, capacity, tile_start, list, rects, off, rowidx);
   if (hipMemsetAsync(rows, 0, (size_t)capacity * sizeof(GsGrad), stream) != hipSuccess) return -1;
   return 0;
