@@ -73,16 +73,22 @@ def reference_modules_cleanup():
         del sys.modules[k]
 
 
-@pytest.mark.parametrize("fused_glue", [False, True])
-def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup, fused_glue):
+@pytest.mark.parametrize("fused_glue,alias_loss_utils", [(False, False), (True, False), (True, True)])
+def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_modules_cleanup, fused_glue, alias_loss_utils):
     """fused_glue: also take the second block of INTEGRATION.md section 1 — `gaussian_renderer.render` and `PerPointAdam`
-    replaced by ours (fused pose kernel, multi-tensor Adam kernel), identical signatures."""
+    replaced by ours (fused pose kernel, multi-tensor Adam kernel), identical signatures.
+    alias_loss_utils: `utils.loss_utils` is instantsplat_amd.loss_utils as well — the configuration bench.py's headline runs: the
+    loss lines of the reference's training() source (train.py:171-177), unmodified, then go through the loss pair and the recorded
+    scalar expression of instantsplat_amd/lazy_loss.py."""
     G = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
     T = lambda k: torch.from_numpy(G[k])
     V, _, W, H, iters = [int(x) for x in G["loop_config"]]
     R = _load_reference(monkeypatch)
     gm, gr, cm, loss_utils, pose_utils, BasicPointCloud, OptimizationParams, fs = (R.gm, R.gr, R.cm, R.loss_utils, R.pose_utils,
                                                                                     R.BasicPointCloud, R.OptimizationParams, R.fs)
+    if alias_loss_utils:
+        import instantsplat_amd.loss_utils as loss_utils   # sys.modules["utils.loss_utils"] = instantsplat_amd.loss_utils
+        from instantsplat_amd import lazy_loss
     if fused_glue:
         import instantsplat_amd.gaussian_renderer as our_gr
         import instantsplat_amd.optim as our_optim
@@ -131,6 +137,9 @@ def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_mo
 
     def fused_ssim_tracked(a, b):          # train.py:173 — OUR fused_ssim through the alias; the loss value is recorded
         v = fs.fused_ssim(a, b)
+        if alias_loss_utils:               # the other half of the pair train.py:171's l1_loss(image, gt_image) has just computed
+            assert type(v) is lazy_loss.LazyScalar and v._rec.image.data_ptr() == a.data_ptr()
+            track["lazy"] = track.get("lazy", 0) + 1
         l1 = loss_utils.l1_loss(a[0], b[0])
         track["loss"].append(float(((1.0 - 0.2) * l1 + 0.2 * (1.0 - v)).detach()))
         return v
@@ -159,6 +168,7 @@ def test_reference_training_runs_on_our_operators(emu, monkeypatch, reference_mo
         ns["training"](dataset, opt, pipe, [], [], [], None, -1)
 
     model = track["models"][-1]
+    assert track.get("lazy", 0) == (iters if alias_loss_utils else 0)
     assert track["uids"] == list(G["loop_view_uids"])
     assert np.allclose(track["loss"], G["loop_losses"], rtol=1e-3, atol=0), (track["loss"], G["loop_losses"])
     for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "P"):

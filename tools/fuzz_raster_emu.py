@@ -1,13 +1,17 @@
 """CPU-only fuzz of the rasterizer kernels (the unmodified .hip sources under the SIMT emulator of tests/emu) against the fp32 C oracle:
 random Gaussian counts (1 .. 4000), image sizes (incl. sizes that are not multiples of the tile, and > 1024 tiles), SH degrees, scale
 distributions from sub-pixel to larger than the image, opacities, scale modifiers, precomputed colours / covariances — the parity
-criteria of tests/util.py::assert_raster_parity.  python tools/fuzz_raster_emu.py <seed> <cases>.  Test tooling, not product code."""
+criteria of tests/util.py::assert_raster_parity.  Round 5: every other case also runs in the deterministic-backward mode (same
+criteria, and gradients within rounding of the default mode's) and takes its forward once more under torch.no_grad() — the
+render-only stage 2 — which must give the same image and radii bit for bit.
+python tools/fuzz_raster_emu.py <seed> <cases>.  Test tooling, not product code."""
 import sys, time, random, traceback
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from instantsplat_amd import _lib
 _lib._use_library_for_testing(__import__('os').environ.get('MI355GS_EMU_LIB') or __import__('os').path.join(sys.path[0], 'tests', 'emu', 'libmi355gs_emu.so'))
-from tests.util import assert_raster_parity, run_blob_case
+from tests.util import assert_raster_parity, relerr, run_blob_case
+import instantsplat_amd.diff_gaussian_rasterization as dgr
 dev = torch.device('cpu')
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -25,6 +29,19 @@ for i in range(n_cases):
     try:
         out = run_blob_case(dev, P, W, H, deg, scale_mean=sm, seed=seed, opacity=op, mod=mod, precomp_color=pc, precomp_cov=pv)
         assert_raster_parity(out)
+        if i % 2 == 0:
+            dgr.set_deterministic(True)
+            try:
+                det = run_blob_case(dev, P, W, H, deg, scale_mean=sm, seed=seed, opacity=op, mod=mod, precomp_color=pc, precomp_cov=pv)
+            finally:
+                dgr.set_deterministic(False)
+            assert_raster_parity(det)
+            assert torch.equal(det["dut"]["color"], out["dut"]["color"])
+            for k, g in out["dut"]["grads"].items():
+                assert relerr(det["dut"]["grads"][k], g) <= 1e-5 or float(g.abs().max()) == 0.0, ("deterministic mode", k, relerr(det["dut"]["grads"][k], g))
+            with torch.no_grad():
+                ro = run_blob_case(dev, P, W, H, deg, scale_mean=sm, seed=seed, opacity=op, mod=mod, precomp_color=pc, precomp_cov=pv, backward=False)
+            assert torch.equal(ro["dut"]["color"], out["dut"]["color"]) and torch.equal(ro["dut"]["radii"], out["dut"]["radii"]), "render-only forward"
     except Exception as e:
         bad += 1
         print("FAIL", cfg, type(e).__name__, str(e)[:300], flush=True)
