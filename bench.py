@@ -757,7 +757,7 @@ def main():
             "loops": {"dropin_reference_loop_train_py_loss": dict(headline, what="THE HEADLINE — train.py:171-176 as written: l1_loss(image, gt), "
                                                                                "fused_ssim(image[None], gt[None]), scalar arithmetic, loss.backward(); "
                                                                                "utils/loss_utils aliased to instantsplat_amd.loss_utils like the operator "
-                                                                               "packages (lazy_loss.py: 4 launches for the expression's 16)"),
+                                                                               "packages (lazy_loss.py: 3 launches for the expression's 16)"),
                       "dropin_reference_loop_fused_loss": dict(fused_sib, what="the same loop with the loss as ONE call, "
                                                                                "instantsplat_amd.fused_ssim.fused_l1_ssim_loss — needs an edit of train.py; "
                                                                                "rounds 2-4 quoted this loop as `value`"),

@@ -232,14 +232,17 @@ int mi355gs_l1_loss_backward(void* stream, int64_t n, const float* a, const floa
  *     Ll1 = l1_loss(image, gt_image);  ssim_value = fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
  *     loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim_value);  loss.backward()
  * two operator calls on the same pair of images and four scalar operations on 0-dim tensors: sixteen eager launches
- * forward + backward.  These three entry points let a binding serve that source text unmodified in four
- * (instantsplat_amd/loss_utils.py: l1_loss runs the pair forward, fused_ssim on the same tensors takes its other half from
+ * forward + backward.  These three entry points let a binding serve that source text unmodified in THREE
+ * (instantsplat_amd/loss_utils.py, lazy_loss.py: l1_loss runs the pair forward, fused_ssim on the same tensors takes its other half from
  * it, the scalar arithmetic is recorded on the host and evaluated by one launch, the backward of the whole expression is one
  * launch over the image).
- *   pair_forward: ONE pass over the images (the kernel of mi355gs_l1_ssim_loss_fused) -> *ssim_mean, *l1_mean (device
- *     float[1] each) and dssim_dimg1[B,C,H,W] = d(ssim_mean)/d(img1); scratch: mi355gs_ssim_scratch_bytes().
- *   program_eval: a postfix program of n_ops <= MI355GS_LOSS_PROGRAM_MAX operations over the two means, ops[i] / consts[i] HOST
- *     arrays, evaluated in float32 with one rounding per operation (what eager PyTorch computes for the same expression):
+ *   pair_forward: ONE pass over the images, one launch (the kernel of mi355gs_l1_ssim_loss_fused) -> dssim_dimg1[B,C,H,W] =
+ *     d(ssim_mean)/d(img1), and both means as per-workgroup partial sums in `scratch` (mi355gs_ssim_scratch_bytes(); it must
+ *     stay untouched until the last program_eval of the pair).
+ *   program_eval: one launch that FINISHES the two means from `scratch` (fixed order, double accumulation: the bits
+ *     mi355gs_ssim_forward / mi355gs_l1_ssim_loss_fused report) into *ssim_mean / *l1_mean (device float[1] each) and evaluates a
+ *     postfix program of n_ops <= MI355GS_LOSS_PROGRAM_MAX operations over them, ops[i] / consts[i] HOST arrays, in float32 with
+ *     one rounding per operation (what eager PyTorch computes for the same expression):
  *     L1 / SSIM push a mean; MULK x*k, ADDK x+k, RSUBK k-x, DIVK x*(1/k), NEG -x act on the top of the stack; ADD / SUB pop two
  *     (a b -> a+b, a-b).  *out = the one value left.  A program that underflows the stack or leaves more than one value is refused.
  *   pair_backward: d_img1[n] = ((g_l1 ? *g_l1 : 1) * c_l1 / n) * sgn(img1 - img2) + ((g_ssim ? *g_ssim : 1) * c_ssim) * dssim_dimg1
@@ -257,11 +260,11 @@ int mi355gs_l1_loss_backward(void* stream, int64_t n, const float* a, const floa
 #define MI355GS_LOSS_OP_ADD 7
 #define MI355GS_LOSS_OP_SUB 8
 int mi355gs_l1_ssim_pair_forward(void* stream, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
-                                 float* ssim_mean, float* l1_mean, float* dssim_dimg1);
+                                 float* dssim_dimg1);
 int mi355gs_l1_ssim_pair_backward(void* stream, int64_t n, const float* img1, const float* img2, const float* dssim_dimg1,
                                   const float* g_l1, float c_l1, const float* g_ssim, float c_ssim, float* d_img1);
-int mi355gs_loss_program_eval(void* stream, int n_ops, const int32_t* ops, const float* consts, const float* l1_mean,
-                              const float* ssim_mean, float* out);
+int mi355gs_loss_program_eval(void* stream, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
+                              const void* scratch, float* ssim_mean, float* l1_mean, float* out);
 
 /* ------------------------------------------------------------------------------------------------
  * simple-knn

@@ -527,17 +527,30 @@ struct GsLossProgram {
   float k[MI355GS_LOSS_PROGRAM_MAX];
 };
 
-__global__ __launch_bounds__(64) void k_loss_program(GsLossProgram p, const float* __restrict__ l1_mean, const float* __restrict__ ssim_mean,
-                                                    float* __restrict__ out) {
+// One launch: the two means finished from the pass's per-workgroup partial sums (the reduction of k_ssim_finish: double
+// accumulation, fixed order — the same bits), left in *ssim_mean / *l1_mean, then the recorded program evaluated on them.
+__global__ __launch_bounds__(1024) void k_loss_program(GsLossProgram p, int nblocks, double inv_n, const float* __restrict__ partial,
+                                                      float* __restrict__ ssim_mean, float* __restrict__ l1_mean, float* __restrict__ out) {
 #pragma clang fp contract(off)   // one rounding per recorded operation, as eager PyTorch's elementwise kernels
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ double s_a[16], s_b[16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 1024) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+  a = gs_wave_sum_row3_f64(a); b = gs_wave_sum_row3_f64(b);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 63) { s_a[wave] = a; s_b[wave] = b; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double ta = 0.0, tb = 0.0;
+  for (int w = 0; w < 16; ++w) { ta += s_a[w]; tb += s_b[w]; }
+  const float sm = (float)(ta * inv_n), lm = (float)(tb * inv_n);
+  *ssim_mean = sm; *l1_mean = lm;
   float st[MI355GS_LOSS_PROGRAM_MAX];
   int sp = 0;
   for (int i = 0; i < p.n; ++i) {
     const float k = p.k[i];
     switch (p.op[i]) {
-      case MI355GS_LOSS_OP_L1: st[sp++] = *l1_mean; break;
-      case MI355GS_LOSS_OP_SSIM: st[sp++] = *ssim_mean; break;
+      case MI355GS_LOSS_OP_L1: st[sp++] = lm; break;
+      case MI355GS_LOSS_OP_SSIM: st[sp++] = sm; break;
       case MI355GS_LOSS_OP_MULK: st[sp - 1] = st[sp - 1] * k; break;
       case MI355GS_LOSS_OP_ADDK: st[sp - 1] = st[sp - 1] + k; break;
       case MI355GS_LOSS_OP_RSUBK: st[sp - 1] = k - st[sp - 1]; break;
@@ -676,10 +689,10 @@ int mi355gs_l1_ssim_loss_fused(void* stream_, int B, int C, int H, int W, const 
 }
 
 int mi355gs_l1_ssim_pair_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
-                                 float* ssim_mean, float* l1_mean, float* dssim_dimg1) {
+                                 float* dssim_dimg1) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !ssim_mean || !l1_mean || !dssim_dimg1) return MI355GS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !dssim_dimg1) return MI355GS_EINVAL;
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
   const double inv_n = 1.0 / ((double)B * C * H * W);
   const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, B * C);
@@ -688,9 +701,6 @@ int mi355gs_l1_ssim_pair_forward(void* stream_, int B, int C, int H, int W, cons
     hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)inv_n, 0.0f, dssim_dimg1, (float*)scratch);
   }
   GS_CHECK_LAUNCH("l1_ssim_pair");
-  hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, fused_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
-                     l1_mean, (float*)nullptr, 0.f);
-  GS_CHECK_LAUNCH("ssim_finish");
   return MI355GS_OK;
 }
 
@@ -706,11 +716,12 @@ int mi355gs_l1_ssim_pair_backward(void* stream_, int64_t n, const float* img1, c
   return MI355GS_OK;
 }
 
-int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, const float* consts, const float* l1_mean,
-                              const float* ssim_mean, float* out) {
+int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
+                              const void* scratch, float* ssim_mean, float* l1_mean, float* out) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
-  if (n_ops <= 0 || n_ops > MI355GS_LOSS_PROGRAM_MAX || !ops || !consts || !l1_mean || !ssim_mean || !out) return MI355GS_EINVAL;
+  if (n_ops <= 0 || n_ops > MI355GS_LOSS_PROGRAM_MAX || !ops || !consts || !scratch || !l1_mean || !ssim_mean || !out) return MI355GS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return MI355GS_EINVAL;
   GsLossProgram p;
   p.n = n_ops;
   int depth = 0;   // a malformed program (stack underflow, two values left) is refused here, not executed
@@ -725,7 +736,8 @@ int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, cons
     p.op[i] = (signed char)op; p.k[i] = consts[i];
   }
   if (depth != 1) return MI355GS_EINVAL;
-  hipLaunchKernelGGL(k_loss_program, dim3(1), dim3(64), 0, stream, p, l1_mean, ssim_mean, out);
+  hipLaunchKernelGGL(k_loss_program, dim3(1), dim3(1024), 0, stream, p, fused_nblocks(B, C, H, W), 1.0 / ((double)B * C * H * W),
+                     (const float*)scratch, ssim_mean, l1_mean, out);
   GS_CHECK_LAUNCH("loss_program");
   return MI355GS_OK;
 }

@@ -693,25 +693,28 @@ std::vector<Tensor> loss_pair_forward(Tensor img1, Tensor img2) {
   const int64_t o = a.dim() == 4 ? 1 : 0;
   const int B = o ? (int)a.size(0) : 1, C = (int)a.size(o), H = (int)a.size(o + 1), W = (int)a.size(o + 2);
   const DeviceScope dev(a);
-  Tensor scratch = empty_bytes(g_abi.ssim_scratch_bytes(B, C, H, W), a);
-  Tensor l1 = at::empty({}, a.options()), ssim = at::empty({}, a.options());
+  Tensor scratch = empty_bytes(g_abi.ssim_scratch_bytes(B, C, H, W), a);   // the means, as per-workgroup partial sums until a program_eval finishes them
+  Tensor means = at::empty({2}, a.options());                               // [l1_mean, ssim_mean], filled by the first program_eval
   Tensor dmap = at::empty_like(a);
-  check(g_abi.pair_forward(dev.stream, B, C, H, W, fp(a), fp(b), scratch.data_ptr(), fp(ssim), fp(l1), fp(dmap)), "l1_ssim_pair_forward");
-  return {l1, ssim, dmap, a, b};
+  check(g_abi.pair_forward(dev.stream, B, C, H, W, fp(a), fp(b), scratch.data_ptr(), fp(dmap)), "l1_ssim_pair_forward");
+  return {means, scratch, dmap, a, b};
 }
 
 struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
-  // image: the tensor the caller differentiates (what was handed to l1_loss); a / b / dmap / l1 / ssim: loss_pair_forward's results
-  static Tensor forward(AutogradContext* ctx, Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor l1, Tensor ssim,
+  // image: the tensor the caller differentiates (what was handed to l1_loss); a / b / dmap / means / scratch: loss_pair_forward's results
+  static Tensor forward(AutogradContext* ctx, Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch,
                         std::vector<int64_t> ops, std::vector<double> consts, double c_l1, double c_ssim) {
     TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
     TORCH_CHECK(ops.size() == consts.size() && !ops.empty() && ops.size() <= MI355GS_LOSS_PROGRAM_MAX, "loss_affine: 1..16 operations");
-    TORCH_CHECK(image.numel() == a.numel(), "loss_affine: image and its contiguous copy differ in size");
+    TORCH_CHECK(image.numel() == a.numel() && means.numel() == 2, "loss_affine: image and its contiguous copy differ in size");
+    const int64_t o = a.dim() == 4 ? 1 : 0;
+    const int B = o ? (int)a.size(0) : 1, C = (int)a.size(o), H = (int)a.size(o + 1), W = (int)a.size(o + 2);
     const DeviceScope dev(a);
     int32_t op32[MI355GS_LOSS_PROGRAM_MAX]; float k32[MI355GS_LOSS_PROGRAM_MAX];
     for (size_t i = 0; i < ops.size(); ++i) { op32[i] = (int32_t)ops[i]; k32[i] = (float)consts[i]; }
     Tensor out = at::empty({}, a.options());
-    check(g_abi.program_eval(dev.stream, (int)ops.size(), op32, k32, fp(l1), fp(ssim), fp(out)), "loss_program_eval");
+    check(g_abi.program_eval(dev.stream, (int)ops.size(), op32, k32, B, C, H, W, scratch.data_ptr(), fp(means) + 1, fp(means), fp(out)),
+          "loss_program_eval");
     ctx->save_for_backward({a, b, dmap});
     ctx->saved_data["c"] = std::vector<double>{c_l1, c_ssim};
     ctx->saved_data["shape"] = image.sizes().vec();
@@ -731,17 +734,17 @@ struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
   }
 };
 
-Tensor loss_affine(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor l1, Tensor ssim, std::vector<int64_t> ops,
+Tensor loss_affine(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch, std::vector<int64_t> ops,
                    std::vector<double> consts, double c_l1, double c_ssim) {
-  return LossAffineFn::apply(image, a, b, dmap, l1, ssim, ops, consts, c_l1, c_ssim);
+  return LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim);
 }
 
 // loss.backward() of a recorded expression (train.py:177) in one call: the node is created and the engine run from here — no
 // Python frames of torch.autograd.backward in between — with a cached 1 per device as the root gradient (autograd's own
 // ones_like(loss) is a fill launch per iteration; the node only reads the value).  Returns the materialised tensor.
-Tensor loss_affine_backward(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor l1, Tensor ssim, std::vector<int64_t> ops,
+Tensor loss_affine_backward(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch, std::vector<int64_t> ops,
                             std::vector<double> consts, double c_l1, double c_ssim) {
-  Tensor out = LossAffineFn::apply(image, a, b, dmap, l1, ssim, ops, consts, c_l1, c_ssim);
+  Tensor out = LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim);
   if (!out.requires_grad()) return out;
   static std::mutex mu;
   static std::map<std::string, Tensor> ones;
@@ -946,7 +949,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pose_row", &pose_row, "GaussianModel.get_RT: row `index` of the [views, 7] pose table as a node the render node's backward cooperates with");
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);
-  m.def("loss_pair_forward", &loss_pair_forward, "-> [l1_mean, ssim_mean, d(ssim_mean)/dimg1, img1, img2 (contiguous)]: one pass, no autograd node");
+  m.def("loss_pair_forward", &loss_pair_forward, "-> [means (l1, ssim: filled by the first loss_affine), partial sums, d(ssim_mean)/dimg1, img1, img2 (contiguous)]: one launch, no autograd node");
   m.def("loss_affine_backward", &loss_affine_backward, "loss_affine + the engine run of loss.backward() in one call (root gradient: a cached 1)");
   m.def("loss_affine", &loss_affine, "the recorded scalar expression over (l1_mean, ssim_mean) as ONE node on `image`");
   m.def("fused_ssim", &fused_ssim);

@@ -1,22 +1,22 @@
-"""The reference's loss expression AS WRITTEN, on four launches instead of sixteen (reference train.py:171-176):
+"""The reference's loss expression AS WRITTEN, on three launches instead of sixteen (reference train.py:171-176):
 
     Ll1 = l1_loss(image, gt_image)
     ssim_value = fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
     loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim_value)
     loss.backward()
 
-With the operator packages aliased and NO change to that source text:
+With the operator packages aliased and NO change to that source text (three launches):
 
   * `l1_loss(image, gt)` on an image that is being differentiated runs ONE pass over the two images
-    (mi355gs_l1_ssim_pair_forward: both means and d(ssim_mean)/d(image)) and keeps the result here, keyed on the two tensors'
+    (mi355gs_l1_ssim_pair_forward, one launch: d(ssim_mean)/d(image) and both means as per-workgroup partial sums) and keeps the result here, keyed on the two tensors'
     memory and version counters (and holding them, so the memory cannot be handed to another tensor meanwhile);
   * `fused_ssim(image[None], gt[None])` on the same two tensors takes the other half from that record: no launch;
   * both return a `LazyScalar` — a `torch.Tensor` subclass that RECORDS multiplication / division by Python numbers, addition
     and subtraction of Python numbers and of each other, and negation as a short postfix program instead of launching a
     kernel per operation (every such launch is a few microseconds the GPU idles through: the loop is launch-bound);
   * anything else that touches one — `.backward()`, `.item()`, `print`, any other torch function — first turns the recorded
-    expression into an ordinary tensor: ONE autograd node on `image` whose forward evaluates the program in one launch, with one
-    float32 rounding per recorded operation (the bits eager PyTorch computes for the same expression), and whose backward is
+    expression into an ordinary tensor: ONE autograd node on `image` whose forward finishes the two means and evaluates the program in
+    one launch, with one float32 rounding per recorded operation (the bits eager PyTorch computes for the same expression), and whose backward is
     one launch over the image.
 
 What cannot see the recorded expression — a C++ extension handed the object directly, `torch.autograd.backward(loss)` (which,
@@ -56,17 +56,26 @@ def _tensor_key(t):
 
 class Pair:
     """One pair forward: the two tensors it was computed from (held: their memory stays theirs) and its results."""
-    __slots__ = ("image", "gt", "image_key", "gt_key", "a", "b", "dmap", "l1", "ssim", "dev")
+    __slots__ = ("image", "gt", "image_key", "gt_key", "a", "b", "dmap", "means", "scratch", "dev")
 
     def __init__(self, image, gt):
+        # means = [l1_mean, ssim_mean]: per-workgroup partial sums in `scratch` until the first materialisation finishes them
         ext = _lib.compiled()
         if ext is not None:
-            self.l1, self.ssim, self.dmap, self.a, self.b = ext.loss_pair_forward(image, gt)
+            self.means, self.scratch, self.dmap, self.a, self.b = ext.loss_pair_forward(image, gt)
         else:
-            self.l1, self.ssim, self.dmap, self.a, self.b = _pair_forward_ctypes(image, gt)
+            self.means, self.scratch, self.dmap, self.a, self.b = _pair_forward_ctypes(image, gt)
         self.image, self.gt = image, gt
         self.image_key, self.gt_key = _tensor_key(image), _tensor_key(gt)
         self.dev = self.a.device
+
+    @property
+    def l1(self):
+        return self.means[0]
+
+    @property
+    def ssim(self):
+        return self.means[1]
 
     def matches(self, img1, img2):
         return (_tensor_key(img1) == self.image_key and _tensor_key(img2) == self.gt_key and img1.is_contiguous() and img2.is_contiguous()
@@ -172,7 +181,7 @@ def materialize(x):
     ops, consts = [p[0] for p in x._prog], [float(p[1]) for p in x._prog]
     ext = _lib.compiled()
     if ext is not None:
-        real = ext.loss_affine(rec.image, rec.a, rec.b, rec.dmap, rec.l1, rec.ssim, ops, consts, c_l1, c_ssim)
+        real = ext.loss_affine(rec.image, rec.a, rec.b, rec.dmap, rec.means, rec.scratch, ops, consts, c_l1, c_ssim)
     else:
         real = _LossAffine.apply(rec.image, rec, ops, consts, c_l1, c_ssim)
     x._real = real
@@ -305,7 +314,7 @@ class LazyScalar(torch.Tensor):
                 if ext is not None and rec.image.requires_grad:
                     c_l1, c_ssim = partials(self._prog)
                     prog = self._prog
-                    self._real = ext.loss_affine_backward(rec.image, rec.a, rec.b, rec.dmap, rec.l1, rec.ssim, [p[0] for p in prog],
+                    self._real = ext.loss_affine_backward(rec.image, rec.a, rec.b, rec.dmap, rec.means, rec.scratch, [p[0] for p in prog],
                                                           [p[1] for p in prog], c_l1, c_ssim)
                     return None
         return materialize(self).backward(gradient, retain_graph, create_graph, inputs)
@@ -345,12 +354,12 @@ def _pair_forward_ctypes(img1, img2):
     B = a.shape[0] if a.dim() == 4 else 1
     C, H, W = a.shape[-3:]
     scratch = torch.empty(int(L.mi355gs_ssim_scratch_bytes(B, C, H, W)), dtype=torch.uint8, device=dev)
-    l1, ssim = torch.empty((), dtype=torch.float32, device=dev), torch.empty((), dtype=torch.float32, device=dev)
+    means = torch.empty(2, dtype=torch.float32, device=dev)
     dmap = torch.empty_like(a)
     with _lib.on_device(dev):
         _lib.check(L.mi355gs_l1_ssim_pair_forward(_lib.stream_ptr(dev), B, C, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(scratch),
-                                                  _lib.ptr(ssim), _lib.ptr(l1), _lib.ptr(dmap)), "l1_ssim_pair_forward")
-    return l1, ssim, dmap, a, b
+                                                  _lib.ptr(dmap)), "l1_ssim_pair_forward")
+    return means, scratch, dmap, a, b
 
 
 class _LossAffine(torch.autograd.Function):
@@ -361,9 +370,13 @@ class _LossAffine(torch.autograd.Function):
         dev = rec.dev
         out = torch.empty((), dtype=torch.float32, device=dev)
         n = len(ops)
+        a = rec.a
+        B = a.shape[0] if a.dim() == 4 else 1
+        C, H, W = a.shape[-3:]
         with _lib.on_device(dev):
-            _lib.check(L.mi355gs_loss_program_eval(_lib.stream_ptr(dev), n, (ctypes.c_int32 * n)(*ops), (ctypes.c_float * n)(*consts),
-                                                   _lib.ptr(rec.l1), _lib.ptr(rec.ssim), _lib.ptr(out)), "loss_program_eval")
+            _lib.check(L.mi355gs_loss_program_eval(_lib.stream_ptr(dev), n, (ctypes.c_int32 * n)(*ops), (ctypes.c_float * n)(*consts), B, C, H, W,
+                                                   _lib.ptr(rec.scratch), rec.means.data_ptr() + 4, rec.means.data_ptr(), _lib.ptr(out)),
+                       "loss_program_eval")
         ctx.save_for_backward(rec.a, rec.b, rec.dmap)
         ctx.c, ctx.shape = (c_l1, c_ssim), image.shape
         return out

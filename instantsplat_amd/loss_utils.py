@@ -10,7 +10,7 @@
 
 `l1_loss` on an image that is being differentiated is the first half of the training loss (train.py:171-176): it runs one pass
 that computes L1 and SSIM together, the `fused_ssim` call on the same tensors takes its half from it, and the scalar arithmetic of
-train.py:176 is recorded on the host and evaluated in one launch (lazy_loss.py: four launches for the reference's sixteen, the
+train.py:176 is recorded on the host and evaluated in one launch (lazy_loss.py: three launches for the reference's sixteen, the
 source text unchanged — bench.py's headline loop).  Any other `l1_loss` call is ONE autograd node over
 `mi355gs_l1_loss_forward / _backward` (two launches forward, one backward) where the reference's expression is three eager
 kernels forward and four backward.  Alias it like the operator

@@ -259,6 +259,33 @@ def test_new_entry_points_reject_bad_arguments():
                                         p, p, p, rows, row, 0, 0)
     assert posed_backward(-1, 0) == EINVAL and posed_backward(3, 3) == EINVAL and posed_backward(3, -1) == EINVAL
     assert L.mi355gs_error_string(EINVAL)
+    # ---- ABI v9
+    I = lambda *v: (ctypes.c_int32 * len(v))(*v)
+    Fl = lambda *v: (ctypes.c_float * len(v))(*v)
+    assert L.mi355gs_raster_forward_render_only(None, 4, 0, 16, 64, p, p, p, p, p, 0) == EINVAL          # W = 0
+    assert L.mi355gs_raster_forward_render_only(None, 4, 16, 16, 64, p, p, p, None, p, 0) == EINVAL      # capacity without a buffer
+    assert 0 < L.mi355gs_raster_binning_bytes_render_only(1000, 64, 64) < L.mi355gs_raster_binning_bytes(1000, 64, 64)
+    assert L.mi355gs_raster_binning_bytes_render_only(1000, 64, 64) >= 12 * 1000 and L.mi355gs_raster_binning_bytes_render_only(1000, 0, 64) == 0
+    assert L.mi355gs_l1_ssim_pair_forward(None, 1, 3, 0, 8, p, p, p, p) == EINVAL and L.mi355gs_l1_ssim_pair_forward(None, 1, 3, 8, 8, p, p, None, p) == EINVAL
+    assert L.mi355gs_l1_ssim_pair_backward(None, 0, p, p, p, p, 1.0, p, 1.0, p) == EINVAL
+    assert L.mi355gs_l1_ssim_pair_backward(None, 16, p, p, None, p, 1.0, p, 1.0, p) == EINVAL            # an SSIM term without its gradient map
+    prog = lambda ops: L.mi355gs_loss_program_eval(None, len(ops), I(*ops), Fl(*([0.5] * len(ops))), 1, 3, 8, 8, p, p, p, p)
+    assert prog([2]) == EINVAL            # MULK on an empty stack
+    assert prog([0, 1]) == EINVAL         # two values left
+    assert prog([0, 7]) == EINVAL         # ADD with one operand
+    assert prog([0, 9]) == EINVAL         # unknown operation
+    assert L.mi355gs_loss_program_eval(None, 17, I(*([0] * 17)), Fl(*([0.0] * 17)), 1, 3, 8, 8, p, p, p, p) == EINVAL
+    assert L.mi355gs_loss_program_eval(None, 1, I(0), Fl(0.0), 1, 3, 8, 8, None, p, p, p) == EINVAL
+    for knob in (L.mi355gs_tune_scale_grad, L.mi355gs_tune_deterministic):   # query-only calls change nothing
+        assert knob(-1) == 0 and knob(1) == 0 and knob(-1) == 1 and knob(0) == 1 and knob(-1) == 0
+    assert L.mi355gs_raster_grad_scratch_bytes(1000) == L.mi355gs_raster_grad_gate_offset(1000) + 256
+    L.mi355gs_tune_deterministic(1)
+    try:   # the deterministic mode enters the size queries
+        assert L.mi355gs_raster_grad_scratch_bytes(1000) >= L.mi355gs_raster_grad_gate_offset(1000) + 256 + 4 * 1001
+        det_bytes = L.mi355gs_raster_binning_bytes(1000, 64, 64)
+    finally:
+        L.mi355gs_tune_deterministic(0)
+    assert det_bytes >= L.mi355gs_raster_binning_bytes(1000, 64, 64) + 52 * 1000
 
 
 def test_render_only_forward_is_bit_identical(emu):
