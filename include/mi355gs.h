@@ -154,7 +154,7 @@ int mi355gs_tune_min_units(int min_units);
  * bit-identical gradients run to run, and with them bit-identical training.  Same arithmetic otherwise; costs five small
  * launches, a memset and 52 bytes per instance per backward (measured at C3: 0.84-0.87 x the default rate).
  * It enters the buffer-size queries (mi355gs_raster_binning_bytes: + 52 B per instance; mi355gs_raster_grad_scratch_bytes:
- * + ~8 B per Gaussian): set it before sizing a frame's buffers and keep it until that frame's backward has been enqueued; a
+ * + ~4 B per Gaussian): set it before sizing a frame's buffers and keep it until that frame's backward has been enqueued; a
  * trainer handle takes a snapshot at mi355gs_trainer_create.  The work-counting instantiation (mi355gs_profile_work_counters)
  * is not available in this mode.  Returns the previous value; on < 0 only queries.  Process-wide. */
 int mi355gs_tune_deterministic(int on);
