@@ -20,3 +20,17 @@ for i in range(3): fb(st.cameras[i])
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(12): fb(st.cameras[i])
 torch.cuda.synchronize(); print(f"C4 render+loss+backward: {1e3*(time.perf_counter()-t0)/12:.3f} ms / view")
+# the render-only forward on the same views (every no-grad render: mi355gs_raster_forward_render_only), and the deterministic backward
+with torch.no_grad():
+    for i in range(3): render(st.cameras[i], g, st.pipe, st.background, camera_pose=g.get_RT(i))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(12): render(st.cameras[i], g, st.pipe, st.background, camera_pose=g.get_RT(i))
+    torch.cuda.synchronize(); print(f"C4 render, no grad (render-only forward): {1e3*(time.perf_counter()-t0)/12:.3f} ms / view")
+if os.environ.get("GS_C4_DET", "1") == "1":
+    import instantsplat_amd.diff_gaussian_rasterization as dgr
+    dgr.set_deterministic(True)
+    for i in range(3): fb(st.cameras[i])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(12): fb(st.cameras[i])
+    torch.cuda.synchronize(); print(f"C4 render+loss+backward, deterministic-backward mode: {1e3*(time.perf_counter()-t0)/12:.3f} ms / view")
+    dgr.set_deterministic(False)
