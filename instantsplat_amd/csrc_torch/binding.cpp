@@ -747,15 +747,18 @@ Tensor loss_affine_backward(Tensor image, Tensor a, Tensor b, Tensor dmap, Tenso
   Tensor out = LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim);
   if (!out.requires_grad()) return out;
   static std::mutex mu;
-  static std::map<std::string, Tensor> ones;
+  static std::map<std::string, std::pair<Tensor, uint32_t>> ones;   // per device: the 1 and its version counter as created
   Tensor one;
   {
     std::lock_guard<std::mutex> lock(mu);
     std::ostringstream key;
     key << out.device();
-    Tensor& slot = ones[key.str()];
-    if (!slot.defined() || slot._version() != 0) slot = at::ones({}, out.options().requires_grad(false));   // (written to: a fresh one)
-    one = slot;
+    auto& slot = ones[key.str()];
+    if (!slot.first.defined() || slot.first._version() != slot.second) {   // (written to since: a fresh one)
+      slot.first = at::ones({}, out.options().requires_grad(false));
+      slot.second = slot.first._version();   // (at::ones fills in place: the counter does not start at 0)
+    }
+    one = slot.first;
   }
   py::gil_scoped_release nogil;   // the engine's worker threads take the GIL themselves for Python-defined nodes
   torch::autograd::backward({out}, {one}, /*retain_graph=*/false, /*create_graph=*/false);

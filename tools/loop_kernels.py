@@ -1,6 +1,7 @@
 """Which kernels does ONE iteration of a loop launch?  Runs N iterations of one of the bench's loops on the C3 scene (after an
 untimed warm-up) — run it under `tools/prof.sh <name> python tools/loop_kernels.py <loop> <N>` and divide the calls by N.
-loop: dropin | dropin_torch_l1 | one_call | run_ahead.   Measurement helper, not product code."""
+loop: dropin_train_py (train.py's loss lines as written: bench.py's headline) | dropin (the loss as one fused call) | dropin_eager
+(lazy_loss off) | dropin_torch_l1 | one_call | run_ahead.   Measurement helper, not product code."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +17,11 @@ if loop == "run_ahead":
     ra = RunAhead(st, window=10)
     step = ra.step
 else:
-    step = {"dropin": lambda: train_iteration(st), "dropin_torch_l1": lambda: train_iteration(st, fused_loss=False),
+    if loop == "dropin_eager":
+        from instantsplat_amd import lazy_loss
+        lazy_loss.ENABLED = False
+    step = {"dropin": lambda: train_iteration(st), "dropin_train_py": lambda: train_iteration(st, fused_loss=False),
+            "dropin_eager": lambda: train_iteration(st, fused_loss=False), "dropin_torch_l1": lambda: train_iteration(st, fused_loss="torch"),
             "one_call": lambda: train_iteration(st, fused_step=True)}[loop]
 for _ in range(N):
     step()
