@@ -245,6 +245,10 @@ int mi355gs_l1_loss_backward(void* stream, int64_t n, const float* a, const floa
  *     one rounding per operation (what eager PyTorch computes for the same expression):
  *     L1 / SSIM push a mean; MULK x*k, ADDK x+k, RSUBK k-x, DIVK x*(1/k), NEG -x act on the top of the stack; ADD / SUB pop two
  *     (a b -> a+b, a-b).  *out = the one value left.  A program that underflows the stack or leaves more than one value is refused.
+ *     host_out (may be null; 8-byte aligned float[2]): a second destination the DEVICE can write and the HOST can read without a
+ *     copy — pinned host memory mapped into the device's address space: the kernel stores (value, ticket) there as one 8-byte
+ *     store.  A caller that presets the slot and polls for its ticket has the value as soon as this launch has run — reference
+ *     train.py:188 `loss.item()` then neither enqueues a copy nor waits for the backward kernels queued behind the loss.
  *   pair_backward: d_img1[n] = ((g_l1 ? *g_l1 : 1) * c_l1 / n) * sgn(img1 - img2) + ((g_ssim ? *g_ssim : 1) * c_ssim) * dssim_dimg1
  *     — the gradient of  c_l1 * l1_mean + c_ssim * ssim_mean  scaled by incoming gradients read from device scalars (autograd's own
  *     operation order for abs(a - b).mean()); dssim_dimg1 may be null when c_ssim == 0.
@@ -264,7 +268,7 @@ int mi355gs_l1_ssim_pair_forward(void* stream, int B, int C, int H, int W, const
 int mi355gs_l1_ssim_pair_backward(void* stream, int64_t n, const float* img1, const float* img2, const float* dssim_dimg1,
                                   const float* g_l1, float c_l1, const float* g_ssim, float c_ssim, float* d_img1);
 int mi355gs_loss_program_eval(void* stream, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
-                              const void* scratch, float* ssim_mean, float* l1_mean, float* out);
+                              const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket);
 
 /* ------------------------------------------------------------------------------------------------
  * simple-knn

@@ -50,7 +50,7 @@ _SIGNATURES = {
     "mi355gs_l1_ssim_loss_fused": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P]),
     "mi355gs_l1_ssim_pair_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "mi355gs_l1_ssim_pair_backward": (c_int, [_P, c_int64, _P, _P, _P, _P, c_float, _P, c_float, _P]),
-    "mi355gs_loss_program_eval": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "mi355gs_loss_program_eval": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float]),
     "mi355gs_knn_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_knn_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "mi355gs_adam_step": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int]),

@@ -530,7 +530,8 @@ struct GsLossProgram {
 // One launch: the two means finished from the pass's per-workgroup partial sums (the reduction of k_ssim_finish: double
 // accumulation, fixed order — the same bits), left in *ssim_mean / *l1_mean, then the recorded program evaluated on them.
 __global__ __launch_bounds__(1024) void k_loss_program(GsLossProgram p, int nblocks, double inv_n, const float* __restrict__ partial,
-                                                      float* __restrict__ ssim_mean, float* __restrict__ l1_mean, float* __restrict__ out) {
+                                                      float* __restrict__ ssim_mean, float* __restrict__ l1_mean, float* __restrict__ out,
+                                                      float* __restrict__ host_out, float ticket) {
 #pragma clang fp contract(off)   // one rounding per recorded operation, as eager PyTorch's elementwise kernels
   __shared__ double s_a[16], s_b[16];
   double a = 0.0, b = 0.0;
@@ -561,7 +562,15 @@ __global__ __launch_bounds__(1024) void k_loss_program(GsLossProgram p, int nblo
       default: break;
     }
   }
-  *out = sp > 0 ? st[sp - 1] : 0.f;
+  const float value = sp > 0 ? st[sp - 1] : 0.f;
+  *out = value;
+  // ... and, if asked, straight to the host: (value, ticket) as ONE 8-byte store into pinned, device-mapped memory — whoever
+  // polls the ticket has the value without a copy, a stream synchronisation or a wait for the kernels enqueued behind this one
+  if (host_out) {
+    typedef float v2f __attribute__((vector_size(8)));
+    v2f both = {value, ticket};
+    *reinterpret_cast<v2f*>(host_out) = both;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_loss_pair_bwd(long long n, const float* __restrict__ a, const float* __restrict__ b,
@@ -717,11 +726,11 @@ int mi355gs_l1_ssim_pair_backward(void* stream_, int64_t n, const float* img1, c
 }
 
 int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
-                              const void* scratch, float* ssim_mean, float* l1_mean, float* out) {
+                              const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket) {
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (n_ops <= 0 || n_ops > MI355GS_LOSS_PROGRAM_MAX || !ops || !consts || !scratch || !l1_mean || !ssim_mean || !out) return MI355GS_EINVAL;
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return MI355GS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ((uintptr_t)host_out & 7) != 0) return MI355GS_EINVAL;
   GsLossProgram p;
   p.n = n_ops;
   int depth = 0;   // a malformed program (stack underflow, two values left) is refused here, not executed
@@ -737,7 +746,7 @@ int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, cons
   }
   if (depth != 1) return MI355GS_EINVAL;
   hipLaunchKernelGGL(k_loss_program, dim3(1), dim3(1024), 0, stream, p, fused_nblocks(B, C, H, W), 1.0 / ((double)B * C * H * W),
-                     (const float*)scratch, ssim_mean, l1_mean, out);
+                     (const float*)scratch, ssim_mean, l1_mean, out, host_out, ticket);
   GS_CHECK_LAUNCH("loss_program");
   return MI355GS_OK;
 }

@@ -702,8 +702,9 @@ std::vector<Tensor> loss_pair_forward(Tensor img1, Tensor img2) {
 
 struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
   // image: the tensor the caller differentiates (what was handed to l1_loss); a / b / dmap / means / scratch: loss_pair_forward's results
+  // host_slot (may be undefined): float32[2] of pinned host memory the program kernel also stores (value, ticket) into
   static Tensor forward(AutogradContext* ctx, Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch,
-                        std::vector<int64_t> ops, std::vector<double> consts, double c_l1, double c_ssim) {
+                        std::vector<int64_t> ops, std::vector<double> consts, double c_l1, double c_ssim, Tensor host_slot, double ticket) {
     TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
     TORCH_CHECK(ops.size() == consts.size() && !ops.empty() && ops.size() <= MI355GS_LOSS_PROGRAM_MAX, "loss_affine: 1..16 operations");
     TORCH_CHECK(image.numel() == a.numel() && means.numel() == 2, "loss_affine: image and its contiguous copy differ in size");
@@ -713,7 +714,13 @@ struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
     int32_t op32[MI355GS_LOSS_PROGRAM_MAX]; float k32[MI355GS_LOSS_PROGRAM_MAX];
     for (size_t i = 0; i < ops.size(); ++i) { op32[i] = (int32_t)ops[i]; k32[i] = (float)consts[i]; }
     Tensor out = at::empty({}, a.options());
-    check(g_abi.program_eval(dev.stream, (int)ops.size(), op32, k32, B, C, H, W, scratch.data_ptr(), fp(means) + 1, fp(means), fp(out)),
+    float* host_out = nullptr;
+    if (host_slot.defined() && host_slot.numel() >= 2) {
+      TORCH_CHECK(host_slot.scalar_type() == at::kFloat && !host_slot.is_cuda() && host_slot.is_contiguous(), "loss_affine: the host slot is float32[2] host memory");
+      host_out = host_slot.data_ptr<float>();
+    }
+    check(g_abi.program_eval(dev.stream, (int)ops.size(), op32, k32, B, C, H, W, scratch.data_ptr(), fp(means) + 1, fp(means), fp(out), host_out,
+                             (float)ticket),
           "loss_program_eval");
     ctx->save_for_backward({a, b, dmap});
     ctx->saved_data["c"] = std::vector<double>{c_l1, c_ssim};
@@ -730,21 +737,43 @@ struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
     Tensor d = at::empty_like(a);
     check(g_abi.pair_backward(dev.stream, a.numel(), fp(a), fp(b), fp(dmap), fp(g), (float)c[0], fp(g), (float)c[1], fp(d)), "l1_ssim_pair_backward");
     Tensor none;
-    return {d.view(ctx->saved_data["shape"].toIntVector()), none, none, none, none, none, none, none, none, none};
+    return {d.view(ctx->saved_data["shape"].toIntVector()), none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
 Tensor loss_affine(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch, std::vector<int64_t> ops,
-                   std::vector<double> consts, double c_l1, double c_ssim) {
-  return LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim);
+                   std::vector<double> consts, double c_l1, double c_ssim, Tensor host_slot, double ticket) {
+  return LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim, host_slot, ticket);
+}
+
+// train.py:188 `loss.item()` for a value the program kernel has also stored to a pinned host slot: spin (GIL released) until the
+// slot carries this materialisation's ticket.  NaN-boxed "not there" on timeout or when a later materialisation has taken the slot
+// over — the caller then reads the tensor the ordinary way.
+py::object wait_for_loss(Tensor host_slot, double ticket, int64_t timeout_us) {
+  TORCH_CHECK(host_slot.scalar_type() == at::kFloat && !host_slot.is_cuda() && host_slot.numel() >= 2, "wait_for_loss: float32[2] host memory");
+  const volatile float* w = host_slot.data_ptr<float>();
+  const float want = (float)ticket;
+  bool there = w[1] == want;
+  if (!there) {
+    py::gil_scoped_release nogil;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+      if (w[1] == want) { there = true; break; }
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(timeout_us)) break;
+    }
+  }
+  if (!there) return py::none();
+  const float v = w[0];
+  if (w[1] != want) return py::none();   // (taken over between the two reads)
+  return py::float_((double)v);
 }
 
 // loss.backward() of a recorded expression (train.py:177) in one call: the node is created and the engine run from here — no
 // Python frames of torch.autograd.backward in between — with a cached 1 per device as the root gradient (autograd's own
 // ones_like(loss) is a fill launch per iteration; the node only reads the value).  Returns the materialised tensor.
 Tensor loss_affine_backward(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch, std::vector<int64_t> ops,
-                            std::vector<double> consts, double c_l1, double c_ssim) {
-  Tensor out = LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim);
+                            std::vector<double> consts, double c_l1, double c_ssim, Tensor host_slot, double ticket) {
+  Tensor out = LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim, host_slot, ticket);
   if (!out.requires_grad()) return out;
   static std::mutex mu;
   static std::map<std::string, std::pair<Tensor, uint32_t>> ones;   // per device: the 1 and its version counter as created
@@ -953,6 +982,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);
   m.def("loss_pair_forward", &loss_pair_forward, "-> [means (l1, ssim: filled by the first loss_affine), partial sums, d(ssim_mean)/dimg1, img1, img2 (contiguous)]: one launch, no autograd node");
+  m.def("wait_for_loss", &wait_for_loss, "the value the program kernel stored to a pinned host slot under this ticket, or None (timeout / slot taken over)");
   m.def("loss_affine_backward", &loss_affine_backward, "loss_affine + the engine run of loss.backward() in one call (root gradient: a cached 1)");
   m.def("loss_affine", &loss_affine, "the recorded scalar expression over (l1_mean, ssim_mean) as ONE node on `image`");
   m.def("fused_ssim", &fused_ssim);

@@ -117,7 +117,7 @@ def forget():
 # ---- the lazy scalar ---------------------------------------------------------------------------------------------------------
 def _new(rec, prog):
     t = torch.Tensor._make_subclass(LazyScalar, _placeholder(rec.dev), False)
-    t._rec, t._prog, t._real = rec, prog, None
+    t._rec, t._prog, t._real, t._slot = rec, prog, None, None
     return t
 
 
@@ -127,6 +127,30 @@ def _is_number(k):
 
 def _is_lazy(x):
     return type(x) is LazyScalar
+
+
+# ---- where `loss.item()` (train.py:188) finds its value: the program kernel stores (value, ticket) into a slot of pinned,
+# device-mapped host memory as well, and item() polls the slot for its ticket — no device-to-host copy is enqueued and, above all,
+# the read does not wait for the backward kernels queued behind the loss: the host goes on to optimizer.step() and the next
+# frame's launches while the device still works on this iteration's backward (stream order keeps everything correct), so the
+# device never idles through the reference loop's host work.  EARLY_ITEM = False restores the ordinary read (copy + stream wait).
+EARLY_ITEM = os.environ.get("MI355GS_EARLY_ITEM", "1") != "0"
+_NO_SLOT = torch.empty(0)   # "no host slot" for the compiled nodes (an empty tensor: pybind takes no None for a Tensor)
+_SLOTS = {}          # device -> [pinned float32[N, 2], next index]
+_N_SLOTS = 64
+_TICKET = [0]
+
+
+def _host_slot(dev):
+    """-> (float32[2] view of a pinned slot, ticket): the slot is reused after _N_SLOTS materialisations, the ticket says whose value it holds"""
+    ring = _SLOTS.get(dev)
+    if ring is None:
+        words = torch.zeros(_N_SLOTS, 2, dtype=torch.float32, pin_memory=(dev.type == "cuda"))
+        ring = _SLOTS[dev] = [words, [words[i] for i in range(_N_SLOTS)], 0]
+    k = ring[2]
+    ring[2] = (k + 1) % _N_SLOTS
+    t = _TICKET[0] = _TICKET[0] % 16000000 + 1    # exactly representable in float32, never 0
+    return ring[1][k], float(t)
 
 
 _PARTIALS = {}
@@ -181,9 +205,12 @@ def materialize(x):
     ops, consts = [p[0] for p in x._prog], [float(p[1]) for p in x._prog]
     ext = _lib.compiled()
     if ext is not None:
-        real = ext.loss_affine(rec.image, rec.a, rec.b, rec.dmap, rec.means, rec.scratch, ops, consts, c_l1, c_ssim)
+        slot, ticket = _host_slot(rec.dev) if EARLY_ITEM else (None, 0.0)
+        real = ext.loss_affine(rec.image, rec.a, rec.b, rec.dmap, rec.means, rec.scratch, ops, consts, c_l1, c_ssim, _NO_SLOT if slot is None else slot, ticket)
+        x._slot = (slot, ticket) if slot is not None else None
     else:
         real = _LossAffine.apply(rec.image, rec, ops, consts, c_l1, c_ssim)
+        x._slot = None
     x._real = real
     return real
 
@@ -314,14 +341,26 @@ class LazyScalar(torch.Tensor):
                 if ext is not None and rec.image.requires_grad:
                     c_l1, c_ssim = partials(self._prog)
                     prog = self._prog
+                    slot, ticket = _host_slot(rec.dev) if EARLY_ITEM else (None, 0.0)
                     self._real = ext.loss_affine_backward(rec.image, rec.a, rec.b, rec.dmap, rec.means, rec.scratch, [p[0] for p in prog],
-                                                          [p[1] for p in prog], c_l1, c_ssim)
+                                                          [p[1] for p in prog], c_l1, c_ssim, _NO_SLOT if slot is None else slot, ticket)
+                    self._slot = (slot, ticket) if slot is not None else None
                     return None
         return materialize(self).backward(gradient, retain_graph, create_graph, inputs)
 
     def item(self):
-        """train.py:188"""
-        return materialize(self).item()
+        """train.py:188.  The value comes from the pinned slot the program kernel stored it in, if this materialisation has one
+        (module comment at EARLY_ITEM): the same bits as the tensor's, without a copy and without waiting for the kernels
+        enqueued behind the loss."""
+        real = materialize(self)
+        slot = self._slot
+        if slot is not None:
+            ext = _lib.compiled()
+            if ext is not None:
+                v = ext.wait_for_loss(slot[0], slot[1], 200_000)
+                if v is not None:
+                    return v
+        return real.item()
 
     def __float__(self):
         return float(materialize(self).detach())
@@ -375,7 +414,7 @@ class _LossAffine(torch.autograd.Function):
         C, H, W = a.shape[-3:]
         with _lib.on_device(dev):
             _lib.check(L.mi355gs_loss_program_eval(_lib.stream_ptr(dev), n, (ctypes.c_int32 * n)(*ops), (ctypes.c_float * n)(*consts), B, C, H, W,
-                                                   _lib.ptr(rec.scratch), rec.means.data_ptr() + 4, rec.means.data_ptr(), _lib.ptr(out)),
+                                                   _lib.ptr(rec.scratch), rec.means.data_ptr() + 4, rec.means.data_ptr(), _lib.ptr(out), None, 0.0),
                        "loss_program_eval")
         ctx.save_for_backward(rec.a, rec.b, rec.dmap)
         ctx.c, ctx.shape = (c_l1, c_ssim), image.shape

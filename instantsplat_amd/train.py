@@ -28,6 +28,7 @@ from .synthetic import PointmapScene
 
 
 from .loss_utils import l1_loss   # reference utils/loss_utils.py:39-40 as one HIP node
+from .lazy_loss import LazyScalar
 
 
 def psnr(img1, img2):
@@ -160,7 +161,9 @@ def _forward_backward_step(st: TrainState, fused_loss: bool):
         Ll1 = l1_loss(image, gt) if fused_loss is False else torch.abs((image - gt)).mean()
         loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - fused_ssim(image.unsqueeze(0), gt.unsqueeze(0)))
     loss.backward()
-    return loss.detach()
+    # (train.py:188 calls `.item()` on `loss` itself: with the loss lines as written that is a LazyScalar whose item() reads the
+    # value from pinned host memory without waiting for the backward, lazy_loss.py — a detached copy would take the ordinary read)
+    return loss if type(loss) is LazyScalar else loss.detach()
 
 
 def _optimizer_step(st: TrainState):

@@ -1561,6 +1561,30 @@ def check_lazy_loss_expression(dev, H=40, W=56):
     assert g.shape == img.shape and float(g.abs().sum()) > 0
     with pytest.raises(RuntimeError):     # the one entry point that does not consult __torch_function__: a loud failure, not a wrong number
         torch.autograd.backward(0.5 * a)
+    # ---- loss.item() (train.py:188) from the pinned slot the program kernel also stored the value in: the tensor's bits, without
+    # a copy; a slot that later materialisations have taken over falls back to the tensor; EARLY_ITEM = False never takes one
+    from instantsplat_amd import _lib as _l
+    leaf, img = image()
+    a, b = l1_loss(img, gt), fused_ssim(img.unsqueeze(0), gt.unsqueeze(0))
+    first = 0.8 * a + 0.2 * (1.0 - b)
+    first.backward()
+    assert (first._slot is not None) == (_l.compiled() is not None)
+    v_first = first.item()
+    assert v_first == float(first._real.detach()) and isinstance(v_first, float)
+    for _ in range(lazy_loss._N_SLOTS + 3):
+        leaf2, img2 = image()
+        a2 = l1_loss(img2, gt)
+        (a2 * 2.0).item()
+    assert first.item() == v_first and first._real.item() == v_first
+    was_early, lazy_loss.EARLY_ITEM = lazy_loss.EARLY_ITEM, False
+    try:
+        leaf2, img2 = image()
+        a2, b2 = l1_loss(img2, gt), fused_ssim(img2.unsqueeze(0), gt.unsqueeze(0))
+        late = 0.8 * a2 + 0.2 * (1.0 - b2)
+        late.backward()
+        assert late._slot is None and late.item() == v_first
+    finally:
+        lazy_loss.EARLY_ITEM = was_early
     # ---- when the second call is NOT the other half
     leaf, img = image()
     a = l1_loss(img, gt)

@@ -269,13 +269,14 @@ def test_new_entry_points_reject_bad_arguments():
     assert L.mi355gs_l1_ssim_pair_forward(None, 1, 3, 0, 8, p, p, p, p) == EINVAL and L.mi355gs_l1_ssim_pair_forward(None, 1, 3, 8, 8, p, p, None, p) == EINVAL
     assert L.mi355gs_l1_ssim_pair_backward(None, 0, p, p, p, p, 1.0, p, 1.0, p) == EINVAL
     assert L.mi355gs_l1_ssim_pair_backward(None, 16, p, p, None, p, 1.0, p, 1.0, p) == EINVAL            # an SSIM term without its gradient map
-    prog = lambda ops: L.mi355gs_loss_program_eval(None, len(ops), I(*ops), Fl(*([0.5] * len(ops))), 1, 3, 8, 8, p, p, p, p)
+    prog = lambda ops: L.mi355gs_loss_program_eval(None, len(ops), I(*ops), Fl(*([0.5] * len(ops))), 1, 3, 8, 8, p, p, p, p, None, 0.0)
     assert prog([2]) == EINVAL            # MULK on an empty stack
     assert prog([0, 1]) == EINVAL         # two values left
     assert prog([0, 7]) == EINVAL         # ADD with one operand
     assert prog([0, 9]) == EINVAL         # unknown operation
-    assert L.mi355gs_loss_program_eval(None, 17, I(*([0] * 17)), Fl(*([0.0] * 17)), 1, 3, 8, 8, p, p, p, p) == EINVAL
-    assert L.mi355gs_loss_program_eval(None, 1, I(0), Fl(0.0), 1, 3, 8, 8, None, p, p, p) == EINVAL
+    assert L.mi355gs_loss_program_eval(None, 17, I(*([0] * 17)), Fl(*([0.0] * 17)), 1, 3, 8, 8, p, p, p, p, None, 0.0) == EINVAL
+    assert L.mi355gs_loss_program_eval(None, 1, I(0), Fl(0.0), 1, 3, 8, 8, None, p, p, p, None, 0.0) == EINVAL
+    assert L.mi355gs_loss_program_eval(None, 1, I(0), Fl(0.0), 1, 3, 8, 8, p, p, p, p, ctypes.c_void_p(p.value + 4), 0.0) == EINVAL   # a host slot that is not 8-byte aligned
     for knob in (L.mi355gs_tune_scale_grad, L.mi355gs_tune_deterministic):   # query-only calls change nothing
         assert knob(-1) == 0 and knob(1) == 0 and knob(-1) == 1 and knob(0) == 1 and knob(-1) == 0
     assert L.mi355gs_raster_grad_scratch_bytes(1000) == L.mi355gs_raster_grad_gate_offset(1000) + 256
