@@ -547,7 +547,8 @@ def main():
         from instantsplat_amd.train import training
         long_runs = {}
         for name, ra_flag in (("one_call_run_ahead", True), ("reference_loop_autograd_both_readbacks", False)):
-            r = training(scene, dev, iterations=1000, run_ahead=ra_flag)
+            # (the reference loop with its loss lines as written, like the headline; the one-call loop has the fused loss inside)
+            r = training(scene, dev, iterations=1000, run_ahead=ra_flag, fused_loss=ra_flag)
             long_runs[name] = {"iters_per_sec": r["iters_per_sec"], "seconds": r["seconds"], "psnr_before": r["psnr_before"],
                                "psnr_after": r["psnr_after"]}
             BinningPolicy.reset("exact")
