@@ -2,7 +2,8 @@
 
 The reference gets there with `init_geo.py` (MASt3R: a checkpoint that cannot be obtained offline) followed by `train.py -s
 assets/sora/Art -n 3`.  Here the init stage is REPLACED — plainly: nothing below comes from MASt3R — by
-  * the three committed frames of reference assets/sora/Art/images (tests/golden/sora_art/*.jpg, 1280 x 720),
+  * the three frames of reference assets/sora/Art/images, re-encoded at their native 1280 x 720 (tests/golden/sora_art/*.jpg,
+    tests/golden/make_golden_sora.py),
   * a synthetic pointmap per view (instantsplat_amd.synthetic.syn_pointmap's smooth depth on a Wm x Hm grid, cameras on an arc,
     field of view 60 degrees) whose points take the colour of the frame's pixel they project to, as MASt3R's do,
   * noisy poses / a random confidence map, as syn_pointmap's student gets them,
@@ -14,7 +15,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FRAMES = [os.path.join(HERE, "golden", "sora_art", n) for n in ("0.jpg", "1.jpg", "2.jpg")]
+FRAMES = [os.path.join(HERE, "golden", "sora_art", n) for n in ("art_frame_0.jpg", "art_frame_1.jpg", "art_frame_2.jpg")]
 
 
 def write_sora_init_dir(dst: str, Wm: int = 160, Hm: int = 90, seed: int = 0):
@@ -39,7 +40,7 @@ def write_sora_init_dir(dst: str, Wm: int = 160, Hm: int = 90, seed: int = 0):
     g = torch.Generator().manual_seed(seed + 7)
     pts = sc.points + 0.01 * torch.randn(sc.points.shape, generator=g)
     scene_io.write_init_scene(dst, w2c, [(c.FoVx, c.FoVy) for c in sc.cameras], FRAMES, pts, torch.cat(cols), sc.confidence,
-                              names=[os.path.basename(f) for f in FRAMES])
+                              names=["%d.jpg" % v for v in range(len(FRAMES))])   # the reference's own file names (assets/sora/Art/images/0.jpg ...)
     return W, H
 
 

@@ -25,7 +25,7 @@ def test_sora_init_directory_loads_and_trains(emu, tmp_path):
         sc = scene_io.load_init_scene(str(tmp_path / "Art"), 3, resolution=res, device="cpu")
         assert [(c.image_width, c.image_height) for c in sc.cameras] == [wh] * 3
         c = sc.cameras[0]
-        with Image.open(sora_util.FRAMES[int(c.image_name)]) as im:
+        with Image.open(sora_util.FRAMES[int(c.image_name)]) as im:   # image_name = "0" / "1" / "2": the reference's file names
             ref = torch.from_numpy(np.array(im.resize(wh))).permute(2, 0, 1) / 255.0
         assert torch.equal(c.original_image, ref.float()) and c.original_image.shape == (3, wh[1], wh[0])
         assert abs(np.tan(c.FoVy / 2) / np.tan(c.FoVx / 2) - 720 / 1280) < 1e-6       # the field of view comes from cameras.txt, not from the resized image

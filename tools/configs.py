@@ -57,7 +57,7 @@ print(f"C1' 3 views / {g.get_xyz.shape[0]} Gaussians / 256^2, 50 train iteration
       f"{l_dev[0]:.5f} -> {l_dev[-1]:.5f} (device); largest relative loss difference over the 50 iterations {worst:.2e}")
 del st, g, cpu
 
-# ---- C1 on the reference's own example frames (assets/sora/Art/images, committed as tests/golden/sora_art): 1280 x 720 JPEGs through the
+# ---- C1 on the reference's own example frames (assets/sora/Art/images, re-encoded at native size as tests/golden/sora_art): 1280 x 720 JPEGs through the
 # init-directory loader; MASt3R (unobtainable offline) is replaced by a synthetic pointmap coloured from the frames + arc poses
 import tempfile
 from tests import sora_util
