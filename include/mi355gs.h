@@ -232,7 +232,8 @@ int mi355gs_l1_loss_backward(void* stream, int64_t n, const float* a, const floa
  *     Ll1 = l1_loss(image, gt_image);  ssim_value = fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
  *     loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim_value);  loss.backward()
  * two operator calls on the same pair of images and four scalar operations on 0-dim tensors: sixteen eager launches
- * forward + backward.  These three entry points let a binding serve that source text unmodified in THREE
+ * forward + backward.  These entry points let a binding serve that source text unmodified in three launches — TWO when the
+ * backward follows the materialisation directly (program_eval_grad) —
  * (instantsplat_amd/loss_utils.py, lazy_loss.py: l1_loss runs the pair forward, fused_ssim on the same tensors takes its other half from
  * it, the scalar arithmetic is recorded on the host and evaluated by one launch, the backward of the whole expression is one
  * launch over the image).
@@ -269,6 +270,12 @@ int mi355gs_l1_ssim_pair_backward(void* stream, int64_t n, const float* img1, co
                                   const float* g_l1, float c_l1, const float* g_ssim, float c_ssim, float* d_img1);
 int mi355gs_loss_program_eval(void* stream, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
                               const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket);
+/* program_eval AND pair_backward for dL/d(value) = 1 in ONE launch (g_l1 = g_ssim = 1; c_l1 / c_ssim: the partial derivatives of
+ * the program with respect to the two means): what `loss.backward()` right behind the materialisation needs — the gradient over
+ * the image does not depend on the means, so one workgroup finishes the value while the others write d_img1[B*C*H*W]. */
+int mi355gs_loss_program_eval_grad(void* stream, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
+                                   const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket,
+                                   const float* img1, const float* img2, const float* dssim_dimg1, float c_l1, float c_ssim, float* d_img1);
 
 /* ------------------------------------------------------------------------------------------------
  * simple-knn

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "mi355gs_l1_ssim_pair_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "mi355gs_l1_ssim_pair_backward": (c_int, [_P, c_int64, _P, _P, _P, _P, c_float, _P, c_float, _P]),
     "mi355gs_loss_program_eval": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float]),
+    "mi355gs_loss_program_eval_grad": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_float,
+                                               c_float, _P]),
     "mi355gs_knn_scratch_bytes": (c_size_t, [c_int]),
     "mi355gs_knn_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "mi355gs_adam_step": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int]),
@@ -125,7 +127,8 @@ _EXT_SYMBOLS = ("mi355gs_raster_geom_bytes", "mi355gs_raster_tiles_bytes", "mi35
                 "mi355gs_raster_grad_scratch_bytes", "mi355gs_raster_grad_gate_offset", "mi355gs_posed_forward_preprocess", "mi355gs_raster_forward_preprocess", "mi355gs_raster_backward",
                 "mi355gs_raster_forward_render", "mi355gs_raster_binning_bytes_render_only", "mi355gs_raster_forward_render_only", "mi355gs_posed_backward", "mi355gs_ssim_scratch_bytes", "mi355gs_l1_ssim_loss_fused", "mi355gs_ssim_forward", "mi355gs_ssim_backward",
                 "mi355gs_adam_multi_step", "mi355gs_error_string", "mi355gs_l1_scratch_bytes", "mi355gs_l1_loss_forward", "mi355gs_l1_loss_backward",
-                "mi355gs_l1_ssim_pair_forward", "mi355gs_l1_ssim_pair_backward", "mi355gs_loss_program_eval")
+                "mi355gs_l1_ssim_pair_forward", "mi355gs_l1_ssim_pair_backward", "mi355gs_loss_program_eval",
+                "mi355gs_loss_program_eval_grad")
 
 
 def compiled():

@@ -529,9 +529,9 @@ struct GsLossProgram {
 
 // One launch: the two means finished from the pass's per-workgroup partial sums (the reduction of k_ssim_finish: double
 // accumulation, fixed order — the same bits), left in *ssim_mean / *l1_mean, then the recorded program evaluated on them.
-__global__ __launch_bounds__(1024) void k_loss_program(GsLossProgram p, int nblocks, double inv_n, const float* __restrict__ partial,
-                                                      float* __restrict__ ssim_mean, float* __restrict__ l1_mean, float* __restrict__ out,
-                                                      float* __restrict__ host_out, float ticket) {
+__device__ __forceinline__ void loss_program_body(const GsLossProgram& p, int nblocks, double inv_n, const float* __restrict__ partial,
+                                                  float* __restrict__ ssim_mean, float* __restrict__ l1_mean, float* __restrict__ out,
+                                                  float* __restrict__ host_out, float ticket) {
 #pragma clang fp contract(off)   // one rounding per recorded operation, as eager PyTorch's elementwise kernels
   __shared__ double s_a[16], s_b[16];
   double a = 0.0, b = 0.0;
@@ -573,20 +573,22 @@ __global__ __launch_bounds__(1024) void k_loss_program(GsLossProgram p, int nblo
   }
 }
 
-__global__ __launch_bounds__(256) void k_loss_pair_bwd(long long n, const float* __restrict__ a, const float* __restrict__ b,
-                                                       const float* __restrict__ dssim, const float* __restrict__ g_l1, float c_l1,
-                                                       const float* __restrict__ g_ssim, float c_ssim, float n_as_float,
-                                                       float* __restrict__ d_a) {
+__global__ __launch_bounds__(1024) void k_loss_program(GsLossProgram p, int nblocks, double inv_n, const float* __restrict__ partial,
+                                                      float* __restrict__ ssim_mean, float* __restrict__ l1_mean, float* __restrict__ out,
+                                                      float* __restrict__ host_out, float ticket) {
+  loss_program_body(p, nblocks, inv_n, partial, ssim_mean, l1_mean, out, host_out, ticket);
+}
+
+// elements [i0, i0 + 4) of d_a = sl * sgn(a - b) + ss * dssim
+__device__ __forceinline__ void loss_pair_bwd_four(long long n, long long i0, const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ dssim, float sl, float ss, bool use_l1, bool use_ss,
+                                                   float* __restrict__ d_a) {
 #pragma clang fp contract(off)
-  const float sl = ((g_l1 ? *g_l1 : 1.0f) * c_l1) / n_as_float;
-  const float ss = (g_ssim ? *g_ssim : 1.0f) * c_ssim;
-  const bool use_l1 = c_l1 != 0.0f, use_ss = c_ssim != 0.0f && dssim != nullptr;   // (a term that was never asked for adds no 0 * inf)
   auto one = [&](float x, float y, float ds) {
     const float d = x - y;
     const float tl = use_l1 ? (d > 0.f ? sl : (d < 0.f ? -sl : 0.f)) : 0.f;
     return use_ss ? tl + ss * ds : tl;
   };
-  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)d_a | (uintptr_t)(use_ss ? dssim : a);
   if (((al & 15) == 0) && i0 + 4 <= n) {
     const float4 x = reinterpret_cast<const float4*>(a)[i0 >> 2], y = reinterpret_cast<const float4*>(b)[i0 >> 2];
@@ -595,6 +597,37 @@ __global__ __launch_bounds__(256) void k_loss_pair_bwd(long long n, const float*
   } else {
     for (long long i = i0; i < min(n, i0 + 4); ++i) d_a[i] = one(a[i], b[i], use_ss ? dssim[i] : 0.f);
   }
+}
+
+__global__ __launch_bounds__(256) void k_loss_pair_bwd(long long n, const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ dssim, const float* __restrict__ g_l1, float c_l1,
+                                                       const float* __restrict__ g_ssim, float c_ssim, float n_as_float,
+                                                       float* __restrict__ d_a) {
+#pragma clang fp contract(off)
+  const float sl = ((g_l1 ? *g_l1 : 1.0f) * c_l1) / n_as_float;
+  const float ss = (g_ssim ? *g_ssim : 1.0f) * c_ssim;
+  const bool use_l1 = c_l1 != 0.0f, use_ss = c_ssim != 0.0f && dssim != nullptr;   // (a term that was never asked for adds no 0 * inf)
+  loss_pair_bwd_four(n, ((long long)blockIdx.x * 256 + threadIdx.x) * 4, a, b, dssim, sl, ss, use_l1, use_ss, d_a);
+}
+
+// loss.backward() right behind the materialisation, i.e. with dL/d(value) = 1 known before anything is launched: ONE launch for
+// the value (workgroup 0: the means finished, the program evaluated — loss_program_body) and for the gradient of the recorded
+// expression over the image (the other workgroups: k_loss_pair_bwd's arithmetic with g = 1, which does not depend on the means)
+__global__ __launch_bounds__(1024) void k_loss_program_grad(GsLossProgram p, int nblocks, double inv_n, const float* __restrict__ partial,
+                                                           float* __restrict__ ssim_mean, float* __restrict__ l1_mean, float* __restrict__ out,
+                                                           float* __restrict__ host_out, float ticket, long long n,
+                                                           const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ dssim, float c_l1, float c_ssim, float n_as_float,
+                                                           float* __restrict__ d_a) {
+#pragma clang fp contract(off)
+  if (blockIdx.x == 0) {
+    loss_program_body(p, nblocks, inv_n, partial, ssim_mean, l1_mean, out, host_out, ticket);
+    return;
+  }
+  const float sl = (1.0f * c_l1) / n_as_float;
+  const float ss = 1.0f * c_ssim;
+  const bool use_l1 = c_l1 != 0.0f, use_ss = c_ssim != 0.0f && dssim != nullptr;
+  loss_pair_bwd_four(n, ((long long)(blockIdx.x - 1) * 1024 + threadIdx.x) * 4, a, b, dssim, sl, ss, use_l1, use_ss, d_a);
 }
 
 }  // namespace
@@ -725,13 +758,8 @@ int mi355gs_l1_ssim_pair_backward(void* stream_, int64_t n, const float* img1, c
   return MI355GS_OK;
 }
 
-int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
-                              const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int debug = 0;
-  if (n_ops <= 0 || n_ops > MI355GS_LOSS_PROGRAM_MAX || !ops || !consts || !scratch || !l1_mean || !ssim_mean || !out) return MI355GS_EINVAL;
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ((uintptr_t)host_out & 7) != 0) return MI355GS_EINVAL;
-  GsLossProgram p;
+static int build_loss_program(int n_ops, const int32_t* ops, const float* consts, GsLossProgram& p) {
+  if (n_ops <= 0 || n_ops > MI355GS_LOSS_PROGRAM_MAX || !ops || !consts) return MI355GS_EINVAL;
   p.n = n_ops;
   int depth = 0;   // a malformed program (stack underflow, two values left) is refused here, not executed
   for (int i = 0; i < MI355GS_LOSS_PROGRAM_MAX; ++i) {
@@ -744,10 +772,38 @@ int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, cons
     else return MI355GS_EINVAL;
     p.op[i] = (signed char)op; p.k[i] = consts[i];
   }
-  if (depth != 1) return MI355GS_EINVAL;
+  return depth == 1 ? MI355GS_OK : MI355GS_EINVAL;
+}
+
+int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
+                              const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (!scratch || !l1_mean || !ssim_mean || !out) return MI355GS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ((uintptr_t)host_out & 7) != 0) return MI355GS_EINVAL;
+  GsLossProgram p;
+  if (build_loss_program(n_ops, ops, consts, p) != MI355GS_OK) return MI355GS_EINVAL;
   hipLaunchKernelGGL(k_loss_program, dim3(1), dim3(1024), 0, stream, p, fused_nblocks(B, C, H, W), 1.0 / ((double)B * C * H * W),
                      (const float*)scratch, ssim_mean, l1_mean, out, host_out, ticket);
   GS_CHECK_LAUNCH("loss_program");
+  return MI355GS_OK;
+}
+
+int mi355gs_loss_program_eval_grad(void* stream_, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
+                                   const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket,
+                                   const float* img1, const float* img2, const float* dssim_dimg1, float c_l1, float c_ssim, float* d_img1) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int debug = 0;
+  if (!scratch || !l1_mean || !ssim_mean || !out || !img1 || !img2 || !d_img1) return MI355GS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ((uintptr_t)host_out & 7) != 0) return MI355GS_EINVAL;
+  if (c_ssim != 0.0f && !dssim_dimg1) return MI355GS_EINVAL;
+  GsLossProgram p;
+  if (build_loss_program(n_ops, ops, consts, p) != MI355GS_OK) return MI355GS_EINVAL;
+  const long long n = (long long)B * C * H * W;
+  hipLaunchKernelGGL(k_loss_program_grad, dim3(1u + (unsigned)((n + 4095) / 4096)), dim3(1024), 0, stream, p, fused_nblocks(B, C, H, W),
+                     1.0 / (double)n, (const float*)scratch, ssim_mean, l1_mean, out, host_out, ticket, n, img1, img2, dssim_dimg1, c_l1, c_ssim,
+                     (float)n, d_img1);
+  GS_CHECK_LAUNCH("loss_program_grad");
   return MI355GS_OK;
 }
 

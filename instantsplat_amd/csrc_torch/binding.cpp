@@ -50,6 +50,7 @@ struct Abi {
   decltype(&mi355gs_l1_ssim_pair_forward) pair_forward = nullptr;
   decltype(&mi355gs_l1_ssim_pair_backward) pair_backward = nullptr;
   decltype(&mi355gs_loss_program_eval) program_eval = nullptr;
+  decltype(&mi355gs_loss_program_eval_grad) program_eval_grad = nullptr;
   decltype(&mi355gs_ssim_forward) ssim_forward = nullptr;
   decltype(&mi355gs_ssim_backward) ssim_backward = nullptr;
   decltype(&mi355gs_adam_multi_step) adam_multi_step = nullptr;
@@ -86,6 +87,7 @@ void bind_abi(const std::map<std::string, uintptr_t>& sym, bool allow_cpu_tensor
   GS_BIND(pair_forward, mi355gs_l1_ssim_pair_forward);
   GS_BIND(pair_backward, mi355gs_l1_ssim_pair_backward);
   GS_BIND(program_eval, mi355gs_loss_program_eval);
+  GS_BIND(program_eval_grad, mi355gs_loss_program_eval_grad);
   GS_BIND(ssim_forward, mi355gs_ssim_forward);
   GS_BIND(ssim_backward, mi355gs_ssim_backward);
   GS_BIND(adam_multi_step, mi355gs_adam_multi_step);
@@ -703,8 +705,13 @@ std::vector<Tensor> loss_pair_forward(Tensor img1, Tensor img2) {
 struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
   // image: the tensor the caller differentiates (what was handed to l1_loss); a / b / dmap / means / scratch: loss_pair_forward's results
   // host_slot (may be undefined): float32[2] of pinned host memory the program kernel also stores (value, ticket) into
+  // unit_grad (may be undefined): the root gradient — a 1 — the caller is about to run the backward with (loss_affine_backward):
+  //   the forward's launch then also writes the expression's gradient over the image, and the backward, finding exactly that
+  //   tensor as its incoming gradient, hands it on without a launch
   static Tensor forward(AutogradContext* ctx, Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch,
-                        std::vector<int64_t> ops, std::vector<double> consts, double c_l1, double c_ssim, Tensor host_slot, double ticket) {
+                        std::vector<int64_t> ops, std::vector<double> consts, double c_l1, double c_ssim, Tensor host_slot, double ticket,
+                        c10::optional<Tensor> unit_grad_) {
+    const Tensor unit_grad = unit_grad_.has_value() ? *unit_grad_ : Tensor();   // (an undefined Tensor cannot be an argument of a custom function)
     TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
     TORCH_CHECK(ops.size() == consts.size() && !ops.empty() && ops.size() <= MI355GS_LOSS_PROGRAM_MAX, "loss_affine: 1..16 operations");
     TORCH_CHECK(image.numel() == a.numel() && means.numel() == 2, "loss_affine: image and its contiguous copy differ in size");
@@ -719,12 +726,22 @@ struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
       TORCH_CHECK(host_slot.scalar_type() == at::kFloat && !host_slot.is_cuda() && host_slot.is_contiguous(), "loss_affine: the host slot is float32[2] host memory");
       host_out = host_slot.data_ptr<float>();
     }
-    check(g_abi.program_eval(dev.stream, (int)ops.size(), op32, k32, B, C, H, W, scratch.data_ptr(), fp(means) + 1, fp(means), fp(out), host_out,
-                             (float)ticket),
-          "loss_program_eval");
-    ctx->save_for_backward({a, b, dmap});
+    Tensor d;
+    const bool with_grad = unit_grad.defined() && unit_grad.numel() == 1;
+    if (with_grad) {
+      d = at::empty_like(a);
+      check(g_abi.program_eval_grad(dev.stream, (int)ops.size(), op32, k32, B, C, H, W, scratch.data_ptr(), fp(means) + 1, fp(means), fp(out), host_out,
+                                    (float)ticket, fp(a), fp(b), fp(dmap), (float)c_l1, (float)c_ssim, fp(d)),
+            "loss_program_eval_grad");
+    } else {
+      check(g_abi.program_eval(dev.stream, (int)ops.size(), op32, k32, B, C, H, W, scratch.data_ptr(), fp(means) + 1, fp(means), fp(out), host_out,
+                               (float)ticket),
+            "loss_program_eval");
+    }
+    ctx->save_for_backward({a, b, dmap, with_grad ? d : Tensor()});
     ctx->saved_data["c"] = std::vector<double>{c_l1, c_ssim};
     ctx->saved_data["shape"] = image.sizes().vec();
+    ctx->saved_data["unit_grad_ptr"] = with_grad ? (int64_t)(uintptr_t)unit_grad.data_ptr() : (int64_t)0;
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grad_out) {
@@ -732,18 +749,23 @@ struct LossAffineFn : public torch::autograd::Function<LossAffineFn> {
     const auto saved = ctx->get_saved_variables();
     const Tensor &a = saved[0], &b = saved[1], &dmap = saved[2];
     const auto c = ctx->saved_data["c"].toDoubleVector();
+    Tensor none;
+    const int64_t unit_ptr = ctx->saved_data["unit_grad_ptr"].toInt();
+    if (unit_ptr != 0 && saved.size() > 3 && saved[3].defined() && (int64_t)(uintptr_t)grad_out[0].data_ptr() == unit_ptr) {
+      // the incoming gradient IS the 1 the forward was told about: its launch has written this gradient already
+      return {saved[3].view(ctx->saved_data["shape"].toIntVector()), none, none, none, none, none, none, none, none, none, none, none, none};
+    }
     const Tensor g = f32c(grad_out[0].reshape({1}), "grad", a);
     const DeviceScope dev(a);
     Tensor d = at::empty_like(a);
     check(g_abi.pair_backward(dev.stream, a.numel(), fp(a), fp(b), fp(dmap), fp(g), (float)c[0], fp(g), (float)c[1], fp(d)), "l1_ssim_pair_backward");
-    Tensor none;
-    return {d.view(ctx->saved_data["shape"].toIntVector()), none, none, none, none, none, none, none, none, none, none, none};
+    return {d.view(ctx->saved_data["shape"].toIntVector()), none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
 Tensor loss_affine(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch, std::vector<int64_t> ops,
                    std::vector<double> consts, double c_l1, double c_ssim, Tensor host_slot, double ticket) {
-  return LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim, host_slot, ticket);
+  return LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim, host_slot, ticket, c10::optional<Tensor>());
 }
 
 // train.py:188 `loss.item()` for a value the program kernel has also stored to a pinned host slot: spin (GIL released) until the
@@ -773,22 +795,23 @@ py::object wait_for_loss(Tensor host_slot, double ticket, int64_t timeout_us) {
 // ones_like(loss) is a fill launch per iteration; the node only reads the value).  Returns the materialised tensor.
 Tensor loss_affine_backward(Tensor image, Tensor a, Tensor b, Tensor dmap, Tensor means, Tensor scratch, std::vector<int64_t> ops,
                             std::vector<double> consts, double c_l1, double c_ssim, Tensor host_slot, double ticket) {
-  Tensor out = LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim, host_slot, ticket);
-  if (!out.requires_grad()) return out;
   static std::mutex mu;
   static std::map<std::string, std::pair<Tensor, uint32_t>> ones;   // per device: the 1 and its version counter as created
   Tensor one;
   {
     std::lock_guard<std::mutex> lock(mu);
     std::ostringstream key;
-    key << out.device();
+    key << a.device();
     auto& slot = ones[key.str()];
     if (!slot.first.defined() || slot.first._version() != slot.second) {   // (written to since: a fresh one)
-      slot.first = at::ones({}, out.options().requires_grad(false));
+      slot.first = at::ones({}, a.options().requires_grad(false));
       slot.second = slot.first._version();   // (at::ones fills in place: the counter does not start at 0)
     }
     one = slot.first;
   }
+  const bool will_run = at::GradMode::is_enabled() && image.requires_grad();
+  Tensor out = LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim, host_slot, ticket, will_run ? c10::optional<Tensor>(one) : c10::optional<Tensor>());
+  if (!out.requires_grad()) return out;
   py::gil_scoped_release nogil;   // the engine's worker threads take the GIL themselves for Python-defined nodes
   torch::autograd::backward({out}, {one}, /*retain_graph=*/false, /*create_graph=*/false);
   return out;

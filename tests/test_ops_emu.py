@@ -277,6 +277,9 @@ def test_new_entry_points_reject_bad_arguments():
     assert L.mi355gs_loss_program_eval(None, 17, I(*([0] * 17)), Fl(*([0.0] * 17)), 1, 3, 8, 8, p, p, p, p, None, 0.0) == EINVAL
     assert L.mi355gs_loss_program_eval(None, 1, I(0), Fl(0.0), 1, 3, 8, 8, None, p, p, p, None, 0.0) == EINVAL
     assert L.mi355gs_loss_program_eval(None, 1, I(0), Fl(0.0), 1, 3, 8, 8, p, p, p, p, ctypes.c_void_p(p.value + 4), 0.0) == EINVAL   # a host slot that is not 8-byte aligned
+    eg = lambda ops, d=p, ds=p, cs=1.0: L.mi355gs_loss_program_eval_grad(None, len(ops), I(*ops), Fl(*([0.5] * len(ops))), 1, 3, 8, 8, p, p, p, p, None, 0.0,
+                                                                           p, p, ds, 1.0, cs, d)
+    assert eg([0, 1]) == EINVAL and eg([0], d=None) == EINVAL and eg([0], ds=None) == EINVAL   # bad program, no output, an SSIM term without its map
     for knob in (L.mi355gs_tune_scale_grad, L.mi355gs_tune_deterministic):   # query-only calls change nothing
         assert knob(-1) == 0 and knob(1) == 0 and knob(-1) == 1 and knob(0) == 1 and knob(-1) == 0
     assert L.mi355gs_raster_grad_scratch_bytes(1000) == L.mi355gs_raster_grad_gate_offset(1000) + 256
