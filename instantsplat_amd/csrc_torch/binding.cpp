@@ -213,6 +213,7 @@ template <class... T> bool any_requires_grad(const T&... t) {
 // ... asked where the operator is CALLED: inside a custom function's forward() grad mode is off, so the question would always be
 // answered "no" there (round 4 shipped it that way for a while: the backward's memset stayed, profiles/r04_dropin_aten_ops.txt)
 thread_local bool t_backward_follows = false;
+bool g_backward_inline = false;   // A/B switch (backward_inline): loss_affine_backward runs the engine on the calling thread
 bool g_render_only_when_no_grad = true;   // A/B switch (render_only): false = every forward runs the training instantiation of stage 2
 bool g_forward_owns_scratch = true;   // A/B switch (forward_owns_scratch): false = the backward allocates and memsets, as before ABI v7
 struct BackwardFollows {
@@ -809,10 +810,23 @@ Tensor loss_affine_backward(Tensor image, Tensor a, Tensor b, Tensor dmap, Tenso
     }
     one = slot.first;
   }
+  // The engine normally hands the device's nodes to a worker thread and parks the caller: a wake-up and a hand-back per
+  // backward() that sit on the stretch of the iteration where the host feeds the device (loss launch -> render backward launch).
+  // With multithreading switched off for THIS call (thread-local autograd state — what torch.autograd.set_multithreading_enabled(False)
+  // sets) the nodes run on the calling thread instead.
+  struct InlineEngine {
+    bool prev;
+    bool on;
+    explicit InlineEngine(bool enable) : prev(c10::AutogradState::get_tls_state().get_multithreading_enabled()), on(enable) {
+      if (on) c10::AutogradState::get_tls_state().set_multithreading_enabled(false);
+    }
+    ~InlineEngine() { if (on) c10::AutogradState::get_tls_state().set_multithreading_enabled(prev); }
+  };
   const bool will_run = at::GradMode::is_enabled() && image.requires_grad();
   Tensor out = LossAffineFn::apply(image, a, b, dmap, means, scratch, ops, consts, c_l1, c_ssim, host_slot, ticket, will_run ? c10::optional<Tensor>(one) : c10::optional<Tensor>());
   if (!out.requires_grad()) return out;
   py::gil_scoped_release nogil;   // the engine's worker threads take the GIL themselves for Python-defined nodes
+  InlineEngine inline_engine(g_backward_inline);
   torch::autograd::backward({out}, {one}, /*retain_graph=*/false, /*create_graph=*/false);
   return out;
 }
@@ -1005,6 +1019,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize);
   m.def("l1_ssim_loss", &l1_ssim_loss);
   m.def("loss_pair_forward", &loss_pair_forward, "-> [means (l1, ssim: filled by the first loss_affine), partial sums, d(ssim_mean)/dimg1, img1, img2 (contiguous)]: one launch, no autograd node");
+  m.def("backward_inline", [](bool on) { const bool was = g_backward_inline; g_backward_inline = on; return was; },
+        "A/B switch: loss_affine_backward runs the autograd engine on the calling thread (thread-local multithreading off for the call)");
   m.def("wait_for_loss", &wait_for_loss, "the value the program kernel stored to a pinned host slot under this ticket, or None (timeout / slot taken over)");
   m.def("loss_affine_backward", &loss_affine_backward, "loss_affine + the engine run of loss.backward() in one call (root gradient: a cached 1)");
   m.def("loss_affine", &loss_affine, "the recorded scalar expression over (l1_mean, ssim_mean) as ONE node on `image`");

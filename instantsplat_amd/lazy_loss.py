@@ -135,6 +135,10 @@ def _is_lazy(x):
 # frame's launches while the device still works on this iteration's backward (stream order keeps everything correct), so the
 # device never idles through the reference loop's host work.  EARLY_ITEM = False restores the ordinary read (copy + stream wait).
 EARLY_ITEM = os.environ.get("MI355GS_EARLY_ITEM", "1") != "0"
+# loss.backward() of a recorded expression runs the autograd engine on the CALLING thread (no hand-off to the device's worker thread
+# and back; csrc_torch/binding.cpp::loss_affine_backward).  MI355GS_BACKWARD_INLINE=0 leaves the engine's threading alone.
+BACKWARD_INLINE = os.environ.get("MI355GS_BACKWARD_INLINE", "0") != "0"
+_INLINE_SET = [None]
 _NO_SLOT = torch.empty(0)   # "no host slot" for the compiled nodes (an empty tensor: pybind takes no None for a Tensor)
 _SLOTS = {}          # device -> [pinned float32[N, 2], next index]
 _N_SLOTS = 64
@@ -339,6 +343,9 @@ class LazyScalar(torch.Tensor):
                 ext = _lib.compiled()
                 rec = self._rec
                 if ext is not None and rec.image.requires_grad:
+                    if BACKWARD_INLINE is not _INLINE_SET[0]:
+                        ext.backward_inline(bool(BACKWARD_INLINE))
+                        _INLINE_SET[0] = BACKWARD_INLINE
                     c_l1, c_ssim = partials(self._prog)
                     prog = self._prog
                     slot, ticket = _host_slot(rec.dev) if EARLY_ITEM else (None, 0.0)
