@@ -659,6 +659,18 @@ def check_dropin_node_housekeeping(dev, Wm=10, W=32, H=24):
             pkg = render(st.cameras[1], g, st.pipe, st.background, camera_pose=g.get_RT(1))
             fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[1].unsqueeze(0), 0.2)[0].backward()   # accumulates: zeros += zeros
             assert float(g._features_rest.grad.abs().max()) == 0.0
+            # ---- two models of the same size in one process (teacher + student, a copy): each f_rest gets its OWN zero buffer — an
+            # in-place edit of one model's .grad must not show up in the other's
+            st2 = generic_start(setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True)))
+            g2 = st2.gaussians
+            for model in (g, g2):
+                for n in names + ("_features_rest",):
+                    getattr(model, n).grad = None
+                pkg = render(cam, model, st.pipe, st.background, camera_pose=model.get_RT(cam.uid))
+                fused_l1_ssim_loss(pkg["render"].unsqueeze(0), st.gt_images[cam.uid].unsqueeze(0), 0.2)[0].backward()
+            assert g._features_rest.grad.data_ptr() != g2._features_rest.grad.data_ptr()
+            g._features_rest.grad.add_(2.0)
+            assert float(g2._features_rest.grad.abs().max()) == 0.0 and float(g._features_rest.grad.min()) == 2.0
             ext = _lib.compiled()
             was = ext.shared_zero_grad(False)
             try:
@@ -1387,6 +1399,15 @@ def check_loss_utils_against_the_references_own(dev):
     bound("loss_utils/ssim_11", abs(float(loss_utils.ssim(x, y)) - float(G["ssim_11"])), 2e-6 if cuda else 1e-6)
     bound("loss_utils/ssim_3d", abs(float(loss_utils.ssim(x[0], y[0])) - float(G["ssim_3d"])), 2e-6 if cuda else 1e-6)
     bound("loss_utils/ssim_7", abs(float(loss_utils.ssim(x, y, window_size=7)) - float(G["ssim_7"])), 2e-6)
+    # a second image that wants a gradient: the fused kernel differentiates img1 only, so the reference's conv2d expression takes over
+    # (same value, and img2 gets ITS gradient); under no_grad the fused kernel is taken again
+    yg = y.clone().requires_grad_(True)
+    v = loss_utils.ssim(x, yg)
+    v.backward()
+    bound("loss_utils/ssim_11_grad_img2_path", abs(float(v.detach()) - float(G["ssim_11"])), 2e-6)
+    assert yg.grad is not None and float(yg.grad.abs().sum()) > 0
+    with torch.no_grad():
+        bound("loss_utils/ssim_11_no_grad", abs(float(loss_utils.ssim(x, yg)) - float(G["ssim_11"])), 2e-6 if cuda else 1e-6)
     bound("loss_utils/ssim_per_image", float((loss_utils.ssim(x, y, size_average=False).cpu() - torch.from_numpy(G["ssim_11_per_image"])).abs().max()), 2e-6)
     bound("loss_utils/l1_mask", abs(float(loss_utils.l1_loss_mask(x, y, mask)) - float(G["l1_mask"])), 1e-6)
     # every name the reference's module defines is here (render.py:30 imports ssim_loss_mask next to the others), with its results
