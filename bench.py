@@ -128,6 +128,7 @@ def main():
         return supervise(args)
 
     import faulthandler
+    faulthandler.enable(file=sys.stderr, all_threads=True)   # a rank that dies on a signal (SIGABRT / SIGSEGV ...) says where, in the launcher's log
     if os.environ.get("MI355GS_BENCH_LIMIT"):   # a supervised child: should it stall, say WHERE before the parent kills it
         faulthandler.dump_traceback_later(max(float(os.environ["MI355GS_BENCH_LIMIT"]) - 15.0, 0.2), exit=False, file=sys.stderr)
     elif "WORLD_SIZE" in os.environ:            # a rank under a launcher: nobody supervises it, but a run still going after 15 minutes
@@ -833,6 +834,7 @@ def main():
         }
         print(json.dumps(out), file=line_out, flush=True)
     if collectives:
+        dist.barrier()   # every rank has handed in its report and rank 0 has printed: tear the group down together, none while a peer still talks to it
         dist.destroy_process_group()
 
 

@@ -32,6 +32,15 @@ extern "C" int mi355gs_probe_set(void* buf, unsigned int capacity_rows) {
 #define GS_PROBE_STORE(...) do {} while (0)
 #endif
 
+// A/B build switch (tools/build_variant.sh precise -DGS_PRECISE_MATH=1): the library's exp2f and an IEEE division in place of
+// v_exp_f32 / v_rcp_f32 in the alpha and transmittance arithmetic of both kernels — what the hardware approximations cost in
+// accuracy against the float64 oracle is measured with it (profiles/EXPERIMENTS.md, round 5); the shipped build has it off.
+#ifndef GS_PRECISE_MATH
+#define GS_PRECISE_MATH 0
+#endif
+__device__ __forceinline__ float gs_exp2(float x) { return GS_PRECISE_MATH ? exp2f(x) : __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float gs_rcp(float x) { return GS_PRECISE_MATH ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
+
 namespace {
 
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256 * FWD_TILES) void k_composite_fwd(int T, int gx
         const gs_v2f d = gs_v2f{a0.x, a0.y} - q.f;
         const gs_v2f sq = (d * gs_v2f{a1.x, a1.y}) * d;                     // packed: (A dx^2, C dy^2)
         const float power2 = fmaf(a1.z * d[0], d[1], sq[0] + sq[1]);        // log2 of the falloff
-        const float alpha = fminf(0.99f, a1.w * __builtin_amdgcn_exp2f(power2));
+        const float alpha = fminf(0.99f, a1.w * gs_exp2(power2));
         // a skipped Gaussian is a transparent one (and so is the padding of a short group)
         valid[u] = live[u] && power2 <= 0.0f && alpha >= ALPHA_MIN;
         al[u] = valid[u] ? alpha : 0.0f;
@@ -528,7 +537,7 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
         // opacity * G, unclamped: the reference clamps alpha to 0.99 but lets dL/dalpha through to G unchanged, so
         // G * dL/dG = (opacity G) dL/dalpha needs the unclamped product.  power2 > 0 can make it inf; such lanes are
         // invalid and every use below selects, never multiplies, them away.
-        const float au = a1.w * __builtin_amdgcn_exp2f(power2);
+        const float au = a1.w * gs_exp2(power2);
         // (contributor = cb + i2 + 1 <= last: the instance lies at or in front of the pixel's last contributor)
         const bool valid = (int)cb + i2 < lastq[qd] && power2 <= 0.0f && au >= ALPHA_MIN;
         if constexpr (COUNT) { c_quads += 1; c_lanes += __popcll(__ballot(valid)); }
@@ -539,7 +548,7 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
           // evolve exactly as if it had been skipped, so the replay state needs no per-field selects.
           const float av = valid ? au : 0.f;
           const float al = __builtin_amdgcn_fmed3f(av, 0.0f, 0.99f);     // min(0.99, av) for av >= 0: one v_med3_f32
-          const float inv_one_m = __builtin_amdgcn_rcpf(1.f - al);        // v_rcp_f32 (1 ulp) instead of two IEEE divisions
+          const float inv_one_m = gs_rcp(1.f - al);                         // v_rcp_f32 (1 ulp) instead of two IEEE divisions
           // dC/dalpha_k = c_k T_k - (sum_{j behind k} c_j alpha_j T_j + T_final bg) / (1 - alpha_k).  Contracted with
           // dL/dC first, the "colour behind" term is ONE running scalar (behind) instead of the reference's three-channel
           // accum_rec / last_color / last_alpha recursion (same quantity: accum_rec_k = sum_{j>k} c_j alpha_j T_j / T_{k+1}).

@@ -19,6 +19,12 @@ def pytest_configure(config):
 def emu_lib_path():
     """g++ build of the UNMODIFIED kernel sources against the SIMT emulator (tests/emu), and the compiled PyTorch binding
     (host code only; a no-op when __graft_entry__.build() has already made it) that the operators go through by default."""
+    if os.environ.get("MI355GS_EMU_LIB"):
+        # a sanitizer run (tools/asan_tests_emu.sh): instrumented builds of the emulated kernels and of the compiled binding
+        from instantsplat_amd import _lib
+        if os.environ.get("MI355GS_TORCH_EXT"):
+            _lib.EXT_PATH = os.environ["MI355GS_TORCH_EXT"]
+        return os.environ["MI355GS_EMU_LIB"]
     subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
     if torch.version.hip is None:
         # a CPU-only PyTorch wheel has no ATen/hip headers or libc10_hip to build the compiled binding against: the emulated

@@ -20,31 +20,33 @@ def relerr(a, b):
 
 
 def run_blob_case(device, P, W, H, deg, scale_mean=0.05, seed=1, opacity="random", bg=(0.2, 0.5, 0.9), mod=1.0,
-                  precomp_color=False, precomp_cov=False, backward=True, scale_grad_exact=False):
-    """Returns dict(ref=..., dut=...) each with color, radii, grads (dict).  scale_grad_exact: both sides return the true
+                  precomp_color=False, precomp_cov=False, backward=True, scale_grad_exact=False, with_f64=False):
+    """Returns dict(ref=..., dut=...) each with color, radii, grads (dict); with_f64 adds "f64": the same case through the
+    float64 build of the oracle (the yardstick for assert_no_worse_than_fp32_oracle).  scale_grad_exact: both sides return the true
     derivative with respect to `scales` instead of the published operator's dL/d(mod * scale) (include/mi355gs.h,
     mi355gs_tune_scale_grad; oracle/gs_ref.c header) — the two only differ at mod != 1."""
     from instantsplat_amd import _lib
     old = (gs_ref.lib().gsref_set_scale_grad_exact(int(scale_grad_exact)), _lib.lib().mi355gs_tune_scale_grad(int(scale_grad_exact)))
     try:
-        return _run_blob_case(device, P, W, H, deg, scale_mean, seed, opacity, bg, mod, precomp_color, precomp_cov, backward)
+        return _run_blob_case(device, P, W, H, deg, scale_mean, seed, opacity, bg, mod, precomp_color, precomp_cov, backward, with_f64)
     finally:
         gs_ref.lib().gsref_set_scale_grad_exact(old[0])
         _lib.lib().mi355gs_tune_scale_grad(old[1])
 
 
-def _run_blob_case(device, P, W, H, deg, scale_mean, seed, opacity, bg, mod, precomp_color, precomp_cov, backward):
+def _run_blob_case(device, P, W, H, deg, scale_mean, seed, opacity, bg, mod, precomp_color, precomp_cov, backward, with_f64=False):
     sc = syn_blob(P, W, H, seed=seed, scale_mean=scale_mean, opacity=opacity)
     bg_t = torch.tensor(bg, dtype=torch.float32)
     torch.manual_seed(seed + 100)
     wgt = torch.randn(3, H, W)
     out = {}
-    for which in ("ref", "dut"):
-        dev = torch.device("cpu") if which == "ref" else torch.device(device)
+    for which in ("ref", "dut") + (("f64",) if with_f64 else ()):
+        dev = torch.device(device) if which == "dut" else torch.device("cpu")
+        dt = torch.float64 if which == "f64" else torch.float32
         leaves = dict(means3D=sc.means3D.clone(), scaling=sc.scaling_logit.clone(), rot=sc.rotation.clone(),
                       op=sc.opacity_logit.clone(), shs=sc.shs.clone())
-        leaves = {k: v.to(dev).requires_grad_(True) for k, v in leaves.items()}
-        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        leaves = {k: v.to(dev, dt).requires_grad_(True) for k, v in leaves.items()}
+        m2d = torch.zeros(P, 3, device=dev, dtype=dt, requires_grad=True)
         kw = {}
         colors = cov = None
         if precomp_color:
@@ -58,15 +60,17 @@ def _run_blob_case(device, P, W, H, deg, scale_mean, seed, opacity, bg, mod, pre
         else:
             kw["scales"] = torch.exp(leaves["scaling"])
             kw["rotations"] = leaves["rot"]
-        if which == "ref":
+        if which != "dut":
             st = settings_for(sc.camera, deg, rt.RasterSettings, bg_t, mod=mod)
+            if which == "f64":
+                st = rt.RasterSettings(*[(x.double() if isinstance(x, torch.Tensor) else x) for x in st])
             color, radii = gs_ref.rasterize(leaves["means3D"], m2d, torch.sigmoid(leaves["op"]), st, **kw)
         else:
             st = settings_for(sc.camera, deg, GaussianRasterizationSettings, bg_t, device=dev, mod=mod)
             color, radii = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2d, opacities=torch.sigmoid(leaves["op"]), **kw)
         grads = {}
         if backward:
-            (color * wgt.to(dev)).sum().backward()
+            (color * wgt.to(dev, dt)).sum().backward()
             grads = {k: v.grad.detach().cpu().clone() for k, v in leaves.items() if v.grad is not None}
             grads["means2D"] = m2d.grad.detach().cpu().clone()
         out[which] = dict(color=color.detach().cpu(), radii=radii.cpu(), grads=grads)
