@@ -21,11 +21,14 @@ Gaussian) pair evaluations per frame NO fp32 implementation meets the small-case
 So the assertions are relative to what the fp32 oracle itself achieves against fp64:
   * image: every value within 5e-3 of fp64; fraction of values off by more than 1e-4 at most FACTOR x the fp32 oracle's (floor 2e-4);
   * per-Gaussian gradient tensors: relative L2 against fp64 at most FACTOR x the fp32 oracle's (floor 1e-3), also with the 64
-    worst Gaussians set aside (floor 1e-4).  FACTOR = 4 for the deterministic cases (blob-200k, and C3 / C4 at iteration 0: the
-    inputs are fixed, the result repeats exactly up to float-atomic order); for the trained states (which pairs flip is luck
-    there: the trained state itself differs from run to run) 8 on whole tensors and 5 on the outlier-free statistics, from
-    the distribution over 30 repeated runs committed as profiles/r04_trained_state_ratio_distribution.txt (see the constants).  Every measured ratio is printed (pytest -s) and recorded (GS_CALIBRATE=1).  A
-    wrong kernel is off by orders of magnitude, not by 4x;
+    worst Gaussians set aside (floor 1e-4).  Round 5: the projection kernels are compiled without FMA contraction and round like
+    the oracle (instantsplat_amd/csrc/Makefile), which took most of the spread out of these ratios — the largest of this
+    file's 80 ratios fell to 1.62 and the image ratios to 1.00-1.12 — so FACTOR = 2.5 (was 4) for the cases with fixed
+    inputs (blob-200k, C3 / C4 at iteration 0, and every case in the deterministic-backward mode, whose trained state repeats
+    bit for bit); for the trained states of the default mode (which pairs flip is luck there: the trained state itself differs
+    from run to run) 3 on whole tensors (was 8) and 4 on the outlier-free statistics (was 5), from 14 repeated runs committed
+    as profiles/r05_trained_state_ratio_distribution.txt (round 4's 30 runs: r04_...); image fractions 2 everywhere.  Every
+    measured ratio is printed (pytest -s) and recorded (GS_CALIBRATE=1).  A wrong kernel is off by orders of magnitude;
   * pose gradients (sums over all Gaussians), loss: plain relative bounds.
 """
 import pytest
@@ -36,14 +39,15 @@ from tests.ops_util import bound
 
 pytestmark = pytest.mark.gpu
 OUTLIERS = 64
-FACTOR_FIXED_INPUTS = 4.0   # device error allowed, in units of the fp32 oracle's own error against fp64 (see the module docstring)
-# Trained states, from the distribution over 30 repeated runs of the C3 case and 6 of the C4 case on the round-4 tree
-# (profiles/r04_trained_state_ratio_distribution.txt, tools/trained_state_ratios.py; worst tensor and view of each run):
-#   whole gradient tensors      median 1.37, 90th percentile 1.9, max 5.75 (ONE run above 2.7: a single pair on a threshold)  -> 8
-#   without the 64 worst rows   median 1.39, 90th percentile 1.9, max 2.64                                                    -> 5
-#   image values off by > 1e-4  median 1.17, 90th percentile 1.8, max 2.39                                                    -> 5
-FACTOR_TRAINED_STATE = 8.0
-FACTOR_TRAINED_STATE_ROBUST = 5.0   # (~2x the largest of 30 runs: a red GPU tier on a rare run teaches nothing)
+FACTOR_FIXED_INPUTS = 2.5   # device error allowed, in units of the fp32 oracle's own error against fp64 (see the module docstring)
+# Trained states, from the distribution over 14 repeated runs of the C3 case and 2 of the C4 case on the round-5 tree
+# (profiles/r05_trained_state_ratio_distribution.txt, tools/trained_state_ratios.py; worst tensor and view of each run):
+#   whole gradient tensors      median 1.12, 90th percentile 1.22, max 1.42   (round 4: 1.37 / 1.9 / 5.75)  -> 3
+#   without the 64 worst rows   median 1.27, 90th percentile 1.44, max 2.18   (round 4: 1.39 / 1.9 / 2.64)  -> 4
+#   image values off by > 1e-4  median 1.01, 90th percentile 1.01, max 1.03   (round 4: 1.17 / 1.8 / 2.39)  -> 2
+FACTOR_TRAINED_STATE = 3.0
+FACTOR_TRAINED_STATE_ROBUST = 4.0   # (~2x the largest of the runs: a red GPU tier on a rare run teaches nothing)
+FACTOR_IMAGE = 2.0
 
 
 def _grad_errors(a, b):
@@ -64,7 +68,7 @@ def _robust(factor):
 
 
 def _check_image(pre, dut, c32, c64, factor):
-    factor = _robust(factor)
+    factor = min(_robust(factor), FACTOR_IMAGE)
     d = (dut.detach().double().cpu() - c64).abs()
     d_ref = (c32.detach().double() - c64).abs()
     bound(pre + "image_max", float(d.max()), 5e-3)

@@ -22,6 +22,7 @@ dev = torch.device('cuda:0' if ON_GPU else 'cpu')
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 bad = noted = 0
+errs, imgs = [], []   # of the cases inside the small-size criteria: worst gradient tensor (relative L2), largest pixel difference
 t0 = time.time()
 
 
@@ -70,6 +71,8 @@ for i in range(n_cases):
         out = run_blob_case(dev, P, W, H, deg, scale_mean=sm, seed=seed, opacity=op, mod=mod, precomp_color=pc, precomp_cov=pv)
         try:
             assert_raster_parity(out)
+            errs.append(max(relerr(out["dut"]["grads"][k], g) for k, g in out["ref"]["grads"].items()))
+            imgs.append(float((out["ref"]["color"] - out["dut"]["color"]).abs().max()))
         except AssertionError as e:
             print(second_stage(cfg, str(e) or "radii differ by more than one"), flush=True)
             noted += 1
@@ -90,3 +93,8 @@ for i in range(n_cases):
         print("FAIL", cfg, type(e).__name__, str(e)[:300], flush=True)
 print("seed", sys.argv[1] if len(sys.argv) > 1 else 0, "cases", n_cases, "failures", bad, "judged against fp64 instead", noted,
       "in %.0f s" % (time.time() - t0), "on", "cuda:0 (libmi355gs.so)" if ON_GPU else "the emulator", flush=True)
+if errs:
+    errs.sort(); imgs.sort()
+    q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]
+    print("inside the criteria: worst gradient tensor against the fp32 oracle, relative L2: median %.1e  90%% %.1e  99%% %.1e  max %.1e (limit 1e-4);"
+          "  largest pixel difference: median %.1e  90%% %.1e  max %.1e" % (q(errs, .5), q(errs, .9), q(errs, .99), errs[-1], q(imgs, .5), q(imgs, .9), imgs[-1]), flush=True)
