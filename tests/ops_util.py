@@ -526,7 +526,7 @@ def check_gated_off_tensor_keeps_moving(dev, Wm=10, W=24):
             bound("gated_off/f_rest_track", float((a_ - b_).norm()) / float(b_.norm() + 1e-12) if float(b_.norm()) > 0 else float(a_.norm()),
                   2e-4 if cuda else 1e-5)
         for i, what in ((1, "exp_avg"), (2, "exp_avg_sq")):
-            bound("gated_off/f_rest_" + what, rel_l2(res[True][i], res[False][i]), 2e-4 if cuda else 1e-5)
+            bound("gated_off/f_rest_" + what, rel_l2(res[True][i], res[False][i]), 2e-5 if cuda else 1e-5)
         # the moments freeze while the tensor is gated off (both paths)
     finally:
         BinningPolicy.reset("exact")
@@ -648,7 +648,7 @@ def check_dropin_node_housekeeping(dev, Wm=10, W=32, H=24):
             if memsets:
                 assert memsets() == n_memsets + 1, "a second backward of the same frame must clear the used accumulators itself"
             for n in names:
-                bound("dropin_housekeeping/second_backward" + n, rel_l2(getattr(g, n).grad, first[n]), 2e-4 if cuda else 0.0)
+                bound("dropin_housekeeping/second_backward" + n, rel_l2(getattr(g, n).grad, first[n]), 2e-5 if cuda else 0.0)
             # ---- the shared zero gradient
             g._features_rest.grad.add_(1.0)                          # an in-place edit the version counter sees
             for n in names + ("_features_rest",):
@@ -1203,8 +1203,8 @@ def check_compiled_gate_flags_are_sound(dev, Wm=10, W=32, H=24):
                 pb, vb, used = scenario(kind)
             assert used == n_flags, (kind, used)
             for n in names:
-                bound("compiled_gates/%s/param%s" % (kind, n), rel_l2(pb[n], pa[n]), 2e-4 if cuda else 0.0)
-                bound("compiled_gates/%s/exp_avg_sq%s" % (kind, n), rel_l2(vb[n], va[n]), 2e-3 if cuda else 0.0)
+                bound("compiled_gates/%s/param%s" % (kind, n), rel_l2(pb[n], pa[n]), 2e-5 if cuda else 0.0)   # MI355X: <= 8e-8
+                bound("compiled_gates/%s/exp_avg_sq%s" % (kind, n), rel_l2(vb[n], va[n]), 2e-4 if cuda else 0.0)
             if kind.startswith("zeroed"):   # Adam's whole-tensor gate: a zeroed gradient must leave the second moment untouched
                 assert float(vb["_scaling"].abs().max()) == 0.0
     finally:
@@ -1229,7 +1229,7 @@ def check_operator_bindings_agree(dev):
         bound(tag + "image", float((a["color"] - b["color"]).abs().max()), 1e-6 if cuda else 0.0)
         assert set(a["grads"]) == set(b["grads"])
         for k in a["grads"]:
-            bound(tag + "grad_" + k, relerr(b["grads"][k], a["grads"][k]), 1e-5 if cuda else 0.0)
+            bound(tag + "grad_" + k, relerr(b["grads"][k], a["grads"][k]), 2e-6 if cuda else 0.0)
     g = torch.Generator().manual_seed(2)
     x = torch.rand(1, 3, 40, 56, generator=g).to(dev)
     y = torch.rand(1, 3, 40, 56, generator=g).to(dev)
@@ -1333,7 +1333,7 @@ def check_pose_row_node(dev, Wm=10, W=32, H=24):
         assert g.P.grad.shape == g.P.shape and g.P.grad.is_contiguous()
         assert float(g.P.grad[0].abs().max()) == 0.0 and float(g.P.grad[2].abs().max()) == 0.0 and float(g.P.grad[1].abs().max()) > 0.0
         for n in names:
-            bound("pose_row/" + n, rel_l2(got[n], ref[n]), 2e-4 if cuda else 0.0)
+            bound("pose_row/" + n, rel_l2(got[n], ref[n]), 2e-5 if cuda else 0.0)
         # the optimizer's fast path takes all seven gradients from the backward's record (pose table included)
         opt = g.optimizer
         opt.step()
@@ -1347,13 +1347,13 @@ def check_pose_row_node(dev, Wm=10, W=32, H=24):
         pr = g.P[1]
         ref = frame(cam, pr, extra=(pr * pr).sum() * 0.5)
         for n in names:
-            bound("pose_row_sum/" + n, rel_l2(got[n], ref[n]), 2e-4 if cuda else 1e-6)
+            bound("pose_row_sum/" + n, rel_l2(got[n], ref[n]), 2e-5 if cuda else 1e-6)
         # ---- two rows alive at once: the render of camera 0 gets row 0, while row 2 was handed out last
         r0, r2 = g.get_RT(0), g.get_RT(2)
         got = frame(st.cameras[0], r0)
         ref = frame(st.cameras[0], g.P[0])
         for n in names:
-            bound("pose_row_two/" + n, rel_l2(got[n], ref[n]), 2e-4 if cuda else 0.0)
+            bound("pose_row_two/" + n, rel_l2(got[n], ref[n]), 2e-5 if cuda else 0.0)
         assert float(g.P.grad[2].abs().max()) == 0.0
         del r2
 
