@@ -1674,3 +1674,72 @@ def check_deterministic_backward(dev, iters=12, Wm=20, W=64, H=48, min_units=Non
     finally:
         if old_units:
             L.mi355gs_tune_min_units(old_units)
+
+
+def check_lazy_scalar_behaves_like_a_tensor(dev, H=40, W=56):
+    """What an unmodified caller may do with the values of train.py:171-176 — `Ll1`, `ssim_value`, `loss` — when they are recorded
+    expressions (instantsplat_amd/lazy_loss.py) instead of eager tensors: ~50 uses (read-backs and formatting, predicates,
+    every backward form, autograd.grad, further arithmetic with numbers / 0-dim / full tensors, in-place ops, stacking, a chain
+    longer than the recorded program, a second image pair, copies and pickles, gradient accumulation over two losses), each
+    compared with the same lines run with the mechanism off."""
+    import copy, math, pickle
+    from instantsplat_amd import lazy_loss, loss_utils
+    from instantsplat_amd.fused_ssim import fused_ssim
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def grad_of(loss, img):
+        loss.backward()
+        return img.grad.clone()
+
+    def chain(x):
+        for _ in range(6):
+            x = ((x * 2 + 1) * 0.5) - 0.25
+        return x
+
+    uses = {
+        "item": lambda l, a, s, i: l.item(), "float": lambda l, a, s, i: float(l), "format": lambda l, a, s, i: f"{l:.5f}",
+        "isnan": lambda l, a, s, i: bool(torch.isnan(l)), "math.isfinite": lambda l, a, s, i: math.isfinite(l), "compare": lambda l, a, s, i: bool(l > 0.01),
+        "shape": lambda l, a, s, i: (tuple(l.shape), l.dtype, l.device.type, l.dim(), l.numel(), l.requires_grad, l.is_leaf, l.grad_fn is None),
+        "backward": lambda l, a, s, i: grad_of(l, i),
+        "backward_retain_twice": lambda l, a, s, i: (l.backward(retain_graph=True), l.backward(), i.grad.clone())[2],
+        "backward_gradient": lambda l, a, s, i: (l.backward(torch.tensor(2.0, device=i.device)), i.grad.clone())[1],
+        "autograd.grad": lambda l, a, s, i: torch.autograd.grad(l, i)[0],
+        "item_then_backward": lambda l, a, s, i: (l.item(), grad_of(l, i))[1], "backward_then_item": lambda l, a, s, i: (grad_of(l, i), l.item())[1],
+        "Ll1_item_after_backward": lambda l, a, s, i: (grad_of(l, i), a.item())[1], "ssim_item": lambda l, a, s, i: s.item(),
+        "detach_cpu": lambda l, a, s, i: l.detach().cpu(), "clone": lambda l, a, s, i: l.clone(), "mean": lambda l, a, s, i: l.mean(),
+        "pow": lambda l, a, s, i: l ** 2, "abs": lambda l, a, s, i: abs(l), "neg": lambda l, a, s, i: -l, "div": lambda l, a, s, i: l / 2,
+        "rdiv": lambda l, a, s, i: 2 / l, "add_0dim": lambda l, a, s, i: l + torch.tensor(0.5, device=i.device),
+        "mul_0dim": lambda l, a, s, i: l * torch.tensor(3.0, device=i.device), "add_image": lambda l, a, s, i: (l + i).sum(),
+        "stack": lambda l, a, s, i: torch.stack([l, a]), "iadd": lambda l, a, s, i: l.__iadd__(1.0), "sqrt": lambda l, a, s, i: torch.sqrt(l),
+        "psnr_like": lambda l, a, s, i: 20 * torch.log10(1.0 / torch.sqrt(a)), "numpy": lambda l, a, s, i: float(l.detach().cpu().numpy()),
+        "tolist": lambda l, a, s, i: l.tolist(), "bool": lambda l, a, s, i: bool(l), "int": lambda l, a, s, i: int(l * 100),
+        "repr": lambda l, a, s, i: repr(l).startswith("tensor("), "long_chain": lambda l, a, s, i: grad_of(chain(l), i),
+        "second_pair": lambda l, a, s, i: float(l + loss_utils.l1_loss(i * 0.5, gt)), "isinstance": lambda l, a, s, i: isinstance(l, torch.Tensor),
+        "deepcopy": lambda l, a, s, i: float(copy.deepcopy(l.detach())), "pickle": lambda l, a, s, i: float(pickle.loads(pickle.dumps(l.detach().cpu()))),
+        "to_f64": lambda l, a, s, i: l.to(torch.float64).dtype,
+        "two_losses_accumulate": lambda l, a, s, i: (l.backward(), loss_utils.l1_loss(i, gt).backward(), i.grad.clone())[2],
+    }
+
+    def same(a, b):
+        if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+            return a.shape == b.shape and torch.allclose(a.detach().double().cpu(), b.detach().double().cpu(), rtol=3e-6, atol=1e-7)
+        if isinstance(a, float) and isinstance(b, float):
+            return abs(a - b) <= 3e-6 * max(1.0, abs(b))
+        return a == b
+
+    was = lazy_loss.ENABLED
+    try:
+        for name, use in uses.items():
+            res = []
+            for enabled in (True, False):
+                lazy_loss.ENABLED = enabled
+                img = (gt + 0.1 * torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)).clamp(0, 1).requires_grad_(True)
+                Ll1 = loss_utils.l1_loss(img, gt)
+                ss = fused_ssim(img.unsqueeze(0), gt.unsqueeze(0))
+                loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - ss)
+                if enabled:
+                    assert type(loss).__name__ == "LazyScalar", type(loss)
+                res.append(use(loss, Ll1, ss, img))
+            assert same(res[0], res[1]), (name, res[0], res[1])
+    finally:
+        lazy_loss.ENABLED = was

@@ -300,6 +300,10 @@ def test_lazy_loss_expression(emu):
     ops_util.check_lazy_loss_expression(emu)
 
 
+def test_lazy_scalar_behaves_like_a_tensor(emu):
+    ops_util.check_lazy_scalar_behaves_like_a_tensor(emu)
+
+
 def test_deterministic_backward(emu):
     ops_util.check_deterministic_backward(emu, iters=3)
 

@@ -177,6 +177,10 @@ def test_lazy_loss_expression(gpu):
     ops_util.check_lazy_loss_expression(gpu)
 
 
+def test_lazy_scalar_behaves_like_a_tensor(gpu):
+    ops_util.check_lazy_scalar_behaves_like_a_tensor(gpu)
+
+
 def test_lazy_loss_expression_at_bench_size(gpu):
     ops_util.check_lazy_loss_expression(gpu, H=512, W=512)
 
