@@ -776,12 +776,23 @@ py::object wait_for_loss(Tensor host_slot, double ticket, int64_t timeout_us) {
   TORCH_CHECK(host_slot.scalar_type() == at::kFloat && !host_slot.is_cuda() && host_slot.numel() >= 2, "wait_for_loss: float32[2] host memory");
   const volatile float* w = host_slot.data_ptr<float>();
   const float want = (float)ticket;
+  // Tickets count 1 .. 16,000,000 and wrap (instantsplat_amd/lazy_loss.py::_host_slot); a slot is handed out again after 64
+  // materialisations.  A slot that already holds a LATER ticket than the one asked for has been taken over: the value will
+  // never come — say so at once instead of spinning for the whole timeout (a caller that kept old losses and reads them late).
+  auto taken_over = [want](float have) {
+    if (have == 0.f || have == want) return false;          // 0: never written
+    float ahead = have - want;
+    if (ahead < 0.f) ahead += 16000000.f;
+    return ahead < 8000000.f;
+  };
   bool there = w[1] == want;
-  if (!there) {
+  if (!there && !taken_over(w[1])) {
     py::gil_scoped_release nogil;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; ++spin) {
-      if (w[1] == want) { there = true; break; }
+      const float have = w[1];
+      if (have == want) { there = true; break; }
+      if (taken_over(have)) break;
       if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(timeout_us)) break;
     }
   }

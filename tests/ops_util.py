@@ -1743,3 +1743,32 @@ def check_lazy_scalar_behaves_like_a_tensor(dev, H=40, W=56):
             assert same(res[0], res[1]), (name, res[0], res[1])
     finally:
         lazy_loss.ENABLED = was
+
+
+def check_late_item_of_an_old_loss(dev, H=24, W=32, kept=70):
+    """A caller that KEEPS its losses and reads them late (`losses.append(loss)` ... `[l.item() for l in losses]`): the pinned
+    word an old loss was promised has been handed to a later one after 64 materialisations (lazy_loss._host_slot).  Its
+    `.item()` must notice at once — not spin for its timeout — and return the loss's own value through the ordinary read."""
+    import time
+    from instantsplat_amd import lazy_loss, loss_utils
+    from instantsplat_amd.fused_ssim import fused_ssim
+    if not (lazy_loss.ENABLED and lazy_loss.EARLY_ITEM):
+        return
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(3, H, W, generator=g).to(dev)
+    losses, want = [], []
+    for k in range(kept):
+        img = (gt + 0.05 * (k + 1) / kept * torch.randn(3, H, W, generator=g).to(dev)).clamp(0, 1).requires_grad_(True)
+        Ll1 = loss_utils.l1_loss(img, gt)
+        loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - fused_ssim(img.unsqueeze(0), gt.unsqueeze(0)))
+        loss.backward()
+        losses.append(loss)
+        with torch.no_grad():
+            d = img.detach()
+            want.append(0.8 * float((d - gt).abs().mean()) + 0.2 * (1.0 - float(ssim_ref.ssim(d.unsqueeze(0).cpu(), gt.unsqueeze(0).cpu()))))
+    t0 = time.perf_counter()
+    got = [l.item() for l in losses]
+    dt = time.perf_counter() - t0
+    for k in range(kept):
+        assert abs(got[k] - want[k]) <= 2e-6, (k, got[k], want[k])
+    assert dt < 0.15 * kept / 70 + 0.1, dt   # (six taken-over slots at the old 200 ms spin each would be 1.2 s)

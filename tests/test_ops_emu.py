@@ -304,6 +304,10 @@ def test_lazy_scalar_behaves_like_a_tensor(emu):
     ops_util.check_lazy_scalar_behaves_like_a_tensor(emu)
 
 
+def test_late_item_of_an_old_loss(emu):
+    ops_util.check_late_item_of_an_old_loss(emu)
+
+
 def test_deterministic_backward(emu):
     ops_util.check_deterministic_backward(emu, iters=3)
 

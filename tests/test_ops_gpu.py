@@ -181,6 +181,10 @@ def test_lazy_scalar_behaves_like_a_tensor(gpu):
     ops_util.check_lazy_scalar_behaves_like_a_tensor(gpu)
 
 
+def test_late_item_of_an_old_loss(gpu):
+    ops_util.check_late_item_of_an_old_loss(gpu)
+
+
 def test_lazy_loss_expression_at_bench_size(gpu):
     ops_util.check_lazy_loss_expression(gpu, H=512, W=512)
 
