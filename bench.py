@@ -436,15 +436,24 @@ def main():
 
     # ---- instance statistics of the state the kernels were timed on (algorithmic bytes of the composite kernels)
     keep_last_frame(True)
-    Rs, Reffs = [], []
+    Rs, Reffs, Rrefs = [], [], []
+    from instantsplat_amd.diff_gaussian_rasterization import reference_instance_count
+    from instantsplat_amd.pose_utils import get_camera_from_tensor
     with torch.no_grad():
         for cam in stp.cameras:
-            render(cam, stp.gaussians, stp.pipe, stp.background, camera_pose=stp.gaussians.get_RT(cam.uid))
+            pose = stp.gaussians.get_RT(cam.uid)
+            out_ = render(cam, stp.gaussians, stp.pipe, stp.background, camera_pose=pose)
             r, reff = last_frame_stats()
             Rs.append(r)
             Reffs.append(reff)
+            # the PUBLISHED operator's instance count for the same frame (every tile of the 3-sigma square; this library drops
+            # the tiles the {alpha >= 1/255} box cannot reach): the unit SURVEY 8(d) counts algorithmic bytes in
+            w2c = get_camera_from_tensor(pose.detach())
+            Rrefs.append(reference_instance_count(stp.gaussians.get_xyz.detach() @ w2c[:3, :3].t() + w2c[:3, 3], cam.projection_matrix,
+                                                  out_["radii"], int(cam.image_width), int(cam.image_height)))
     keep_last_frame(False)
     R_eff = sum(Reffs) / len(Reffs)
+    R_ref = sum(Rrefs) / len(Rrefs)
 
     # ---- what kind of box this is: the pool has boxes on which the same build runs every kernel 25-70 % longer;
     # a plain device-to-device copy of 256 MiB says which kind the line comes from (fast boxes: 4.8-5.5 TB/s read + write)
@@ -836,6 +845,15 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": bwd_ms,
                          "launches": bwd_n, "timed_every": 1, "timed_where": f"untimed pass, iterations {PIN_ITER + 6} .. {PIN_ITER + 5 + n_prof} of the one-call step",
                          "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs),
+                         "reference_binning": {
+                             "R": R_ref, "over_this_library": R_ref / max(sum(Rs) / len(Rs), 1.0),
+                             "algorithmic_bytes_per_launch": 112.0 * R_ref * (R_eff / max(sum(Rs) / len(Rs), 1.0)) + 20.0 * res * res,
+                             "frac": ((112.0 * R_ref * (R_eff / max(sum(Rs) / len(Rs), 1.0)) + 20.0 * res * res) / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if bwd_ms > 0 else 0.0,
+                             "what": "ADDITIONAL to `frac`, which counts this library's own lists: the published operator bins every tile of a "
+                                     "Gaussian's 3-sigma square (its num_rendered for the same frames: instantsplat_amd.diff_gaussian_rasterization."
+                                     "reference_instance_count), this library drops the tiles in which no pixel can pass alpha >= 1/255 — same image, "
+                                     "same gradients.  R x (this run's R_eff / R) stands in for the reference lists' consumed instances; bytes and "
+                                     "frac are the composite backward's in the reference formulation's accounting (SURVEY 8d)"},
                          "pmc_sq": valu, "compute": compute,
                          "note": "achieved / peak / frac are the HBM roofline the contract asks for (algorithmic bytes / kernel time / 8 TB/s); "
                                  "the kernel is bound by VALU issue, not by HBM: frac_issue = modelled VALU issue cycles per SIMD / the kernel's "

@@ -56,6 +56,27 @@ def last_frame_stats():
     return int(r), int(reff)
 
 
+def reference_instance_count(means_cam: torch.Tensor, projmatrix: torch.Tensor, radii: torch.Tensor, W: int, H: int) -> int:
+    """Roofline accounting only: the number of (tile, Gaussian) instances the PUBLISHED operator's binning holds for this frame —
+    its `num_rendered`: every tile of the 3-sigma square around the projected centre (recalled upstream `getRect`: truncating
+    `(p - r) / 16` and `(p + r + 15) / 16`, clamped to the grid), summed over the Gaussians with radii > 0.  This library bins
+    fewer (csrc/preprocess.hip intersects the square with the box around {alpha >= 1/255}); SURVEY 8(d) counts a kernel's
+    algorithmic bytes per instance of the reference formulation.  means_cam: camera-frame centres [P,3]; projmatrix as handed to
+    the operator; radii: the operator's output."""
+    with torch.no_grad():
+        m = means_cam.detach().float()
+        hom = torch.cat([m, torch.ones_like(m[:, :1])], dim=1) @ projmatrix.to(m.device).float()
+        pw = 1.0 / (hom[:, 3] + 0.0000001)
+        px = ((hom[:, 0] * pw + 1.0) * W - 1.0) * 0.5
+        py = ((hom[:, 1] * pw + 1.0) * H - 1.0) * 0.5
+        r = radii.to(m.device).float()
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        x0 = ((px - r) / 16).trunc().clamp(0, gx); x1 = ((px + r + 15) / 16).trunc().clamp(0, gx)
+        y0 = ((py - r) / 16).trunc().clamp(0, gy); y1 = ((py + r + 15) / 16).trunc().clamp(0, gy)
+        area = ((x1 - x0) * (y1 - y0)).to(torch.int64)
+        return int(area[radii.to(m.device) > 0].sum())
+
+
 class _Pending:
     """One frame rendered without reading its instance count back (BinningPolicy mode "bounded")."""
     __slots__ = ("ev", "slot", "capacity", "key", "tag", "hold", "dev")

@@ -269,3 +269,17 @@ def test_fd_harness_detects_a_wrong_gradient():
     s = float(fd["scales"].abs().max())
     assert float((ana["scales"] - fd["scales"]).abs().max()) / s <= 1e-6
     assert float((wrong - fd["scales"]).abs().max()) / s > 1e-6 or float(ana["scales"][2, 1].abs()) < 1e-3 * s
+
+
+@pytest.mark.parametrize("P,W,H,sm", [(3000, 200, 150, 0.05), (800, 64, 48, 0.6), (5000, 333, 100, 0.01), (1, 16, 16, 0.05)])
+def test_reference_instance_count_is_the_oracles_num_rendered(P, W, H, sm):
+    """bench.py's `roofline.reference_binning.R` (diff_gaussian_rasterization.reference_instance_count: the published operator's
+    3-sigma-square tile count from centres and radii, no oracle involved) equals the instance count of the oracle's own binning."""
+    from instantsplat_amd.diff_gaussian_rasterization import reference_instance_count
+    from instantsplat_amd.synthetic import syn_blob
+    from tests.util import settings_for
+    sc = syn_blob(P, W, H, seed=2, scale_mean=sm)
+    st = settings_for(sc.camera, 1, rt.RasterSettings, torch.zeros(3))
+    _, radii, ctx = gs_ref.forward(sc.means3D, torch.sigmoid(sc.opacity_logit).reshape(-1), st, shs=sc.shs, scales=torch.exp(sc.scaling_logit),
+                                   rotations=sc.rotation)
+    assert reference_instance_count(sc.means3D, st.projmatrix, radii, W, H) == ctx.num_rendered   # (identity view: camera frame = world)
