@@ -8,8 +8,13 @@ LR schedule, random view, render (pose transform + rasterizer forward), fused L1
 `value` is the loop an UNMODIFIED reference train.py executes with the operator packages aliased: its loop
 shape on the drop-in operators — `render()` / `GaussianRasterizer` / `l1_loss` / `fused_ssim` / `PerPointAdam` through the compiled
 binding —, the loss formed exactly as train.py:171-176 writes it (l1_loss + fused_ssim + scalar arithmetic, served by
-instantsplat_amd/lazy_loss.py), autograd, and BOTH of the reference's blocking host read-backs per iteration (the operator's
-instance count, `loss.item()` at train.py:188).  Measured next to it under the same protocol and reported as siblings (`loops`):
+instantsplat_amd/lazy_loss.py), autograd, and both of the reference's host read-backs per iteration: the operator's instance count
+(blocking) and `loss.item()` at train.py:188, which in this loop is NOT a blocking read — it polls a pinned host word the loss
+kernel stores into, so the host runs one stage ahead of the backward (the timed blocks are bracketed by device synchronizes, the
+rate is honest).  The like-for-like number against the reference's blocking `item()` and against rounds 1-4 is the sibling
+`dropin_reference_loop_train_py_loss_late_item`; `value_without_host_tricks` is the loop with lazy_loss off altogether.
+THE LINE: one JSON line under 8 KB (compact_line); the long form of the run is written to gpurun_out/bench_full_n<N>.json.
+Measured next to it under the same protocol and reported as siblings (`loops`):
 the same loop with the loss as ONE fused call (`dropin_reference_loop_fused_loss`: what a caller who may edit train.py would
 write), with torch's own l1_loss, and with the lazy loss mechanism switched off (the expression's sixteen eager launches); the same iteration behind one library call with the loss read back every iteration
 (`one_call_synced`: the library's two-part step — forward + backward of iteration t + 1 are enqueued before the host reads
@@ -44,6 +49,94 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+LINE_LIMIT = 8192   # bytes: the driver stores a tail of stdout; round 5's 23.8 KB line came back as `parsed: null`
+
+
+def _sig(x, n=5):
+    """floats to n significant digits (the line is read by people and by a parser with a small window), containers recursively"""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def compact_line(full, full_path):
+    """THE line the contract asks for, from the full record: the contract's keys, `roofline`, `cpu_baseline`, one number per loop,
+    the other BASELINE configs as two numbers each, a short per-rank table at N > 1.  Everything else (block times, per-part
+    issue tables, counter readings of the small kernels, prose) stays in the full record at `full_record`."""
+    rf = full["roofline"]
+    pick = lambda d, keys: {k: d[k] for k in keys if d is not None and k in d}
+    roof = pick(rf, ("kernel", "bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_issue", "traffic", "avg_kernel_ms", "launches",
+                     "algorithmic_bytes_per_launch", "R_eff", "R"))
+    roof["useful_lane_frac"] = (rf.get("compute") or {}).get("useful_lane_frac")
+    roof["valu_wave_insts_pmc"] = (rf.get("pmc_sq") or {}).get("wave_insts_per_launch")
+    roof["valu_wave_insts_model"] = (rf.get("compute") or {}).get("valu_wave_instructions_per_launch_model")
+    roof["reference_binning"] = pick(rf.get("reference_binning") or {}, ("R", "frac"))
+    roof["composite_fwd"] = dict(pick(rf["composite_fwd"], ("avg_kernel_ms", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch")),
+                                 frac_issue=(rf["composite_fwd"].get("compute") or {}).get("issue_frac_at_2.4GHz"))
+    roof["render_only"] = pick(rf["render_only"], ("avg_kernel_ms", "achieved", "frac", "traffic", "write_traffic"))
+    roof["small_kernels"] = {k: pick(v, ("avg_kernel_ms", "frac", "traffic")) for k, v in (rf.get("small_kernels") or {}).items()}
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "config", "rasterize_ms_per_frame")}
+    line["value_path"] = full["value_path"]
+    line["value_without_host_tricks"] = full["value_without_host_tricks"]
+    line["loops"] = {k: v["iters_per_sec"] for k, v in full["loops"].items()}
+    line["timed_blocks"] = full["timed_blocks"]
+    lr = full.get("iters_per_sec_1k")
+    line["iters_per_sec_1k"] = {k: v["iters_per_sec"] for k, v in lr.items()} if lr else None
+    line["fps_reference_method"] = (full.get("fps_reference_method") or {}).get("fps")
+    line["psnr_before"], line["psnr_after_mean"] = full["psnr_before"], full["psnr_after_mean"]
+    line["roofline"] = roof
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "sample", "c2_forward_ms_per_frame")) if cb else None
+    line["configs"] = full.get("configs")
+    line["box"] = pick(full.get("box") or {}, ("device_copy_TB_per_s", "cpus_visible", "pin", "cpus_kept"))
+    line["collective_backend"], line["ranks_share_a_gpu"] = full["collective_backend"], full["ranks_share_a_gpu"]
+    m = full.get("multi_gpu")
+    if m:
+        rk = ("rank", "gpu", "cpus", "first_cpu", "iters_per_sec_median_block_own_clock", "psnr_after", "composite_bwd_avg_ms",
+              "composite_fwd_avg_ms", "composite_bwd_frac_hbm", "composite_fwd_frac_hbm", "R_eff")
+        line["multi_gpu"] = dict(pick(m, ("ranks_seen", "world_size", "backend", "rccl_version", "solo_rank0_iters_per_sec",
+                                          "scaling_efficiency_vs_solo_rank0")),
+                                 hosts=sorted({r_.get("host") for r_ in m["per_rank"]}),
+                                 collectives_checked=(m.get("collective_selftest") or {}).get("checked"),
+                                 per_rank=[dict(pick(r_, rk), gpu=(r_.get("gpu") or {}).get("device"),
+                                                device_copy_TB_per_s=(r_.get("box") or {}).get("device_copy_TB_per_s")) for r_ in m["per_rank"]])
+    else:
+        line["multi_gpu"] = None
+    line["legs_skipped"] = len(full.get("legs_skipped") or [])
+    line["binding"] = full["binding"]
+    line["full_record"] = full_path
+    line = _sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:   # never again an unreadable line: shed the optional blocks, largest first, and say so
+        for victim in (("roofline", "small_kernels"), ("configs",), ("multi_gpu", "per_rank"), ("roofline", "render_only"), ("loops",)):
+            d = line
+            for k in victim[:-1]:
+                d = d.get(k) or {}
+            if victim[-1] in d:
+                d[victim[-1]] = "see full_record"
+                line["line_trimmed"] = True
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    return text
+
+
+def write_full_record(full, world):
+    """the long form of the run — every block time, table and explanatory string — next to the other scratch records"""
+    path = os.environ.get("MI355GS_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", f"bench_full_n{world}.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(full, fh, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
 
 
 def supervise(args):
@@ -81,8 +174,8 @@ def supervise(args):
             sys.exit(proc.returncode or 1)
         line = json.loads(lines[-1])
         line["attempts"] = attempt
-        line["attempt_seconds"] = time.perf_counter() - t0
-        print(json.dumps(line), flush=True)
+        line["attempt_seconds"] = round(time.perf_counter() - t0, 2)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
         return
     sys.exit(1)
 
@@ -99,6 +192,9 @@ def main():
                     help="active SH degree during the run (exploratory; the reference's 1000-iteration schedule trains at 0)")
     ap.add_argument("--no-long-run", dest="long_run", action="store_false",
                     help="skip the two 1000-iteration training runs and the 1000-frame FPS loop reported next to the bench line (~3 s)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip the C2 (50k Gaussians, forward only) and C4 (995k Gaussians, 1080p, render + loss + backward) legs reported "
+                         "as `configs` next to the bench line (~5 s; N = 1 only)")
     ap.add_argument("--emulated-kernels", default=None, metavar="LIBMI355GS_EMU_SO",
                     help="TEST MODE for the CPU tier only (tests/test_dist.py): run the spawn / rendezvous / reduction plumbing with "
                          "the g++-built SIMT emulation of the kernels on CPU tensors over gloo.  Never a measurement; the line says so.")
@@ -174,7 +270,9 @@ def main():
     if pin_mode() != "off":   # MI355GS_PIN: node (default) | compact | off, see launch.pin_mode
         cpus = pin_rank_to_cpu_slice(local_rank, local_world_size(world), device_of_rank=None if emulated else (lambda r: r % n_dev_),
                                      compact=pin_mode() == "compact" and not emulated)
-    collectives = world > 1 or args.force_collectives   # a process group exists: every barrier / reduction below goes through it
+    # a process group exists — every barrier / reduction below goes through it — at N > 1, on request, and whenever a launcher
+    # started this rank (the driver's N > 1 command shape at world size 1 exercises the same init path and per-rank table)
+    collectives = world > 1 or args.force_collectives or "WORLD_SIZE" in os.environ
     selftest = None
     if collectives:
         init_collectives(backend, rank, world, dev)
@@ -640,18 +738,18 @@ def main():
     except Exception:
         ro_traffic = None
 
-    valu = None
+    pmc_sq = None
     try:  # SQ counter pass of the same command (separate run)
         for rnd in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 row = pmc_rows(f"{rnd}_pmc_c3_SQ_counters.csv")["k_composite_bwd"]
             except (OSError, KeyError):
                 continue
-            valu = {"wave_insts_per_launch": float(row["mean_SQ_INSTS_VALU"]), "salu_insts_per_launch": float(row["mean_SQ_INSTS_SALU"]),
-                    "source": f"profiles/{rnd}_pmc_c3_SQ_counters.csv"}
+            pmc_sq = {"wave_insts_per_launch": float(row["mean_SQ_INSTS_VALU"]), "salu_insts_per_launch": float(row["mean_SQ_INSTS_SALU"]),
+                      "source": f"profiles/{rnd}_pmc_c3_SQ_counters.csv"}
             break
     except Exception:
-        valu = None
+        pmc_sq = None
 
     # ---- the three largest kernels of the small-kernel tail (a third of the iteration is nine kernels of 5-17 us): HBM roofline from
     # this run's event times and each kernel's algorithmic bytes, and WHY it is not on that roofline from the SQ counters of a
@@ -716,9 +814,9 @@ def main():
             try:
                 wc = float(row["mean_SQ_WAVE_CYCLES"])
                 parked, stalled, active = float(row["mean_SQ_WAIT_ANY"]) / wc, float(row["mean_SQ_WAIT_INST_ANY"]) / wc, float(row["mean_SQ_ACTIVE_INST_ANY"]) / wc
-                valu = float(row["mean_SQ_ACTIVE_INST_VALU"]) / wc
+                issuing_valu = float(row["mean_SQ_ACTIVE_INST_VALU"]) / wc   # (NOT `valu`: that name is roofline.pmc_sq, the backward's instruction counts)
                 ent["counters"] = {"source": sq_src, "wave_cycles_parked_frac": parked, "wave_cycles_issue_stalled_frac": stalled,
-                                   "wave_cycles_issuing_frac": active, "wave_cycles_issuing_valu_frac": valu,
+                                   "wave_cycles_issuing_frac": active, "wave_cycles_issuing_valu_frac": issuing_valu,
                                    "valu_wave_instructions_per_launch": float(row["mean_SQ_INSTS_VALU"]),
                                    "waves_per_launch": float(row["mean_SQ_WAVES"]),
                                    "busy_cycles_per_launch": float(row["mean_SQ_BUSY_CYCLES"])}
@@ -727,6 +825,82 @@ def main():
             except (KeyError, ValueError, ZeroDivisionError):
                 pass
         small[kname] = ent
+
+    # ---- BASELINE configs[1] (C2) and configs[3] (C4) as two numbers each, outside the timed region (N = 1 only; --no-other-configs skips)
+    configs_out, c2_img, c2_scene = None, None, None
+    if not emulated and world == 1 and args.other_configs:
+        import math
+        from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        from instantsplat_amd.fused_ssim import fused_l1_ssim_loss
+        from instantsplat_amd.synthetic import syn_blob
+        del stp
+        torch.cuda.empty_cache()
+        configs_out = {}
+        # C2: 50k random Gaussians (SH degree 3), one 512 x 512 camera, forward raster only — the operator call with its count read-back
+        c2_scene = syn_blob(50000, 512, 512, seed=0)
+        cam2 = c2_scene.camera
+        stg = GaussianRasterizationSettings(cam2.image_height, cam2.image_width, math.tan(cam2.FoVx / 2), math.tan(cam2.FoVy / 2), c2_scene.bg.to(dev), 1.0,
+                                            torch.eye(4, device=dev), cam2.projection_matrix.to(dev), 3, torch.zeros(3, device=dev), False, False)
+        a2 = dict(means3D=c2_scene.means3D.to(dev), means2D=torch.zeros(50000, 3, device=dev), opacities=torch.sigmoid(c2_scene.opacity_logit).to(dev),
+                  shs=c2_scene.shs.to(dev), scales=torch.exp(c2_scene.scaling_logit).to(dev), rotations=c2_scene.rotation.to(dev))
+        rast2 = GaussianRasterizer(stg)
+        with torch.no_grad():
+            for _ in range(5):
+                rast2(**a2)
+            dev_sync()
+            t2 = time.perf_counter()
+            for _ in range(200):
+                rast2(**a2)
+            dev_sync()
+            c2_ms = 1e3 * (time.perf_counter() - t2) / 200
+            c2_img = rast2(**a2)[0].cpu()
+        configs_out["C2"] = {"ms_per_frame": c2_ms, "max_abs_diff_vs_oracle": None}
+        del a2, rast2
+        # C4: 12 views, 995,328 Gaussians, 1920 x 1080 — render + fused L1/SSIM loss + backward per view; the composite backward's
+        # event time and its HBM fraction on this frame's own R_eff
+        sc4 = syn_pointmap(12, 288, 288, 1920, 1080, seed=0)
+        st4 = setup_training(sc4, dev)
+        g4 = st4.gaussians
+
+        def fb4(cam_):
+            img_ = render(cam_, g4, st4.pipe, st4.background, camera_pose=g4.get_RT(cam_.uid))["render"]
+            loss_, _ = fused_l1_ssim_loss(img_.unsqueeze(0), st4.gt_images[cam_.uid].unsqueeze(0), 0.2)
+            loss_.backward()
+            for p_ in (g4._xyz, g4._features_dc, g4._features_rest, g4._opacity, g4._scaling, g4._rotation, g4.P):
+                p_.grad = None
+        for i in range(3):
+            fb4(st4.cameras[i])
+        dev_sync()
+        t4 = time.perf_counter()
+        for i in range(12):
+            fb4(st4.cameras[i])
+        dev_sync()
+        c4_ms = 1e3 * (time.perf_counter() - t4) / 12
+        L.mi355gs_profile_set_period(1)
+        L.mi355gs_profile_begin()
+        for i in range(12):
+            fb4(st4.cameras[i])
+        dev_sync()
+        c4k = {}
+        for kind, name in ((0, "fwd"), (1, "bwd")):
+            _lib.check(L.mi355gs_profile_read(kind, ctypes.byref(tot_ms), ctypes.byref(n)), "profile_read")
+            c4k[name] = tot_ms.value / max(n.value, 1)
+        L.mi355gs_profile_end()
+        keep_last_frame(True)
+        reff4 = []
+        with torch.no_grad():
+            for cam_ in st4.cameras:
+                render(cam_, g4, st4.pipe, st4.background, camera_pose=g4.get_RT(cam_.uid))
+                reff4.append(last_frame_stats()[1])
+        keep_last_frame(False)
+        R4 = sum(reff4) / len(reff4)
+        configs_out["C4"] = {"ms_per_view": c4_ms, "gaussians": int(g4.get_xyz.shape[0]), "R_eff": R4,
+                             "composite_bwd_ms": c4k["bwd"], "composite_fwd_ms": c4k["fwd"],
+                             "bwd_frac": (112.0 * R4 + 20.0 * 1920 * 1080) / (c4k["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS if c4k["bwd"] > 0 else None,
+                             "fwd_frac": (40.0 * R4 + 20.0 * 1920 * 1080 + 8.0 * 120 * 68) / (c4k["fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS if c4k["fwd"] > 0 else None}
+        del st4, g4, sc4
+        torch.cuda.empty_cache()
+        BinningPolicy.reset("exact")
 
     cpu_baseline = None
     if cpu_trainer is not None:
@@ -747,9 +921,22 @@ def main():
             cpu_trainer.iteration()
         cdt = time.perf_counter() - tc
         cpu_baseline = {"value": args.cpu_iters / cdt, "unit": "iters/s", "cores": threads, "kind": "port",
-                        "sample": f"{args.cpu_iters} full train iterations (after 1 warm-up) of the same workload from the same "
-                                  f"initial state: oracle/gs_ref.c rasterizer fwd+bwd (OpenMP) + PyTorch CPU glue, SSIM/L1 "
-                                  f"(the reference's own utils/loss_utils.py definition) and PerPointAdam restatement"}
+                        "sample": f"{args.cpu_iters} full C3 train iterations after 1 warm-up, same initial state: oracle/gs_ref.c "
+                                  f"rasterizer fwd+bwd (OpenMP) + PyTorch CPU glue, the reference's SSIM/L1, PerPointAdam restatement"}
+        if c2_scene is not None:   # configs[1] on the CPU path, and the device's C2 image checked against it (the checker, in the checker's leg)
+            import math
+            from oracle import raster_torch as rt
+            cam2 = c2_scene.camera
+            stc = rt.RasterSettings(cam2.image_height, cam2.image_width, math.tan(cam2.FoVx / 2), math.tan(cam2.FoVy / 2), c2_scene.bg, 1.0,
+                                    torch.eye(4), cam2.projection_matrix, 3, torch.zeros(3), False, False)
+            c2f = lambda: gs_ref.forward(c2_scene.means3D, torch.sigmoid(c2_scene.opacity_logit).reshape(-1), stc, shs=c2_scene.shs,
+                                         scales=torch.exp(c2_scene.scaling_logit), rotations=c2_scene.rotation)
+            c2f()
+            tc = time.perf_counter()
+            for _ in range(5):
+                img_cpu = c2f()[0]
+            cpu_baseline["c2_forward_ms_per_frame"] = 1e3 * (time.perf_counter() - tc) / 5
+            configs_out["C2"]["max_abs_diff_vs_oracle"] = float((c2_img - img_cpu).abs().max())
 
     # ---- N > 1: who ran where, and how the ranks compare (the driver gets one shot at the 8-GPU node: make it informative)
     multi = None
@@ -782,7 +969,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "train_iters_per_sec", "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "metric": "train_iters_per_sec" + ("_SHARED_GPU" if shared_gpu else ""), "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not emulated else "synthetic — EMULATED KERNELS ON CPU (plumbing test mode, not a measurement)",
@@ -791,13 +978,16 @@ def main():
                                    f"optimisation (PerPointAdam, lambda_dssim 0.2, SH degree {args.sh_degree}"
                                    f"{' as in the reference first 1000 iterations' if args.sh_degree == 0 else ' (exploratory)'}"
                                    f"), one scene per GPU", "views": V, "gaussians": P, "width": res, "height": res,
-                       "parallelism": f"scene-per-gpu x{world}"},
+                       "parallelism": f"scene-per-gpu x{world}" + (" — RANKS SHARE A GPU: not a scaling result" if shared_gpu else ""),
+                       "parity": "oracle-relative (fp32 oracle's own error vs fp64 x <= 2.5 fixed inputs, 3-4 trained states); rasterizer core (N1) unpinned: no CUDA reference exists"},
             "rasterize_ms_per_frame": raster_ms,
             "rasterize_ms_per_frame_without_count_readback": {"ms_per_frame": raster_ms_bounded, "overflowed_frames": bounded_overflows,
                                                               "what": "the same view rendered 200 times with BinningPolicy 'bounded' (instance buffers sized from the view's last verified count, counts verified afterwards): no host wait inside render().  "
                                                                       "Equal to the line above when the frame is bound by its kernels (preprocess + binning + render-only composite), which is the case at this size"},
             "box": box,
-            "value_path": "drop-in reference loop, train.py:171-176 loss as written",
+            "value_path": "drop-in reference loop, train.py:171-176 loss as written (lazy_loss: 3 launches; loss.item() polls a pinned word, non-blocking)",
+            "value_without_host_tricks": eager_sib["iters_per_sec"],   # MI355GS_LAZY_LOSS=0 (and with it no early item): the three operator aliases alone
+            "configs": configs_out,
             "loop": "what an unmodified reference train.py executes with the operator packages aliased (INTEGRATION.md 1): render() / "
                     "GaussianRasterizer / l1_loss / fused_ssim / PerPointAdam through the compiled binding, the loss formed as "
                     "train.py:171-176 writes it (l1_loss + fused_ssim + four scalar operations: instantsplat_amd/lazy_loss.py), autograd, "
@@ -840,7 +1030,7 @@ def main():
             "multi_gpu": multi, "legs_skipped": legs_skipped,
             "psnr_before": psnr_before, "psnr_after_mean": mean_psnr,
             "iters_per_sec_1k": long_runs, "fps_reference_method": fps,
-            "roofline": {"kernel": "k_composite_bwd", "bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_composite_bwd", "bound": "hbm", "limited_by": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_hbm": achieved / HBM_PEAK_GBS, "frac_issue": (compute or {}).get("issue_frac_at_2.4GHz"),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": bwd_ms,
                          "launches": bwd_n, "timed_every": 1, "timed_where": f"untimed pass, iterations {PIN_ITER + 6} .. {PIN_ITER + 5 + n_prof} of the one-call step",
@@ -854,7 +1044,7 @@ def main():
                                      "reference_instance_count), this library drops the tiles in which no pixel can pass alpha >= 1/255 — same image, "
                                      "same gradients.  R x (this run's R_eff / R) stands in for the reference lists' consumed instances; bytes and "
                                      "frac are the composite backward's in the reference formulation's accounting (SURVEY 8d)"},
-                         "pmc_sq": valu, "compute": compute,
+                         "pmc_sq": pmc_sq, "compute": compute,
                          "note": "achieved / peak / frac are the HBM roofline the contract asks for (algorithmic bytes / kernel time / 8 TB/s); "
                                  "the kernel is bound by VALU issue, not by HBM: frac_issue = modelled VALU issue cycles per SIMD / the kernel's "
                                  "cycles at 2.4 GHz (roofline.compute: work counters of this run x per-part costs of the shipped binary).  "
@@ -878,7 +1068,7 @@ def main():
                                          "rasterize_ms_per_frame_whole_render": raster_ms}},
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out), file=line_out, flush=True)
+        print(compact_line(out, write_full_record(out, world)), file=line_out, flush=True)
     if collectives:
         dist.barrier()   # every rank has handed in its report and rank 0 has printed: tear the group down together, none while a peer still talks to it
         dist.destroy_process_group()

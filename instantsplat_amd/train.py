@@ -587,7 +587,9 @@ class RunAhead:
                 self.flush()
                 self._snapshot()
             loss = _forward_backward_step(self.st, self.fused)
-            self.ring[self.n_in_window] = loss
+            # (a detached value: with the loss lines as written `loss` is a LazyScalar whose materialised tensor requires grad after
+            # the backward — written as it is, the persistent ring would become a non-leaf and chain every iteration's graph onto itself)
+            self.ring[self.n_in_window] = loss.detach()
             _optimizer_step(self.st)
         self.n_in_window += 1
         if self.n_in_window == self.window:

@@ -297,6 +297,34 @@ def check_run_ahead_equals_sync_loop(dev, iters=23, force_overflow=False, Wm=20,
         BinningPolicy.reset("exact")
 
 
+def check_run_ahead_ring_stays_a_leaf_with_the_loss_as_written(dev, Wm=10, W=24):
+    """RunAhead on the autograd path with train.py's loss lines as written (fused_loss=False, no one-call
+    trainer).  `_forward_backward_step` hands back the LazyScalar; written into the persistent loss ring as it is, its materialised
+    tensor — which requires grad after the backward — turned the ring into a non-leaf and chained every iteration's render graph
+    onto it for the whole run.  The ring must stay a plain buffer, and hold the same values as the per-iteration read."""
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.diff_gaussian_rasterization import BinningPolicy
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import RunAhead, setup_training, train_iteration
+    sc = syn_pointmap(3, Wm, Wm, W, W, seed=3)
+    mk = lambda: setup_training(sc, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True))
+    try:
+        st_a = mk()
+        want = [train_iteration(st_a, fused_loss=False) for _ in range(4)]
+        ra = RunAhead(mk(), window=8, fused_loss=False, fused_step=False)
+        assert ra.trainer is None
+        for _ in range(4):
+            ra.step()
+            assert ra.ring.grad_fn is None and not ra.ring.requires_grad
+        got = ra.ring[:4].tolist()
+        ra.flush()
+        cuda = torch.device(dev).type == "cuda"
+        for a, b in zip(got, want):
+            bound("run_ahead_ring/loss", abs(a - b) / max(1e-3, abs(b)), 2e-3 if cuda else 1e-6)
+    finally:
+        BinningPolicy.reset("exact")
+
+
 def check_run_ahead_sticky_commit_gate(dev, iters=17, Wm=20, W=48):
     """An overflow in the MIDDLE of a run-ahead window on the one-call step: the buffers hold every view but the heaviest one, so
     windows overflow at whatever position that view is drawn.  The sticky commit gate (include/mi355gs.h) makes that iteration's

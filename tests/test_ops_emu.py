@@ -47,6 +47,10 @@ def test_run_ahead_equals_sync_loop(emu):
     ops_util.check_run_ahead_equals_sync_loop(emu, iters=7, Wm=12, W=32)
 
 
+def test_run_ahead_ring_stays_a_leaf_with_the_loss_as_written(emu):
+    ops_util.check_run_ahead_ring_stays_a_leaf_with_the_loss_as_written(emu)
+
+
 def test_run_ahead_overflow_is_replayed_exactly(emu):
     ops_util.check_run_ahead_equals_sync_loop(emu, iters=7, force_overflow=True, Wm=12, W=32)
 

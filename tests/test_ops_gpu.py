@@ -39,6 +39,10 @@ def test_run_ahead_equals_sync_loop(gpu):
     ops_util.check_run_ahead_equals_sync_loop(gpu, iters=23)
 
 
+def test_run_ahead_ring_stays_a_leaf_with_the_loss_as_written(gpu):
+    ops_util.check_run_ahead_ring_stays_a_leaf_with_the_loss_as_written(gpu)
+
+
 def test_run_ahead_overflow_is_replayed_exactly(gpu):
     ops_util.check_run_ahead_equals_sync_loop(gpu, iters=23, force_overflow=True)
 
