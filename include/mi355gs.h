@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355GS_ABI_VERSION 9
+#define MI355GS_ABI_VERSION 10
 
 /* error codes */
 #define MI355GS_OK 0
@@ -188,6 +188,15 @@ int mi355gs_profile_set_period(int every);
 int mi355gs_profile_work_counters(void* counters);
 int mi355gs_profile_read(int kind, double* total_ms, int* launches);
 int mi355gs_profile_end(void);
+/* roctx ranges (ABI v10; SURVEY.md section 5, row 1: the reference has no ranges at all, its profile is TensorBoard's iter_time,
+ * train.py:114-115,140,178).  While on, every entry point that enqueues kernels brackets itself with
+ * roctxRangePushA(<its name>) / roctxRangePop() — the stages of a train step appear as nested ranges under
+ * "mi355gs_trainer_step" in `rocprofv3 --marker-trace --kernel-trace` (tools/prof.sh).  The roctx library
+ * (librocprofiler-sdk-roctx.so, else libroctx64.so) is opened with dlopen on first use: the library has no link-time dependency
+ * on it, and without it this stays off.  on = 1 / 0: switch (also on at load with MI355GS_ROCTX=1); on = -1: query.
+ * Returns the number of ranges pushed since the library was loaded (>= 0), or MI355GS_EINVAL if roctx could not be opened when
+ * asked to switch on. */
+int mi355gs_profile_ranges(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * fused SSIM (+ optional L1) loss

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "mi355gs_profile_work_counters": (c_int, [_P]),
     "mi355gs_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "mi355gs_profile_end": (c_int, []),
+    "mi355gs_profile_ranges": (c_int, [c_int]),
     "mi355gs_ssim_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mi355gs_ssim_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
     "mi355gs_ssim_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
@@ -78,7 +79,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-ABI_VERSION = 9   # include/mi355gs.h MI355GS_ABI_VERSION the signatures above were written for
+ABI_VERSION = 10   # include/mi355gs.h MI355GS_ABI_VERSION the signatures above were written for
 
 
 def _bind(path: str):

@@ -199,6 +199,7 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
                                        const float* const* per_point_lr, const float* lr, float beta1, float beta2, float eps,
                                        const int32_t* step, float* scratch, const float* gate, const int32_t* gate_index,
                                        uint32_t* live, uint32_t seq) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (ntensors < 0 || ntensors > MT_MAX || (gate && !gate_index)) return MI355GS_EINVAL;
@@ -266,6 +267,7 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
       s.n = k;
       if (hipMemsetAsync(scratch, 0, MT_MAX * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
       if (sblocks > 0) {
+        GS_KRANGE("adam_sumsq");
         hipLaunchKernelGGL(k_adam_sumsq, dim3(sblocks), dim3(256), 0, stream, s, scratch);
         GS_CHECK_LAUNCH("adam_sumsq");
       }
@@ -276,9 +278,11 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
     for (int t = 0; t < ntensors; ++t) a.gidx[t] = t;
   } else {
     if (hipMemsetAsync(scratch, 0, MT_MAX * sizeof(float), stream) != hipSuccess) return MI355GS_ELAUNCH;
+    GS_KRANGE("adam_sumsq");
     hipLaunchKernelGGL(k_adam_sumsq, dim3(blocks), dim3(256), 0, stream, a, scratch);
     GS_CHECK_LAUNCH("adam_sumsq");
   }
+  GS_KRANGE("adam_multi");
   hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, stream, a, (const float*)scratch, beta1, beta2, eps);
   GS_CHECK_LAUNCH("adam_multi");
   return MI355GS_OK;
@@ -287,6 +291,7 @@ extern "C" int mi355gs_adam_multi_step(void* stream_, int ntensors, const int64_
 extern "C" int mi355gs_adam_step(void* stream_, int64_t n, int row, float* param, const float* grad, float* exp_avg,
                                  float* exp_avg_sq, const float* per_point_lr, const float* grad_sumsq, float lr, float beta1,
                                  float beta2, float eps, int step) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (n < 0 || row <= 0 || step <= 0 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return MI355GS_EINVAL;
@@ -295,6 +300,7 @@ extern "C" int mi355gs_adam_step(void* stream_, int64_t n, int row, float* param
   const float step_size = (float)((double)lr * (sqrt(bc2) / bc1));
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 4) blocks = 2048 * 4;
+  GS_KRANGE("adam");
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, stream, n, row, param, grad, exp_avg, exp_avg_sq, per_point_lr,
                      grad_sumsq, step_size, beta1, beta2, eps);
   GS_CHECK_LAUNCH("adam");

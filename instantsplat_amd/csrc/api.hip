@@ -2,6 +2,8 @@
 // Host-side only: argument checks, scratch-layout arithmetic, kernel enqueue order.
 #include <stdio.h>
 #include "common.h"
+#include <dlfcn.h>
+#include <cstdlib>
 
 // launchers implemented next to their kernels
 int gs_launch_preprocess_fwd(hipStream_t, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*,
@@ -59,6 +61,37 @@ typedef GsProfScope ProfScope;
 
 thread_local GsFusedStepHooks g_fused;
 
+// ---- roctx ranges (mi355gs_profile_ranges): the marker library is opened at run time, on request
+bool g_ranges_on = false;
+thread_local bool g_krange_open = false;
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+  unsigned long long pushed = 0;
+} g_roctx;
+bool roctx_open() {
+  if (!g_roctx.tried) {
+    g_roctx.tried = true;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      g_roctx.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (g_roctx.push && g_roctx.pop) break;
+      g_roctx.push = nullptr; g_roctx.pop = nullptr;
+    }
+  }
+  return g_roctx.push != nullptr;
+}
+struct RoctxEnv {   // MI355GS_ROCTX=1: ranges from the first call on (a whole run under rocprofv3 --marker-trace)
+  RoctxEnv() { const char* e = getenv("MI355GS_ROCTX"); if (e && e[0] == '1' && roctx_open()) g_ranges_on = true; }
+} g_roctx_env;
+}  // namespace
+void gs_range_push(const char* name) { ++g_roctx.pushed; (void)g_roctx.push(name); }
+void gs_range_pop() { (void)g_roctx.pop(); }
+
 void gs_log_error(const char* where, const char* what) { fprintf(stderr, "[mi355gs] %s failed: %s\n", where, what); }
 
 static int g_scale_grad_exact = 0;   // mi355gs_tune_scale_grad
@@ -113,6 +146,7 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
                                       const float* viewmatrix, const float* projmatrix, const float* campos, float tanfovx,
                                       float tanfovy, int prefiltered, int32_t* radii, void* geom, void* tiles,
                                       int32_t* num_rendered, uint8_t* visible, void* grad_scratch, int debug) {
+  GS_RANGE();
   (void)prefiltered;  // as in the reference operator it only affects an internal consistency check
   hipStream_t stream = (hipStream_t)stream_;
   if (P < 0 || W <= 0 || H <= 0 || W > 65535 * GS_TILE || H > 65535 * GS_TILE || D < 0 || D > 3) return MI355GS_EINVAL;
@@ -140,12 +174,15 @@ int mi355gs_raster_forward_preprocess(void* stream_, int P, int D, int M, int W,
     }
   }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
+  GS_KRANGE("preprocess_fwd");
   gs_launch_preprocess_fwd(stream, P, D, M, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, cp, radii,
                            (GsRec*)(g + gl.rec), (float*)(g + gl.cov3D), (uint2*)(g + gl.rect), (uint8_t*)(g + gl.clamped), (float*)(g + gl.depth), visible, pro);
   GS_CHECK_LAUNCH("preprocess_fwd");
+  GS_KRANGE("count_tiles");
   gs_launch_count_tiles(stream, P, tl.T, tl.gx, (const uint2*)(g + gl.rect), (uint32_t*)(t + tl.count), (uint32_t*)(g + gl.bin_entries),
                         (uint32_t*)(g + gl.bin_n));
   GS_CHECK_LAUNCH("count_tiles");
+  GS_KRANGE("scan_tiles");
   gs_launch_scan_tiles(stream, tl.T, (const uint32_t*)(t + tl.count), (uint32_t*)(t + tl.start), num_rendered,
                        (uint32_t*)(t + tl.order), (uint32_t*)(t + tl.meta), (uint32_t*)(t + tl.seg_first), (uint32_t*)(t + tl.part_first));
   GS_CHECK_LAUNCH("scan_tiles");
@@ -166,6 +203,7 @@ static int forward_stage2(void* stream_, int P, int W, int H, int64_t capacity, 
   const char* g = (const char*)geom;
   char* t = (char*)tiles;
   char* b = (char*)binning;
+  GS_KRANGE("binning");
   gs_launch_binning(stream, P, tl.T, tl.gx, (const float*)(g + gl.depth), (const uint2*)(g + gl.rect),
                     (const uint32_t*)(t + tl.start), (uint32_t*)(t + tl.cursor), (uint64_t*)(b + bl.keys),
                     (uint32_t*)(b + bl.list), cap, (const uint32_t*)(t + tl.order), (const uint32_t*)(g + gl.bin_entries),
@@ -173,6 +211,7 @@ static int forward_stage2(void* stream_, int P, int W, int H, int64_t capacity, 
   GS_CHECK_LAUNCH("binning");
   {
     ProfScope prof(train ? 0 : 2, stream);
+    GS_KRANGE("composite_fwd");
     gs_launch_composite_fwd(stream, tl.T, tl.gx, W, H, cap, (const uint32_t*)(t + tl.start), (const uint32_t*)(b + bl.list),
                             (const GsRec*)(g + gl.rec), bg, out_color, (float*)(t + tl.final_T), (uint32_t*)(t + tl.n_contrib),
                             (const uint32_t*)(t + tl.order), (const uint32_t*)(t + tl.seg_first), (const uint32_t*)(t + tl.part_first),
@@ -186,6 +225,7 @@ static int forward_stage2(void* stream_, int P, int W, int H, int64_t capacity, 
 
 int mi355gs_raster_forward_render(void* stream, int P, int W, int H, int64_t capacity, const float* bg, const void* geom,
                                   void* tiles, void* binning, float* out_color, int debug) {
+  GS_RANGE();
   return forward_stage2(stream, P, W, H, capacity, bg, geom, tiles, binning, out_color, debug, true);
 }
 
@@ -196,6 +236,7 @@ size_t mi355gs_raster_binning_bytes_render_only(int64_t n, int W, int H) {
 
 int mi355gs_raster_forward_render_only(void* stream, int P, int W, int H, int64_t capacity, const float* bg, const void* geom,
                                        void* tiles, void* binning, float* out_color, int debug) {
+  GS_RANGE();
   return forward_stage2(stream, P, W, H, capacity, bg, geom, tiles, binning, out_color, debug, false);
 }
 
@@ -207,6 +248,7 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                             const float* dL_dpix, void* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                             float* dL_dshs_rest, float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                             int grad_scratch_is_clear, int debug) {
+  GS_RANGE();
   (void)opacities; (void)colors_precomp;
   hipStream_t stream = (hipStream_t)stream_;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return MI355GS_EINVAL;
@@ -252,10 +294,12 @@ int mi355gs_raster_backward(void* stream_, int P, int D, int M, int W, int H, co
                               (const unsigned long long*)(b + bl.hitmask), bl.max_chunks, (const uint32_t*)(t + tl.qmax),
                               det ? nullptr : g_prof.work_counters, rowidx, rows);
     }
+    GS_KRANGE("composite_bwd");
     if (det) gs_launch_det_gather(stream, P, cap, det_scratch, rows, grads);
     GS_CHECK_LAUNCH("composite_bwd");
   }
   const CamParams cp = make_cam(viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier, W, H);
+  GS_KRANGE("preprocess_bwd");
   gs_launch_preprocess_bwd(stream, P, D, M, means3D, shs, shs_rest, scales, rotations, use_shs, use_cov, cp, radii,
                            (const GsRec*)(g + gl.rec), (const float*)(g + gl.cov3D), (const uint8_t*)(g + gl.clamped), grads, dL_dmeans3D, dL_dmeans2D,
                            dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D,
@@ -278,12 +322,14 @@ int mi355gs_tune_scale_grad(int mode) {
 }
 
 int mi355gs_raster_frame_stats(void* stream_, int W, int H, const void* tiles, int64_t* stats) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (W <= 0 || H <= 0 || !tiles || !stats) return MI355GS_EINVAL;
   const TilesLayout tl(W, H);
   const char* t = (const char*)tiles;
   if (hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), stream) != hipSuccess) return MI355GS_ELAUNCH;
+  GS_KRANGE("frame_stats");
   gs_launch_frame_stats(stream, tl.T, tl.gx, W, H, (const uint32_t*)(t + tl.start), (const uint32_t*)(t + tl.n_contrib), stats);
   GS_CHECK_LAUNCH("frame_stats");
   return MI355GS_OK;
@@ -325,12 +371,24 @@ int mi355gs_profile_end(void) {
   return MI355GS_OK;
 }
 
+int mi355gs_profile_ranges(int on) {
+  if (on == 1) {
+    if (!roctx_open()) return MI355GS_EINVAL;
+    g_ranges_on = true;
+  } else if (on == 0) {
+    g_ranges_on = false;
+  }
+  return (int)(g_roctx.pushed & 0x7fffffffull);
+}
+
 int mi355gs_raster_mark_visible(void* stream_, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                                 uint8_t* present) {
+  GS_RANGE();
   (void)projmatrix;
   const int debug = 0;
   void* stream = stream_;
   if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return MI355GS_EINVAL;
+  GS_KRANGE("mark_visible");
   gs_launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
   GS_CHECK_LAUNCH("mark_visible");
   return MI355GS_OK;

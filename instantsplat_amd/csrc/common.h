@@ -294,8 +294,11 @@ __device__ __forceinline__ uint32_t gs_physical_cu() {
   return ((xcc & 7u) << 6) | (((hw >> 13) & 3u) << 4) | ((hw >> 8) & 15u);
 }
 
+extern thread_local bool g_krange_open;
+void gs_range_pop();
 #define GS_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \
+    if (g_krange_open) { g_krange_open = false; gs_range_pop(); }               \
     hipError_t e_ = hipGetLastError();                                          \
     if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize((hipStream_t)stream); \
     if (e_ != hipSuccess) {                                                     \
@@ -305,6 +308,22 @@ __device__ __forceinline__ uint32_t gs_physical_cu() {
   } while (0)
 
 void gs_log_error(const char* where, const char* what);
+
+// roctx range around an entry point's launches (mi355gs_profile_ranges, api.hip): one predictable branch when off
+extern bool g_ranges_on;
+void gs_range_push(const char* name);
+void gs_range_pop();
+struct GsRange {
+  bool active;
+  explicit GsRange(const char* name) : active(g_ranges_on) { if (active) gs_range_push(name); }
+  ~GsRange() { if (active) gs_range_pop(); }
+  GsRange(const GsRange&) = delete;
+  GsRange& operator=(const GsRange&) = delete;
+};
+#define GS_RANGE() GsRange gs_range_(__func__)
+// ... and around ONE launch: GS_KRANGE("name") in front of it, popped by the GS_CHECK_LAUNCH("name") behind it
+extern thread_local bool g_krange_open;
+#define GS_KRANGE(name) do { if (g_ranges_on) { gs_range_push(name); g_krange_open = true; } } while (0)
 
 // Optional in-library kernel timing (mi355gs_profile_*, api.hip): an event pair around the launches made in its scope, on the
 // launch stream, when profiling is on and it is this launch's turn.  kind: include/mi355gs.h mi355gs_profile_read.

@@ -115,16 +115,6 @@ __device__ __forceinline__ float gs_power2(float dx, float dy, float A, float C,
   const float sum = sx + sy;
   return fmaf(B * dx, dy, sum);
 }
-// The same for a lane's two horizontally adjacent pixels (dx, dx - 8; one dy) with the squares, their sum and B dx as packed
-// FP32 — the same roundings in the same order, so both elements are the forward's bits (GS_BW_PAIR experiment below).
-__device__ __forceinline__ gs_v2f gs_power2_pair(gs_v2f dx, float dy, float A, float C, float B) {
-#pragma clang fp contract(off)
-  const gs_v2f sx = (dx * A) * dx;
-  const float sy = (dy * C) * dy;
-  const gs_v2f sum = sx + sy;
-  const gs_v2f bdx = dx * B;
-  return gs_v2f{fmaf(bdx[0], dy, sum[0]), fmaf(bdx[1], dy, sum[1])};
-}
 
 // ------------------------------------------------------------------------------------------------
 // K6 forward.  Workgroup = one 16x16 tile (heaviest tiles first), wave = one 8x8 pixel quadrant of it — and the four waves
@@ -380,35 +370,6 @@ constexpr bool BW_REDUCE_LDS = GS_BW_LDS != 0;
 // 15 adds, two quad_perm steps and lanes 0, 4, .., 32 hold the nine sums.  The LDS crossbar moves the data on its own pipe;
 // the VALU is left with the additions (~40 issue cycles instead of ~128 for the register-transposed form).
 constexpr int RED_PITCH = 68;
-// The nine stores of a step (row c, column = lane <- moment c).  A ds_write_b32 occupies the VGPR -> LDS transfer path for 4
-// cycles (address + data dword at 2 cycles each, MI355X_MICROARCH.md, LDS) and the path is shared by the CU's four SIMDs: 36 of
-// the ~60 LDS cycles of a step, on a pipe the counters put at 0.85 busy.  ds_write_addtid_b32 takes its address from
-// M0 + offset + 4 * lane — no address VGPR — and 2 cycles: GS_BW_ADDTID = 1 issues the nine stores in that form (the wave is
-// the whole workgroup, so "lane" is the hardware's thread index; M0 is not otherwise used by this kernel — checked in the
-// compiler's output).  Under the SIMT emulator (g++, no AMDGCN target) the same stores are the plain ones.
-#ifndef GS_BW_ADDTID
-#define GS_BW_ADDTID 0
-#endif
-__device__ __forceinline__ void gs_store_rows9(float* __restrict__ red, int lane, float m0, float m1, float m2, float m3, float m4,
-                                               float m5, float m6, float m7, float m8) {
-#if defined(__AMDGCN__) && GS_BW_ADDTID
-  // (ds_write_addtid_b32 adds the thread's index: the kernel asserts one wave per workgroup)
-  const uint32_t lds = (uint32_t)(uintptr_t)red;   // the low half of a flat LDS address is the LDS offset
-  asm volatile("s_mov_b32 m0, %9\n\t"
-               "ds_write_addtid_b32 %0 offset:%10\n\tds_write_addtid_b32 %1 offset:%11\n\tds_write_addtid_b32 %2 offset:%12\n\t"
-               "ds_write_addtid_b32 %3 offset:%13\n\tds_write_addtid_b32 %4 offset:%14\n\tds_write_addtid_b32 %5 offset:%15\n\t"
-               "ds_write_addtid_b32 %6 offset:%16\n\tds_write_addtid_b32 %7 offset:%17\n\tds_write_addtid_b32 %8 offset:%18"
-               :: "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7), "v"(m8), "s"(lds),
-                  "i"(0 * RED_PITCH * 4), "i"(1 * RED_PITCH * 4), "i"(2 * RED_PITCH * 4), "i"(3 * RED_PITCH * 4), "i"(4 * RED_PITCH * 4),
-                  "i"(5 * RED_PITCH * 4), "i"(6 * RED_PITCH * 4), "i"(7 * RED_PITCH * 4), "i"(8 * RED_PITCH * 4)
-               : "m0", "memory");
-  (void)lane;
-#else
-  red[0 * RED_PITCH + lane] = m0; red[1 * RED_PITCH + lane] = m1; red[2 * RED_PITCH + lane] = m2;
-  red[3 * RED_PITCH + lane] = m3; red[4 * RED_PITCH + lane] = m4; red[5 * RED_PITCH + lane] = m5;
-  red[6 * RED_PITCH + lane] = m6; red[7 * RED_PITCH + lane] = m7; red[8 * RED_PITCH + lane] = m8;
-#endif
-}
 // GS_BW_HALF: every 64-instance unit of the one-chunk instantiation is replayed by TWO waves that never meet: the BACK half of
 // the unit (instances 32..63) back to front from the unit's far boundary record, exactly as before, and the FRONT half
 // (instances 0..31) FRONT TO BACK from the near boundary record (= the previous unit's far record; T = 1, C = 0 for a tile's
@@ -420,15 +381,6 @@ __device__ __forceinline__ void gs_store_rows9(float* __restrict__ red, int lane
 #ifndef GS_BW_HALF
 #define GS_BW_HALF 0
 #endif
-// GS_BW_PAIR (built and measured in round 6 — profiles/r06_ab_bwd_packed_pairs.txt): the bodies of two
-// horizontally adjacent quadrants as ONE body in packed FP32.  The lane's two pixels share dy and their dx differ by 8; the
-// squares, the moments and every multiply-add run as v_pk_mul / v_pk_add / v_pk_fma on (left, right) register pairs; exp2, rcp,
-// med3, the compares and the selects do not pack and run once per element.  A pair body runs when EITHER quadrant's mask names
-// the record (the other element is then an invalid lane: alpha 0, a no-op for its state).
-#ifndef GS_BW_PAIR
-#define GS_BW_PAIR 0
-#endif
-constexpr bool BW_PAIR = GS_BW_PAIR != 0;
 constexpr int BW_UNITS = 1;  // units (waves) per workgroup: single-wave workgroups give the dispatcher the finest grain (129.4 -> 128.2 us at C3 against 4)
 
 // CHUNKS: 64-instance chunks per unit (1, or 0 = the frame's own value from meta[2] for the longer units of big frames; the
@@ -557,16 +509,6 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
     }
   }
 
-  // GS_BW_PAIR: the replay state of the lane's four pixels as two (left, right) pairs
-  [[maybe_unused]] gs_v2f TrP[2], behindP[2], G0P[2], G1P[2], G2P[2];
-  if constexpr (BW_PAIR) {
-    static_assert(!BW_PAIR || !HALVES, "the pair bodies are written for the back-to-front replay");
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      TrP[pr] = gs_v2f{Tr[2 * pr], Tr[2 * pr + 1]}; behindP[pr] = gs_v2f{behind[2 * pr], behind[2 * pr + 1]};
-      G0P[pr] = gs_v2f{g0[2 * pr], g0[2 * pr + 1]}; G1P[pr] = gs_v2f{g1[2 * pr], g1[2 * pr + 1]}; G2P[pr] = gs_v2f{g2[2 * pr], g2[2 * pr + 1]};
-    }
-  }
   typedef float v4f __attribute__((vector_size(16)));
   [[maybe_unused]] float sel[9];   // BW_REDUCE_MFMA: the B operands "column c"
   if constexpr (BW_REDUCE_MFMA) {
@@ -587,46 +529,6 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
     const float dx0 = a0.x - fx0, dy0 = a0.y - fy0;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m7 = 0.f, m8 = 0.f;
     bool any_valid = false;
-    if constexpr (BW_PAIR) {
-      gs_v2f M0 = {0.f, 0.f}, M1 = M0, M2 = M0, M3 = M0, M4 = M0, M5 = M0, M6 = M0, M7 = M0, M8 = M0;
-      const gs_v2f dx = gs_v2f{dx0, dx0 - 8.f};
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const bool hL = (mq[2 * pr] >> i2) & 1ull, hR = (mq[2 * pr + 1] >> i2) & 1ull;   // wave-uniform: scalar bit tests
-        if (hL || hR) {
-          const float dy = pr ? dy0 - 8.f : dy0;
-          const gs_v2f p2 = gs_power2_pair(dx, dy, a1.x, a1.y, a1.z);
-          const gs_v2f au = gs_v2f{gs_exp2(p2[0]), gs_exp2(p2[1])} * a1.w;
-          // a quadrant the forward's cull did not name is skipped whatever its pixels' alphas round to (the forward skipped it)
-          const bool vL = hL && (int)cb + i2 < lastq[2 * pr] && p2[0] <= 0.0f && au[0] >= ALPHA_MIN;
-          const bool vR = hR && (int)cb + i2 < lastq[2 * pr + 1] && p2[1] <= 0.0f && au[1] >= ALPHA_MIN;
-          if constexpr (COUNT) { c_quads += 2; c_lanes += __popcll(__ballot(vL)) + __popcll(__ballot(vR)); }
-          if (__any(vL || vR)) {
-            any_valid = true;
-            if constexpr (COUNT) c_quads_valid += 2;
-            const gs_v2f av = gs_v2f{vL ? au[0] : 0.f, vR ? au[1] : 0.f};
-            const gs_v2f al = gs_v2f{__builtin_amdgcn_fmed3f(av[0], 0.0f, 0.99f), __builtin_amdgcn_fmed3f(av[1], 0.0f, 0.99f)};
-            const gs_v2f one_m = 1.f - al;
-            const gs_v2f inv_one_m = gs_v2f{gs_rcp(one_m[0]), gs_rcp(one_m[1])};
-            const gs_v2f cg = gs_fma2(G2P[pr], gs_v2f{a2.z, a2.z}, gs_fma2(G1P[pr], gs_v2f{a2.y, a2.y}, G0P[pr] * a2.x));
-            TrP[pr] = TrP[pr] * inv_one_m;
-            const gs_v2f dL_dalpha = TrP[pr] * cg - behindP[pr] * inv_one_m;
-            const gs_v2f dchannel = al * TrP[pr];
-            behindP[pr] = gs_fma2(cg, dchannel, behindP[pr]);
-            const gs_v2f w = av * dL_dalpha;
-            const gs_v2f wdx = w * dx, wdy = w * dy;
-            M0 += wdx; M1 += wdy;
-            M2 = gs_fma2(wdx, dx, M2); M3 = gs_fma2(wdx, gs_v2f{dy, dy}, M3); M4 = gs_fma2(wdy, gs_v2f{dy, dy}, M4);
-            M5 += w;
-            M6 = gs_fma2(dchannel, G0P[pr], M6); M7 = gs_fma2(dchannel, G1P[pr], M7); M8 = gs_fma2(dchannel, G2P[pr], M8);
-          }
-        }
-      }
-      if (any_valid) {
-        m0 = M0[0] + M0[1]; m1 = M1[0] + M1[1]; m2 = M2[0] + M2[1]; m3 = M3[0] + M3[1]; m4 = M4[0] + M4[1];
-        m5 = M5[0] + M5[1]; m6 = M6[0] + M6[1]; m7 = M7[0] + M7[1]; m8 = M8[0] + M8[1];
-      }
-    } else
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       if ((mq[qd] >> i2) & 1ull) {   // wave-uniform: scalar bit test
@@ -690,7 +592,9 @@ __global__ GS_BW_BOUNDS void k_composite_bwd(int gx, int W, int H, uint32_t capa
         // (LDS operations of one wave execute in program order: the reads below see this step's writes, and the next step's
         // writes come after these reads — no barrier; the fences keep the compiler from reordering across lanes' accesses)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        gs_store_rows9(red, lane, m0, m1, m2, m3, m4, m5, m6, m7, m8);
+        red[0 * RED_PITCH + lane] = m0; red[1 * RED_PITCH + lane] = m1; red[2 * RED_PITCH + lane] = m2;
+        red[3 * RED_PITCH + lane] = m3; red[4 * RED_PITCH + lane] = m4; red[5 * RED_PITCH + lane] = m5;
+        red[6 * RED_PITCH + lane] = m6; red[7 * RED_PITCH + lane] = m7; red[8 * RED_PITCH + lane] = m8;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -183,6 +183,7 @@ extern "C" {
 size_t mi355gs_knn_scratch_bytes(int N) { return KnnLayout(N).total + 256; }
 
 int mi355gs_knn_dist2(void* stream_, int N, const float* points, float* mean_dist2, void* scratch) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (N < 0 || (N > 0 && (!points || !mean_dist2 || !scratch))) return MI355GS_EINVAL;
@@ -201,18 +202,23 @@ int mi355gs_knn_dist2(void* stream_, int N, const float* points, float* mean_dis
     hipLaunchKernelGGL(k_knn_bbox, dim3(bbox_blocks), dim3(1024), 0, stream, N, points, (float*)sorted);
     hipLaunchKernelGGL(k_knn_bbox, dim3(1), dim3(1024), 0, stream, 2 * bbox_blocks, (const float*)sorted, bbox);
   } else {
+    GS_KRANGE("knn_bbox");
     hipLaunchKernelGGL(k_knn_bbox, dim3(1), dim3(1024), 0, stream, N, points, bbox);
   }
   GS_CHECK_LAUNCH("knn_bbox");
   const int blocks = (N + 255) / 256;
+  GS_KRANGE("knn_count");
   hipLaunchKernelGGL(k_knn_count, dim3(blocks), dim3(256), 0, stream, N, L.G, points, (const float*)bbox, count);
   GS_CHECK_LAUNCH("knn_count");
   // exclusive scan over the cell table (cells that the tight per-axis grid does not use stay 0)
+  GS_KRANGE("knn_scan");
   gs_launch_scan_large(stream, cells + 1, count, start, (uint32_t*)(w + L.block_sums), (int32_t*)(w + L.total));
   GS_CHECK_LAUNCH("knn_scan");
+  GS_KRANGE("knn_scatter");
   hipLaunchKernelGGL(k_knn_scatter, dim3(blocks), dim3(256), 0, stream, N, L.G, points, (const float*)bbox, (const uint32_t*)start,
                      cursor, sorted);
   GS_CHECK_LAUNCH("knn_scatter");
+  GS_KRANGE("knn_query");
   hipLaunchKernelGGL(k_knn_query, dim3(blocks), dim3(256), 0, stream, N, L.G, (const float*)bbox, (const uint32_t*)start,
                      (const float4*)sorted, mean_dist2);
   GS_CHECK_LAUNCH("knn_query");

@@ -187,12 +187,14 @@ extern "C" {
 int mi355gs_pose_forward(void* stream_, int P, const float* xyz, const float* rot, const float* scaling,
                          const float* opacity_logit, const float* pose, float* means_cam, float* rot_cam, float* scales,
                          float* opac) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (P < 0 || !pose) return MI355GS_EINVAL;
   if (P == 0) return MI355GS_OK;
   if (!xyz || !rot || !scaling || !opacity_logit || !means_cam || !rot_cam || !scales || !opac) return MI355GS_EINVAL;
   const int blocks = min((P + 255) / 256, 4096);
+  GS_KRANGE("pose_fwd");
   hipLaunchKernelGGL(k_pose_fwd, dim3(blocks), dim3(256), 0, stream, P, xyz, rot, scaling, opacity_logit, pose, means_cam, rot_cam,
                      scales, opac, g_fused.prologue);
   GS_CHECK_LAUNCH("pose_fwd");
@@ -203,6 +205,7 @@ int mi355gs_pose_backward(void* stream_, int P, const float* xyz, const float* r
                           const float* pose, const float* g_means, const float* g_rot, const float* g_scales,
                           const float* g_opac, float* d_xyz, float* d_rot, float* d_scaling, float* d_opacity_logit,
                           float* d_pose, float* scratch16) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (P < 0 || !pose || !d_pose || !scratch16) return MI355GS_EINVAL;
@@ -213,12 +216,14 @@ int mi355gs_pose_backward(void* stream_, int P, const float* xyz, const float* r
         !d_opacity_logit)
       return MI355GS_EINVAL;
     const int blocks = min((P + 255) / 256, 1024);
+    GS_KRANGE("pose_bwd");
     hipLaunchKernelGGL(k_pose_bwd, dim3(blocks), dim3(256), 0, stream, P, xyz, rot, scales, opac, pose, g_means, g_rot, g_scales,
                        g_opac, d_xyz, d_rot, d_scaling, d_opacity_logit, scratch16, g_fused.gate, g_fused.gate_xyz, g_fused.gate_rot,
                        g_fused.gate_scaling, g_fused.gate_opacity);
     GS_CHECK_LAUNCH("pose_bwd");
   }
   // (folding this into k_pose_bwd's last workgroup was measured: the ticket round trips cost more than the launch)
+  GS_KRANGE("pose_finish");
   hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, stream, pose, (const float*)scratch16, d_pose, pose_gate);
   GS_CHECK_LAUNCH("pose_finish");
   return MI355GS_OK;

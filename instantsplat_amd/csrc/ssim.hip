@@ -645,6 +645,7 @@ size_t mi355gs_ssim_scratch_bytes(int B, int C, int H, int W) {
 
 int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, float* dm_dmu1,
                          float* dm_dsigma1_sq, float* dm_dsigma12, void* scratch, float* ssim_mean, float* l1_mean, int padding_valid) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch) return MI355GS_EINVAL;
@@ -653,11 +654,13 @@ int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float*
   if ((dm_dmu1 == nullptr) != (dm_dsigma1_sq == nullptr) || (dm_dmu1 == nullptr) != (dm_dsigma12 == nullptr)) return MI355GS_EINVAL;
   if ((size_t)B * C > 65535) return MI355GS_EINVAL;
   const dim3 grid((W + TSX - 1) / TSX, (H + TS - 1) / TS, B * C);
+  GS_KRANGE("ssim_fwd");
   hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(TS, TS), 0, stream, H, W, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)scratch, crop);
   GS_CHECK_LAUNCH("ssim_fwd");
   // one finishing launch normalises both sums by the same count: with "valid" padding that is the cropped map's, so the L1
   // mean (a "same"-padding quantity of the training loss) is only offered with padding_valid == 0
   const double inv_n = 1.0 / ((double)B * C * (H - 2 * crop) * (W - 2 * crop));
+  GS_KRANGE("ssim_finish");
   hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, ssim_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
                      l1_mean, (float*)nullptr, 0.f);
   GS_CHECK_LAUNCH("ssim_finish");
@@ -667,6 +670,7 @@ int mi355gs_ssim_forward(void* stream_, int B, int C, int H, int W, const float*
 int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
                           const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* ssim_grad_scale,
                           const float* l1_grad_scale, float* dL_dimg1, int padding_valid) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dL_dimg1) return MI355GS_EINVAL;
@@ -677,6 +681,7 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
   if (padding_valid && (l1_grad_scale || H <= 2 * HALO || W <= 2 * HALO)) return MI355GS_EINVAL;
   // the forward zeroed the saved partials outside the counted region, so the same kernel serves both paddings
   const float inv_n = (float)(1.0 / ((double)B * C * (H - 2 * crop) * (W - 2 * crop)));
+  GS_KRANGE("ssim_bwd");
   hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(TS, TS), 0, stream, H, W, inv_n, img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
                      ssim_grad_scale, l1_grad_scale, ssim_grad_scale ? 1.f : 0.f, l1_grad_scale ? 1.f : 0.f, dL_dimg1);
   GS_CHECK_LAUNCH("ssim_bwd");
@@ -686,11 +691,14 @@ int mi355gs_ssim_backward(void* stream_, int B, int C, int H, int W, const float
 size_t mi355gs_l1_scratch_bytes(int64_t n) { return gs_align((size_t)(n > 0 ? l1_nblocks(n) : 1) * 2 * sizeof(float)); }
 
 int mi355gs_l1_loss_forward(void* stream_, int64_t n, const float* a, const float* b, void* scratch, float* mean_out) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (n <= 0 || n > (int64_t)1 << 40 || !a || !b || !scratch || !mean_out) return MI355GS_EINVAL;
+  GS_KRANGE("l1_partial");
   hipLaunchKernelGGL(k_l1_partial, dim3(l1_nblocks(n)), dim3(L1_THREADS), 0, stream, (long long)n, a, b, (float*)scratch);
   GS_CHECK_LAUNCH("l1_partial");
+  GS_KRANGE("l1_finish");
   hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, l1_nblocks(n), 1.0 / (double)n, (const float*)scratch, mean_out,
                      (float*)nullptr, (float*)nullptr, 0.f);
   GS_CHECK_LAUNCH("l1_finish");
@@ -698,9 +706,11 @@ int mi355gs_l1_loss_forward(void* stream_, int64_t n, const float* a, const floa
 }
 
 int mi355gs_l1_loss_backward(void* stream_, int64_t n, const float* a, const float* b, const float* grad_scale, float* d_a) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (n <= 0 || n > (int64_t)1 << 40 || !a || !b || !grad_scale || !d_a) return MI355GS_EINVAL;
+  GS_KRANGE("l1_bwd");
   hipLaunchKernelGGL(k_l1_bwd, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, (long long)n, a, b, grad_scale, (float)n, d_a);
   GS_CHECK_LAUNCH("l1_bwd");
   return MI355GS_OK;
@@ -712,6 +722,7 @@ static inline int fused_nblocks(int B, int C, int H, int W) { return B * C * ((H
 // the gradient and its backward only scales it by the incoming dL/dloss.
 int mi355gs_l1_ssim_loss_fused(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
                                float lambda_dssim, float* ssim_mean, float* l1_mean, float* loss, float* dloss_dimg1) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !loss || !dloss_dimg1) return MI355GS_EINVAL;
@@ -720,10 +731,12 @@ int mi355gs_l1_ssim_loss_fused(void* stream_, int B, int C, int H, int W, const 
   const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, B * C);
   {
     GsProfScope prof(3, stream);
+    GS_KRANGE("l1_ssim_fused");
     hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
                        (float)((1.0 - (double)lambda_dssim) * inv_n), dloss_dimg1, (float*)scratch);
   }
   GS_CHECK_LAUNCH("l1_ssim_fused");
+  GS_KRANGE("ssim_finish");
   hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, stream, fused_nblocks(B, C, H, W), inv_n, (const float*)scratch, ssim_mean,
                      l1_mean, loss, lambda_dssim);
   GS_CHECK_LAUNCH("ssim_finish");
@@ -732,6 +745,7 @@ int mi355gs_l1_ssim_loss_fused(void* stream_, int B, int C, int H, int W, const 
 
 int mi355gs_l1_ssim_pair_forward(void* stream_, int B, int C, int H, int W, const float* img1, const float* img2, void* scratch,
                                  float* dssim_dimg1) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !scratch || !dssim_dimg1) return MI355GS_EINVAL;
@@ -740,6 +754,7 @@ int mi355gs_l1_ssim_pair_forward(void* stream_, int B, int C, int H, int W, cons
   const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, B * C);
   {
     GsProfScope prof(3, stream);
+    GS_KRANGE("l1_ssim_pair");
     hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)inv_n, 0.0f, dssim_dimg1, (float*)scratch);
   }
   GS_CHECK_LAUNCH("l1_ssim_pair");
@@ -748,10 +763,12 @@ int mi355gs_l1_ssim_pair_forward(void* stream_, int B, int C, int H, int W, cons
 
 int mi355gs_l1_ssim_pair_backward(void* stream_, int64_t n, const float* img1, const float* img2, const float* dssim_dimg1,
                                   const float* g_l1, float c_l1, const float* g_ssim, float c_ssim, float* d_img1) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (n <= 0 || n > (int64_t)1 << 40 || !img1 || !img2 || !d_img1) return MI355GS_EINVAL;
   if (c_ssim != 0.0f && !dssim_dimg1) return MI355GS_EINVAL;
+  GS_KRANGE("loss_pair_bwd");
   hipLaunchKernelGGL(k_loss_pair_bwd, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, (long long)n, img1, img2, dssim_dimg1, g_l1,
                      c_l1, g_ssim, c_ssim, (float)n, d_img1);
   GS_CHECK_LAUNCH("loss_pair_bwd");
@@ -777,12 +794,14 @@ static int build_loss_program(int n_ops, const int32_t* ops, const float* consts
 
 int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
                               const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (!scratch || !l1_mean || !ssim_mean || !out) return MI355GS_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ((uintptr_t)host_out & 7) != 0) return MI355GS_EINVAL;
   GsLossProgram p;
   if (build_loss_program(n_ops, ops, consts, p) != MI355GS_OK) return MI355GS_EINVAL;
+  GS_KRANGE("loss_program");
   hipLaunchKernelGGL(k_loss_program, dim3(1), dim3(1024), 0, stream, p, fused_nblocks(B, C, H, W), 1.0 / ((double)B * C * H * W),
                      (const float*)scratch, ssim_mean, l1_mean, out, host_out, ticket);
   GS_CHECK_LAUNCH("loss_program");
@@ -792,6 +811,7 @@ int mi355gs_loss_program_eval(void* stream_, int n_ops, const int32_t* ops, cons
 int mi355gs_loss_program_eval_grad(void* stream_, int n_ops, const int32_t* ops, const float* consts, int B, int C, int H, int W,
                                    const void* scratch, float* ssim_mean, float* l1_mean, float* out, float* host_out, float ticket,
                                    const float* img1, const float* img2, const float* dssim_dimg1, float c_l1, float c_ssim, float* d_img1) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
   if (!scratch || !l1_mean || !ssim_mean || !out || !img1 || !img2 || !d_img1) return MI355GS_EINVAL;
@@ -800,6 +820,7 @@ int mi355gs_loss_program_eval_grad(void* stream_, int n_ops, const int32_t* ops,
   GsLossProgram p;
   if (build_loss_program(n_ops, ops, consts, p) != MI355GS_OK) return MI355GS_EINVAL;
   const long long n = (long long)B * C * H * W;
+  GS_KRANGE("loss_program_grad");
   hipLaunchKernelGGL(k_loss_program_grad, dim3(1u + (unsigned)((n + 4095) / 4096)), dim3(1024), 0, stream, p, fused_nblocks(B, C, H, W),
                      1.0 / (double)n, (const float*)scratch, ssim_mean, l1_mean, out, host_out, ticket, n, img1, img2, dssim_dimg1, c_l1, c_ssim,
                      (float)n, d_img1);
@@ -818,6 +839,7 @@ int gs_loss_fused(hipStream_t stream, int C, int H, int W, const float* img1, co
   const dim3 grid((W + FT - 1) / FT, (H + FT - 1) / FT, C);
   {
     GsProfScope prof(3, stream);
+    GS_KRANGE("l1_ssim_fused");
     hipLaunchKernelGGL(k_l1_ssim_fused, grid, dim3(FTHREADS), 0, stream, H, W, img1, img2, (float)(-(double)lambda_dssim * inv_n),
                        (float)((1.0 - (double)lambda_dssim) * inv_n), dL_dimg1, (float*)scratch);
   }

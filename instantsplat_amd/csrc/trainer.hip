@@ -113,6 +113,7 @@ int mi355gs_posed_forward_preprocess(void* stream, int P, int D, int W, int H, c
                                      const float* rotation, const float* pose, const float* view_identity, const float* projmatrix,
                                      const float* origin, float tanfovx, float tanfovy, int32_t* radii, void* geom, void* tiles,
                                      int32_t* num_rendered, uint8_t* visible, void* grad_scratch, int debug) {
+  GS_RANGE();
   if (!pose || D < 0 || D > 3 || (D > 0 && !f_rest)) return MI355GS_EINVAL;
   struct Scope { ~Scope() { g_fused = GsFusedStepHooks(); } } scope;
   g_fused.posed.pose = pose;
@@ -129,6 +130,7 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
                            void* grad_scratch, float* pose_scratch, float* d_xyz, float* d_means2D, float* d_f_dc, float* d_f_rest,
                            float* d_opacity_logit, float* d_log_scales, float* d_rotation, float* d_pose, int pose_rows, int pose_row,
                            int grad_scratch_is_clear, int debug) {
+  GS_RANGE();
   hipStream_t stream = (hipStream_t)stream_;
   if (!pose || !pose_scratch || !d_pose || D < 0 || D > 3 || (D > 0 && (!f_rest || !d_f_rest))) return MI355GS_EINVAL;
   if (pose_rows < 0 || (pose_rows > 0 && (pose_row < 0 || pose_row >= pose_rows))) return MI355GS_EINVAL;
@@ -152,6 +154,7 @@ int mi355gs_posed_backward(void* stream_, int P, int D, int W, int H, const floa
                                  grad_scratch_is_clear, debug);
   }
   if (rc) return rc;
+  GS_KRANGE("pose_finish");
   gs_launch_pose_finish_partials(stream, pose, pose_scratch, rows, d_pose, gate + 6, nullptr, 0, 0.0, 0.f, nullptr, pose_rows, pose_row);
   GS_CHECK_LAUNCH("pose_finish");
   return MI355GS_OK;
@@ -198,6 +201,7 @@ const float* mi355gs_trainer_grad(void* handle, int k) {
 int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, const float* gt_image, const float* projmatrix,
                          float tanfovx, float tanfovy, const float* bg, const float* lr, const int32_t* step, float beta1, float beta2, float eps,
                          float lambda_dssim, int do_optimizer_step, float* loss_out, int32_t* num_rendered_out) {
+  GS_RANGE();
   Trainer* t = (Trainer*)handle;
   hipStream_t stream = (hipStream_t)stream_;
   const int debug = 0;
@@ -205,6 +209,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
     return MI355GS_EINVAL;
   const int P = t->P, W = t->W, H = t->H;
   if (!t->consts_ready) {
+    GS_KRANGE("trainer_consts");
     hipLaunchKernelGGL(k_trainer_consts, dim3(1), dim3(64), 0, stream, t->consts);
     GS_CHECK_LAUNCH("trainer_consts");
     // at SH degree 0 f_rest receives no gradient: its (all-zero) gradient buffer is written once here and first
@@ -255,6 +260,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
                                     t->capacity, t->radii, t->image, t->dL_dimg, t->grad_scratch, t->g_xyz, t->g_means2D, t->g_fdc,
                                     g_rest, t->g_colors, t->g_opacity, t->g_scaling, t->g_rot, nullptr, 0, 0)))
     return rc;
+  GS_KRANGE("pose_finish");
   gs_launch_pose_finish_partials(stream, pose, t->pose_partial, (P + 255) / 256, t->g_poses + 7 * (size_t)view, t->adam_scratch + 6,
                                  (const float*)t->ssim_scratch, gs_loss_fused_nblocks(3, H, W), 1.0 / (3.0 * H * W), lambda_dssim, loss_out, 0, 0);
   GS_CHECK_LAUNCH("pose_finish");
@@ -265,6 +271,7 @@ int mi355gs_trainer_step(void* handle, void* stream_, int view, int sh_degree, c
 
 int mi355gs_trainer_optimizer_step(void* handle, void* stream_, const float* lr, const int32_t* step, float beta1, float beta2,
                                    float eps, int commit_gate) {
+  GS_RANGE();
   Trainer* t = (Trainer*)handle;
   if (!t || !lr || !step || !t->consts_ready) return MI355GS_EINVAL;  // needs the gradients of a preceding step
   // gate flags of the gradients produced by the preceding mi355gs_trainer_step(..., do_optimizer_step = 0) are still in place

@@ -157,7 +157,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.mi355gs_abi_version.restype = ctypes.c_int
-    assert lib.mi355gs_abi_version() == 9
+    assert lib.mi355gs_abi_version() == 10
 
 
 def test_product_path_refuses_cpu_tensors_and_missing_library(monkeypatch):
@@ -294,6 +294,36 @@ def test_new_entry_points_reject_bad_arguments():
     finally:
         L.mi355gs_tune_deterministic(0)
     assert det_bytes >= L.mi355gs_raster_binning_bytes(1000, 64, 64) + 52 * 1000
+
+
+def test_roctx_ranges_bracket_every_stage_of_a_train_step(emu):
+    """ABI v10: with mi355gs_profile_ranges(1) every launching entry point pushes a roctx range
+    named after itself — one one-call train step = mi355gs_trainer_step with the projection / binning, composite forward, loss,
+    backward and optimizer entry points nested inside it — and with (0) nothing is pushed.  The marker library is opened at run
+    time; a box without one (no ROCm install) refuses to switch on and everything else works."""
+    from instantsplat_amd import _lib
+    from instantsplat_amd.arguments import OptimizationParams
+    from instantsplat_amd.synthetic import syn_pointmap
+    from instantsplat_amd.train import release_trainer, setup_training, train_iteration
+    L = _lib.lib()
+    st = setup_training(syn_pointmap(3, 8, 8, 24, 24, seed=2), emu, opt=OptimizationParams(iterations=100, pp_optimizer=True, optim_pose=True))
+    train_iteration(st, fused_step=True)        # (creates the trainer handle: its exact-count renders are not the step's launches)
+    before = L.mi355gs_profile_ranges(-1)
+    train_iteration(st, fused_step=True)
+    assert L.mi355gs_profile_ranges(-1) == before                  # off: not a single push
+    rc = L.mi355gs_profile_ranges(1)
+    if rc < 0:
+        release_trainer(st)
+        pytest.skip("no roctx library can be opened on this box")
+    try:
+        train_iteration(st, fused_step=True)
+        # trainer_step { forward_preprocess, forward_render, l1_ssim_loss_fused, raster_backward } + trainer_optimizer_step { adam_multi_step }
+        assert L.mi355gs_profile_ranges(-1) - before >= 6 + 10, L.mi355gs_profile_ranges(-1) - before   # 6 entry points + 10 launch sites (scatter + sort share one)
+    finally:
+        after = L.mi355gs_profile_ranges(0)
+        release_trainer(st)
+    train_iteration(st, fused_loss=False)
+    assert L.mi355gs_profile_ranges(-1) == after
 
 
 def test_render_only_forward_is_bit_identical(emu):
