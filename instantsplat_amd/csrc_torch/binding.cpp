@@ -318,6 +318,20 @@ struct PoseRowFn : public torch::autograd::Function<PoseRowFn> {
 
 Tensor pose_row(Tensor table, int64_t index) { return PoseRowFn::apply(table, index); }
 
+// The deterministic-backward mode (mi355gs_tune_deterministic) is process-wide and enters the layout of `binning` and the size
+// of the gradient scratch.  A frame must see the SAME mode in its backward as in its forward: switched on in between (a retained
+// graph, a frame in flight, a second thread), the backward would write per-instance rows past the end of buffers laid out
+// without them.  The sizes say so: checked on the host before anything is enqueued.
+void check_frame_buffers(const Tensor& binning, const Tensor& scratch, int64_t R, int P, int W, int H) {
+  const size_t need_b = g_abi.binning_bytes(R, W, H), need_s = g_abi.grad_scratch_bytes(P);
+  TORCH_CHECK(!binning.defined() || (size_t)binning.numel() >= need_b || R <= 0,
+              "mi355gs: this frame's binning buffer (", binning.numel(), " bytes) is smaller than the backward's layout needs (", need_b,
+              "): the deterministic-backward mode was switched on between the frame's forward and its backward");
+  TORCH_CHECK(!scratch.defined() || (size_t)scratch.numel() >= need_s,
+              "mi355gs: this frame's gradient scratch (", scratch.numel(), " bytes) is smaller than the backward needs (", need_s,
+              "): the deterministic-backward mode was switched on between the frame's forward and its backward");
+}
+
 // ------------------------------------------------------------------------------------------------
 // render()'s differentiable body: raw GaussianModel tensors + the 7-vector camera pose in, image out
 // (reference gaussian_renderer/__init__.py:81-135; the Python twin is instantsplat_amd/fused.py::_RenderPosed)
@@ -448,6 +462,7 @@ struct RenderPosedFn : public torch::autograd::Function<RenderPosedFn> {
     ctx->saved_data["scratch_is_clear"] = false;
     if (!scratch.defined()) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), xyz);
     Tensor pose_scratch = at::empty({16 * (((int64_t)P + 255) / 256) + 32}, xyz.options());
+    check_frame_buffers(binning, scratch, R, P, W, H);
     check(g_abi.posed_backward(dev.stream, P, D, W, H, fp(bg), fp(xyz), fp(f_dc), fp(f_rest), fp(opl), fp(scaling), (float)sc[2], fp(rot),
                                fp(pose), fp(view), fp(proj), fp(origin), (float)sc[0], (float)sc[1], geom.data_ptr(), tiles.data_ptr(),
                                binning.data_ptr(), R, radii.data_ptr<int32_t>(), fp(color), fp(g), scratch.data_ptr(), fp(pose_scratch),
@@ -501,6 +516,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t D, bool prefiltered,
                                int64_t capacity, int64_t count_hint, Tensor count_slot) {
     TORCH_CHECK(g_abi.bound, "mi355gs torch binding: bind() has not been called");
+    HostClock clock(&g_host_us[0]);
     (void)means2D;
     auto opt = [&](const OptTensor& t, const char* name, const Tensor& like) {
       return (t.has_value() && t->defined() && t->numel()) ? f32c(*t, name, like) : Tensor();
@@ -550,7 +566,10 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     } else {   // blocking count read-back with a speculative stage 2: see RenderPosedFn::forward
       const int64_t guess = count_hint > 0 ? count_hint + count_hint / 2 + 16384 : -1;
       if (guess > 0) stage2(guess);
-      wait_for_count(count, dev, means3D);
+      {
+        HostClock wait_clock(&g_host_us[5]);
+        wait_for_count(count, dev, means3D);
+      }
       R = *reinterpret_cast<volatile int32_t*>(count);
       if (guess > 0 && R <= guess) {
         R = guess;
@@ -592,6 +611,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     const int scratch_is_clear = (scratch.defined() && ctx->saved_data["scratch_is_clear"].toBool()) ? 1 : 0;
     ctx->saved_data["scratch_is_clear"] = false;
     if (!scratch.defined()) scratch = empty_bytes(g_abi.grad_scratch_bytes(P), means3D);
+    check_frame_buffers(binning, scratch, R, P, W, H);
     check(g_abi.raster_backward(dev.stream, P, D, M, W, H, fp(bg), fp(means3D), fp(sh), fp(sh_rest), fp(colors), fp(opac), fp(scales), (float)sc[2],
                                 fp(rot), fp(cov), fp(view), fp(proj), fp(campos), (float)sc[0], (float)sc[1], geom.data_ptr(), tiles.data_ptr(),
                                 binning.data_ptr(), R, radii.data_ptr<int32_t>(), fp(color), fp(g), scratch.data_ptr(), fp(d_means3D), fp(d_means2D),

@@ -233,6 +233,16 @@ def size_and_render(L, stream, dev, P, W, H, num_rendered, bg, geom, tiles, colo
     return R, binning
 
 
+def check_frame_buffers(L, binning, R, W, H):
+    """The deterministic-backward mode is process-wide and enters the layout of `binning`: a frame must see the same mode in its
+    backward as in its forward.  Switched on in between (a retained graph, a frame in flight, another thread) the backward would
+    write per-instance rows past the end of a buffer laid out without them — refused here, on the host, from the sizes."""
+    need = int(L.mi355gs_raster_binning_bytes(int(R), W, H))
+    if R > 0 and binning.numel() < need:
+        raise RuntimeError(f"mi355gs: this frame's binning buffer ({binning.numel()} bytes) is smaller than the backward's layout needs ({need}): "
+                           "the deterministic-backward mode was switched on between the frame's forward and its backward")
+
+
 def _empty_bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
 
@@ -420,6 +430,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dL_dcov = new(P, 6) if cov_ is not None else None
         scratch = _empty_bytes(grad_scratch_bytes(L, P), dev)
         stream = _lib.stream_ptr(dev)
+        check_frame_buffers(L, binning, int(ctx.num_rendered), W, H)
 
         def run():
             _lib.check(L.mi355gs_raster_backward(

@@ -120,6 +120,7 @@ class _RenderPosed(torch.autograd.Function):
         d_pose = torch.empty(7, dtype=torch.float32, device=dev)
         scratch = dgr._empty_bytes(dgr.grad_scratch_bytes(L, P), dev)
         pose_scratch = torch.empty(16 * ((P + 255) // 256) + 32, dtype=torch.float32, device=dev)
+        dgr.check_frame_buffers(L, binning, int(ctx.capacity), W, H)
         with _lib.on_device(dev):
             _lib.check(L.mi355gs_posed_backward(
                 _lib.stream_ptr(dev), P, D, W, H, _lib.ptr(bg), _lib.ptr(xyz), _lib.ptr(f_dc), _lib.ptr(f_rest), _lib.ptr(opl),

@@ -27,6 +27,8 @@ switches the whole mechanism off: `l1_loss` and `fused_ssim` are then two indepe
 from __future__ import annotations
 
 import os
+import time
+import warnings
 
 import numpy as np
 import torch
@@ -364,9 +366,18 @@ class LazyScalar(torch.Tensor):
         if slot is not None:
             ext = _lib.compiled()
             if ext is not None:
+                t0 = time.perf_counter()
                 v = ext.wait_for_loss(slot[0], slot[1], 200_000)
                 if v is not None:
                     return v
+                if time.perf_counter() - t0 > 0.1:
+                    # the slot never showed the value although the kernel ran (the ordinary read below returns it): host memory the
+                    # device's stores do not reach coherently on this system.  Every later item() would spin for the whole timeout
+                    # before falling back — switch the early read off for the process and say so once.
+                    global EARLY_ITEM
+                    EARLY_ITEM = False
+                    warnings.warn("instantsplat_amd.lazy_loss: the pinned loss slot did not receive the value within 200 ms; "
+                                  "loss.item() falls back to an ordinary read for the rest of the process (MI355GS_EARLY_ITEM=0)")
         return real.item()
 
     def __float__(self):

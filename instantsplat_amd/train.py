@@ -8,6 +8,7 @@ optimizer.step() unless it is the last iteration -> zero_grad(set_to_none=True).
 from __future__ import annotations
 
 import ctypes
+import gc
 import math
 import random
 import time
@@ -752,6 +753,16 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
         save_pose(os.path.join(model_path, "pose", f"ours_{it}", "pose_org.npy"), st.gaussians.P, colmap_ids)
     psnr0 = evaluate_psnr(st)
     is_cuda = torch.device(device).type == "cuda"
+    # Host housekeeping before the loop: one FULL collection of Python's cyclic collector now, and everything that survives it
+    # parked in the permanent generation for the duration of the loop.  A process that has imported torch tracks ~2 x 10^5
+    # container objects and a full (generation-2) pass over them takes 70-90 ms — a quarter of a 1000-iteration run of this
+    # scene (0.28 ms per iteration) whenever one happens to fall inside it, which is what made `iters_per_sec_1k` read 2650-2830
+    # on some runs and 3500-3650 on others (profiles/r06_onek_probe_*.txt: a single stall of 87 ms at a varying iteration,
+    # no allocator activity).  With the old objects frozen, the collections that do run inside the loop only walk what the loop
+    # itself allocated.  Undone on the way out (the caller's process gets its collector back as it was).
+    gc_was_enabled = gc.isenabled()
+    gc.collect()
+    gc.freeze()
     if is_cuda:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -802,6 +813,13 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
     if is_cuda:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.unfreeze()
+    if gc_was_enabled:
+        gc.enable()
+    # the loss pair of the last iteration (train.py:171-176 as written) holds that frame's image, its render graph and four
+    # image-sized buffers until the next l1_loss call: none will come from this loop
+    from . import lazy_loss
+    lazy_loss.forget()
     if model_path:   # reference train.py:229-231
         save_time(model_path, "[2] train_joint", dt)
     n_done = max(iterations - int(first_iter), 1)

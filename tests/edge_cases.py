@@ -494,3 +494,37 @@ def check_speculative_stage2_overflow_is_rerendered(dev):
             assert float((a[2] - b[2]).norm() / (a[2].norm() + 1e-30)) <= (1e-5 if cuda else 0.0)
     finally:
         BinningPolicy.reset("exact")
+
+
+def check_deterministic_toggle_between_forward_and_backward_is_refused(dev):
+    """the deterministic-backward mode is a process-wide switch that enters the layout of a frame's `binning` buffer
+    (+ 52 B per instance of rows and row indices).  Switched ON between a frame's forward and its backward, the backward would
+    write those rows past the end of a buffer laid out without them: both bindings refuse from the buffer sizes, on the host,
+    before anything is enqueued.  Switched OFF in between is harmless (the buffer is the larger one) and must keep working."""
+    import pytest
+    import torch
+    from instantsplat_amd import _lib
+    from instantsplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, set_deterministic
+    from instantsplat_amd.synthetic import syn_blob
+    from tests.util import settings_for
+    sc = syn_blob(400, 64, 48, seed=5, scale_mean=0.08)
+    was_binding = _lib.BINDING
+    try:
+        for binding in ("compiled", "ctypes") if _lib.compiled() is not None else ("ctypes",):
+            _lib.BINDING = binding
+            for first, second, refused in ((False, True, True), (True, False, False), (True, True, False)):
+                set_deterministic(first)
+                leaves = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.scaling_logit, sc.rotation, sc.opacity_logit, sc.shs)]
+                st = settings_for(sc.camera, 1, GaussianRasterizationSettings, sc.bg, device=dev)
+                color, _ = GaussianRasterizer(st)(means3D=leaves[0], means2D=torch.zeros(400, 3, device=dev, requires_grad=True),
+                                                  opacities=torch.sigmoid(leaves[3]), shs=leaves[4], scales=torch.exp(leaves[1]), rotations=leaves[2])
+                set_deterministic(second)
+                if refused:
+                    with pytest.raises(RuntimeError, match="deterministic-backward mode was switched on"):
+                        color.sum().backward()
+                else:
+                    color.sum().backward()
+                    assert all(t.grad is not None and bool(torch.isfinite(t.grad).all()) for t in leaves)
+    finally:
+        set_deterministic(False)
+        _lib.BINDING = was_binding

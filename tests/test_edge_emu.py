@@ -249,3 +249,7 @@ def test_tile_lists_sorted_as_two_runs(emu, n):
     assert any((512 < x <= 768) if n < 1200 else (1024 < x <= 1536) for x in lengths), lengths
     if n == 1900:
         assert any(1024 < x <= 1280 for x in lengths) and any(1280 < x <= 1536 for x in lengths), lengths
+
+
+def test_deterministic_toggle_between_forward_and_backward_is_refused(emu):
+    edge_cases.check_deterministic_toggle_between_forward_and_backward_is_refused(emu)

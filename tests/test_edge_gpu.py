@@ -77,3 +77,7 @@ def test_count_slots_survive_unpolled_forwards(gpu, binding):
 
 def test_speculative_stage2_overflow_is_rerendered(gpu):
     edge_cases.check_speculative_stage2_overflow_is_rerendered(gpu)
+
+
+def test_deterministic_toggle_between_forward_and_backward_is_refused(gpu):
+    edge_cases.check_deterministic_toggle_between_forward_and_backward_is_refused(gpu)

@@ -74,7 +74,7 @@ def test_bench_line_with_the_drivers_exact_argv_under_the_launcher(gpu):
     cb = out["cpu_baseline"]
     assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and out["value"] > 5 * cb["value"]
     c = out["configs"]
-    assert c["C2"]["ms_per_frame"] > 0 and c["C2"]["max_abs_diff_vs_oracle"] < 5e-3
+    assert 0 < c["C2"]["ms_per_frame"] < 0.5 and c["C2"]["ms_per_frame_after_the_training_loops"] > 0 and c["C2"]["max_abs_diff_vs_oracle"] < 5e-3
     assert c["C4"]["ms_per_view"] > 0 and 0.02 < c["C4"]["bwd_frac"] < 1.0 and c["C4"]["gaussians"] == 995328
     m = out["multi_gpu"]   # a launcher started the rank: the process group is RCCL's and the per-rank table is filled
     assert out["collective_backend"] == "nccl" and m["world_size"] == 1 and 0.02 < m["per_rank"][0]["composite_bwd_frac_hbm"] < 1.0

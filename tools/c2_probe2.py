@@ -25,7 +25,7 @@ def c2(tag, n=300):
             r(**a)
         torch.cuda.synchronize()
         if ext is not None:
-            ext.host_us(True)
+            ext.host_times_us(True)
         ts = []
         t0 = time.perf_counter()
         for _ in range(n):
@@ -35,7 +35,7 @@ def c2(tag, n=300):
         torch.cuda.synchronize()
         tot = time.perf_counter() - t0
         ts.sort()
-        clocks = [round(x / n, 1) for x in ext.host_us(True)] if ext is not None else None
+        clocks = [round(x / n, 1) for x in ext.host_times_us(True)] if ext is not None else None
         print(f"{tag}: {1e3 * tot / n:.4f} ms/frame; per call us: min {1e6 * ts[0]:.0f} median {1e6 * ts[n // 2]:.0f} p90 {1e6 * ts[int(.9 * n)]:.0f} "
               f"p99 {1e6 * ts[int(.99 * n)]:.0f} max {1e6 * ts[-1]:.0f}; calls over 1 ms: {sum(t > 1e-3 for t in ts)}; host clocks us/frame {clocks}", flush=True)
 
@@ -69,3 +69,10 @@ for _ in range(30):
 os.environ["X"] = "1"
 _lib.BINDING = "ctypes"
 c2("after 30 more drop-in iterations, C2 through the ctypes binding")
+_lib.BINDING = "compiled"
+from instantsplat_amd.launch import pin_rank_to_cpu_slice
+pin_rank_to_cpu_slice(0, 1, device_of_rank=lambda r: 0)
+c2("compiled binding again, after pinning to the GPU's NUMA node")
+for _ in range(30):
+    train_iteration(st, fused_loss=False)
+c2("pinned, after 30 more drop-in iterations")

@@ -27,6 +27,24 @@ for name, kw in (("reference loop (train.py loss as written)", dict(fused_loss=F
                 torch.cuda.synchronize()
                 marks.append((i + 1, time.perf_counter() - t0))
         release_trainer(st)
+        if rep == 0:   # a second, finer look at the first 60 iterations: every iteration on its own clock, with the caching allocator's counters
+            st2 = setup_training(scene, dev, opt=OptimizationParams(iterations=1000, pp_optimizer=True, optim_pose=True))
+            torch.cuda.synchronize()
+            slow = []
+            for i in range(60):
+                ms0 = torch.cuda.memory_stats(dev)
+                t = time.perf_counter()
+                train_iteration(st2, **kw)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t
+                ms1 = torch.cuda.memory_stats(dev)
+                if dt > 1e-3:
+                    slow.append(f"it {i + 1}: {dt * 1e3:.2f} ms, cudaMalloc calls +{ms1['num_device_alloc'] - ms0['num_device_alloc']}, "
+                                f"reserved {ms0['reserved_bytes.all.current'] >> 20} -> {ms1['reserved_bytes.all.current'] >> 20} MiB, "
+                                f"frees +{ms1['num_device_free'] - ms0['num_device_free']}")
+            release_trainer(st2)
+            print(f"{name}: iterations of the first 60 over 1 ms: " + ("; ".join(slow) or "none"), flush=True)
+            del st2
         total = marks[-1][1]
         prev_i, prev_t, out = 0, 0.0, []
         for i, t in marks:

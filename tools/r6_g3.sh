@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 600 python tools/c2_probe2.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_c2_probe2.txt
+timeout 600 python tools/onek_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_onek_probe.txt
+bash tools/marker_trace.sh r06_one_call python tools/loop_kernels.py one_call 100
+timeout 600 python -m pytest tests/test_ops_gpu.py -q -x -k "run_ahead" 2>&1 | tail -3
