@@ -71,7 +71,7 @@ def compact_line(full, full_path):
     issue tables, counter readings of the small kernels, prose) stays in the full record at `full_record`."""
     rf = full["roofline"]
     pick = lambda d, keys: {k: d[k] for k in keys if d is not None and k in d}
-    roof = pick(rf, ("kernel", "bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_issue", "traffic", "avg_kernel_ms", "launches",
+    roof = pick(rf, ("kernel", "bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_issue", "traffic", "traffic_from", "avg_kernel_ms", "launches",
                      "algorithmic_bytes_per_launch", "R_eff", "R"))
     roof["useful_lane_frac"] = (rf.get("compute") or {}).get("useful_lane_frac")
     roof["valu_wave_insts_pmc"] = (rf.get("pmc_sq") or {}).get("wave_insts_per_launch")
@@ -754,7 +754,7 @@ def main():
     traffic, traffic_src, fwd_traffic = None, None, None
     try:  # HBM-side bytes per launch: rocprofv3 --pmc passes of this command, collected separately (counters cannot run inside a
         # timed bench) and committed under profiles/; the newest round present is used and named
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 fr, wr = pmc_rows(f"{rnd}_pmc_c3_FETCH_SIZE.csv"), pmc_rows(f"{rnd}_pmc_c3_WRITE_SIZE.csv")
                 f_, w_ = fr["k_composite_bwd"], wr["k_composite_bwd"]
@@ -770,18 +770,20 @@ def main():
         traffic = None
 
     ro_traffic, ro_traffic_src = None, None
-    try:   # the render-only instantiation has its own PMC pass (tools/pmc.sh over tools/render_only_loop.py)
-        fr, wr = pmc_rows("r05_pmc_render_only_FETCH_SIZE.csv", True), pmc_rows("r05_pmc_render_only_WRITE_SIZE.csv", True)
-        f_, w_ = fr["k_composite_fwd"], wr["k_composite_fwd"]
-        ro_traffic = {"bytes": (2.0 * float(f_["mean_FETCH_SIZE"]) + float(w_["mean_WRITE_SIZE"])) * 1024.0,
-                      "write_bytes": float(w_["mean_WRITE_SIZE"]) * 1024.0}
-        ro_traffic_src = "profiles/r05_pmc_render_only_FETCH_SIZE.csv + r05_pmc_render_only_WRITE_SIZE.csv"
-    except Exception:
-        ro_traffic = None
+    for rnd in ("r06", "r05"):   # the render-only instantiation has its own PMC pass (tools/pmc.sh over tools/render_only_loop.py)
+        try:
+            fr, wr = pmc_rows(f"{rnd}_pmc_render_only_FETCH_SIZE.csv", True), pmc_rows(f"{rnd}_pmc_render_only_WRITE_SIZE.csv", True)
+            f_, w_ = fr["k_composite_fwd"], wr["k_composite_fwd"]
+            ro_traffic = {"bytes": (2.0 * float(f_["mean_FETCH_SIZE"]) + float(w_["mean_WRITE_SIZE"])) * 1024.0,
+                          "write_bytes": float(w_["mean_WRITE_SIZE"]) * 1024.0}
+            ro_traffic_src = f"profiles/{rnd}_pmc_render_only_FETCH_SIZE.csv + {rnd}_pmc_render_only_WRITE_SIZE.csv"
+            break
+        except Exception:
+            ro_traffic = None
 
     pmc_sq = None
     try:  # SQ counter pass of the same command (separate run)
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 row = pmc_rows(f"{rnd}_pmc_c3_SQ_counters.csv")["k_composite_bwd"]
             except (OSError, KeyError):
@@ -811,21 +813,21 @@ def main():
          "for count + scatter together)"))
     small = {}
     sq_tab, sq_src, fr5, wr5 = {}, None, {}, {}
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         try:
             sq_tab = pmc_rows(f"{rnd}_pmc_c3_SQ_wait_counters.csv")
             sq_src = f"profiles/{rnd}_pmc_c3_SQ_wait_counters.csv"
             break
         except OSError:
             continue
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         try:
             fr5, wr5 = pmc_rows(f"{rnd}_pmc_c3_FETCH_SIZE.csv"), pmc_rows(f"{rnd}_pmc_c3_WRITE_SIZE.csv")
             break
         except OSError:
             continue
     rocprof_us, rocprof_src = {}, None
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         try:   # rocprofv3 --kernel-trace --stats summary of this command (tools/prof.sh): the average duration the event times must agree with
             import csv
             with open(os.path.join(ROOT, "profiles", f"{rnd}_bench_c3_kernel_stats.csv")) as fh:
@@ -1050,7 +1052,9 @@ def main():
             "iters_per_sec_1k": long_runs, "fps_reference_method": fps,
             "roofline": {"kernel": "k_composite_bwd", "bound": "hbm", "limited_by": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_hbm": achieved / HBM_PEAK_GBS, "frac_issue": (compute or {}).get("issue_frac_at_2.4GHz"),
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": bwd_ms,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_from": (traffic_src.split(" ")[0] + " (a separate rocprofv3 --pmc pass, committed; not this run)") if traffic_src else None,
+                         "avg_kernel_ms": bwd_ms,
                          "launches": bwd_n, "timed_every": 1, "timed_where": f"untimed pass, iterations {PIN_ITER + 6} .. {PIN_ITER + 5 + n_prof} of the one-call step",
                          "algorithmic_bytes_per_launch": bwd_bytes, "R_eff": R_eff, "R": sum(Rs) / len(Rs),
                          "reference_binning": {

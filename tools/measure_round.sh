@@ -5,13 +5,12 @@
 R=${1:-rXX}
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${R}_gputest_full_v3.txt; tail -8 gpurun_out/${R}_gputest_full_v3.txt
-timeout 600 python bench.py > gpurun_out/${R}_bench_default_run_v3.json 2> gpurun_out/bench_default.err; tail -c 400 gpurun_out/bench_default.err
-bash tools/prof.sh ${R}_bench_c3 python bench.py --steps 200 --warmup 20 --cpu-iters 0 --no-long-run > /dev/null 2>&1
+timeout 600 python bench.py > gpurun_out/${R}_bench_default_run_v3.json 2> gpurun_out/bench_default.err; tail -c 400 gpurun_out/bench_default.err; cp gpurun_out/bench_full_n1.json gpurun_out/${R}_bench_default_full_record.json
+bash tools/prof.sh ${R}_bench_c3 python bench.py --steps 200 --warmup 20 --cpu-iters 0 --no-long-run --no-other-configs > /dev/null 2>&1
 A=SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES
 B=SQ_WAVE_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_INSTS_VALU,SQ_BUSY_CYCLES,SQ_WAVES
 for c in FETCH_SIZE WRITE_SIZE $A $B; do
-  bash tools/pmc.sh c3 $c python bench.py --steps 20 --warmup 5 --cpu-iters 0 --no-long-run > /dev/null 2>&1
+  bash tools/pmc.sh c3 $c python bench.py --steps 20 --warmup 5 --cpu-iters 0 --no-long-run --no-other-configs > /dev/null 2>&1
 done
 cp gpurun_out/pmc_c3_FETCH_SIZE.csv gpurun_out/${R}_pmc_c3_FETCH_SIZE.csv; cp gpurun_out/pmc_c3_WRITE_SIZE.csv gpurun_out/${R}_pmc_c3_WRITE_SIZE.csv
 cp gpurun_out/pmc_c3_${A//,/_}.csv gpurun_out/${R}_pmc_c3_SQ_counters.csv; cp gpurun_out/pmc_c3_${B//,/_}.csv gpurun_out/${R}_pmc_c3_SQ_wait_counters.csv
@@ -22,13 +21,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
   bash tools/pmc.sh render_only $c python tools/render_only_loop.py 10 > /dev/null 2>&1
   cp gpurun_out/pmc_render_only_$c.csv gpurun_out/${R}_pmc_render_only_$c.csv; grep -E "kernel,|composite_fwd" gpurun_out/${R}_pmc_render_only_$c.csv
 done
+bash tools/prof.sh ${R}_c4_1M_1080p python tools/c4_probe.py > /dev/null 2>&1
+timeout 300 python tools/c4_probe.py 2>&1 | grep "^C4" > gpurun_out/${R}_c4_probe.txt; cat gpurun_out/${R}_c4_probe.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  GS_C4_DET=0 bash tools/pmc.sh c4 $c python tools/c4_probe.py > /dev/null 2>&1
+  cp gpurun_out/pmc_c4_$c.csv gpurun_out/${R}_pmc_c4_$c.csv
+done
+python tools/kernel_roofline_table.py gpurun_out/${R}_bench_c3_kernel_stats.csv gpurun_out/${R}_pmc_c3 > gpurun_out/${R}_kernel_traffic_table.txt 2>&1; head -20 gpurun_out/${R}_kernel_traffic_table.txt
+python tools/kernel_roofline_table.py gpurun_out/${R}_c4_1M_1080p_kernel_stats.csv gpurun_out/${R}_pmc_c4 > gpurun_out/${R}_kernel_traffic_table_c4.txt 2>&1
 timeout 300 python tools/det_cost.py 2>/dev/null | grep "^{" > gpurun_out/${R}_deterministic_mode_cost.txt; cat gpurun_out/${R}_deterministic_mode_cost.txt
 bash tools/prof.sh ${R}_det_c3 python tools/det_cost.py 100 > /dev/null 2>&1
 R=$R python - <<'PY'
 import json, os
 d = json.load(open("gpurun_out/%s_bench_default_run_v3.json" % os.environ["R"]))
 r = d["roofline"]
-print("value %.0f | loops %s" % (d["value"], {k: round(v["iters_per_sec"]) for k, v in d["loops"].items()}))
+print("value %.0f | loops %s" % (d["value"], {k: round(v) for k, v in d["loops"].items()}))
 print({k: (round(v["avg_kernel_ms"] * 1e3, 1), round(v["frac"], 3)) for k, v in r["small_kernels"].items()})
 PY
 ls gpurun_out | grep ${R}_
