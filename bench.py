@@ -48,6 +48,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's and torch's cross-process handles fail with
+# `hipIpcGetMemHandle: invalid argument` under the legacy mode); the boxes export it already — this only covers a shell that lost it.
+# Set before anything initialises the HSA runtime (torch is imported inside main()).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 

@@ -16,8 +16,12 @@ import json
 import os
 import socket
 
-import torch
-import torch.distributed as dist
+# (multi-process GPU work on this pool needs dmabuf IPC; the boxes export it — this only covers a shell that lost it, and must
+# precede whatever initialises the HSA runtime)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def _physical_core_of(cpu: int):
