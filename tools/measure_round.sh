@@ -28,7 +28,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp gpurun_out/pmc_c4_$c.csv gpurun_out/${R}_pmc_c4_$c.csv
 done
 python tools/kernel_roofline_table.py gpurun_out/${R}_bench_c3_kernel_stats.csv gpurun_out/${R}_pmc_c3 > gpurun_out/${R}_kernel_traffic_table.txt 2>&1; head -20 gpurun_out/${R}_kernel_traffic_table.txt
-python tools/kernel_roofline_table.py gpurun_out/${R}_c4_1M_1080p_kernel_stats.csv gpurun_out/${R}_pmc_c4 > gpurun_out/${R}_kernel_traffic_table_c4.txt 2>&1
+python tools/kernel_roofline_table.py gpurun_out/${R}_c4_1M_1080p_kernel_stats.csv gpurun_out/${R}_pmc_c4 10 > gpurun_out/${R}_kernel_traffic_table_c4.txt 2>&1
 timeout 300 python tools/det_cost.py 2>/dev/null | grep "^{" > gpurun_out/${R}_deterministic_mode_cost.txt; cat gpurun_out/${R}_deterministic_mode_cost.txt
 bash tools/prof.sh ${R}_det_c3 python tools/det_cost.py 100 > /dev/null 2>&1
 R=$R python - <<'PY'
