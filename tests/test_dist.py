@@ -259,3 +259,28 @@ def test_compact_cpus_is_one_cache_domain_one_thread_per_core():
     assert compact_cpus([2, 3, 10, 11], core_of, l3_of, min_cores=2) == [2, 3]
     assert compact_cpus([0, 1, 2], core_of, lambda c: None) == [0, 1, 2]
     assert compact_cpus([0, 8], core_of, l3_of) == [0, 8]                                            # nothing qualifies: unchanged
+
+
+def test_compact_line_never_exceeds_the_limit_and_says_what_it_shed(tmp_path):
+    """The last-resort trimmer of bench.compact_line: a record whose optional blocks would push the line past 8 KB (sixty-four
+    per-rank rows, a bloated small-kernel block) still yields ONE parsable line under the limit that keeps every contract key,
+    `roofline.frac` and `cpu_baseline`, and flags `line_trimmed`; NaN / inf become null (JSON has neither)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT_, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT_, "profiles", "r06_bench_default_full_record.json")) as fh:
+        full = json.load(fh)
+    line = bench.compact_line(full, "gpurun_out/x.json")
+    assert len(line) < 4096 and "line_trimmed" not in json.loads(line)
+    rank = {"rank": 0, "host": "h" * 40, "gpu": {"device": "cuda:0"}, "cpus": 16, "first_cpu": 0, "iters_per_sec_median_block_own_clock": 3512.123456,
+            "psnr_after": 50.123456, "composite_bwd_avg_ms": 0.1071234, "composite_fwd_avg_ms": 0.0741234, "composite_bwd_frac_hbm": 0.1051234,
+            "composite_fwd_frac_hbm": 0.0591234, "R_eff": 756123.4, "box": {"device_copy_TB_per_s": 5.41234}}
+    full["multi_gpu"] = {"per_rank": [dict(rank, rank=i) for i in range(64)], "ranks_seen": 64, "world_size": 64, "backend": "nccl", "rccl_version": "2.26.6",
+                         "collective_selftest": {"checked": ["barrier"]}, "solo_rank0_iters_per_sec": 3500.0, "scaling_efficiency_vs_solo_rank0": float("nan")}
+    full["roofline"]["small_kernels"] = {"k_%d" % i: {"avg_kernel_ms": 0.01, "frac": 0.05, "traffic": 1.0e6} for i in range(40)}
+    line = bench.compact_line(full, "gpurun_out/x.json")
+    out = json.loads(line)
+    assert len(line) < bench.LINE_LIMIT == 8192 and out["line_trimmed"] is True
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0 and out["value"] > 0 and out["config"]["workload"]
+    assert out["multi_gpu"]["scaling_efficiency_vs_solo_rank0"] is None and "NaN" not in line
