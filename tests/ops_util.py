@@ -122,11 +122,35 @@ def check_adam_golden(dev):
         assert torch.allclose(p2.detach().cpu(), T(f"adam_p2_{t + 1}"), rtol=2e-6, atol=1e-7), t
 
 
+def oracle_frame_grads(params, cam, gt, dtype):
+    """Gradients of the training loss of ONE frame from the CPU oracle in `dtype` (float32: what oracle/train_ref.CpuTrainer
+    computes; float64: the yardstick), from the raw parameters `params` (name -> tensor) through the reference's glue —
+    pose -> camera-frame means and rotations, activations, rasterizer, 0.8 L1 + 0.2 (1 - SSIM)."""
+    import math
+    from oracle import gs_ref
+    from oracle.raster_torch import RasterSettings
+    from oracle.ssim_ref import l1_loss, ssim
+    from oracle.train_ref import _pose_to_w2c, _quadmul
+    p = {k: v.detach().cpu().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+    pose = p["pose"][cam.uid]
+    R, t = _pose_to_w2c(pose)
+    means = p["xyz"] @ R.t() + t
+    rots = _quadmul(pose[:4], p["rotation"])
+    st = RasterSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, dtype=dtype), 1.0,
+                        torch.eye(4, dtype=dtype), cam.projection_matrix.cpu().to(dtype), 0, torch.zeros(3, dtype=dtype), False, False)
+    img, _ = gs_ref.rasterize(means, torch.zeros_like(means, requires_grad=True), torch.sigmoid(p["opacity"]), st,
+                              shs=torch.cat([p["f_dc"], p["f_rest"]], dim=1), scales=torch.exp(p["scaling"]), rotations=rots)
+    g = gt.detach().cpu().to(dtype)
+    (0.8 * l1_loss(img, g) + 0.2 * (1.0 - ssim(img.unsqueeze(0), g.unsqueeze(0)))).backward()
+    return {k: v.grad for k, v in p.items()}
+
+
 def check_train_matches_cpu_oracle(dev, iters, Wm=16, W=32, fused_step=False):
     """Full train iterations on the device path vs the all-CPU oracle trainer from identical state
     (fused_step: the iterations of part (2) run on the one-call library step instead of the op-by-op path).
 
-    (1) gradients of one iteration agree per tensor (rel-L2 <= 1e-4).  `rotation` is compared with an
+    (1) gradients of one iteration agree per tensor (rel-L2 <= 1e-4 against the fp32 oracle; a tensor outside that is judged
+        against the float64 oracle: at most 2.5 x the fp32 oracle's own error).  `rotation` is compared with an
         absolute bound instead: at initialisation every Gaussian is isotropic (3 equal scales, reference
         scene/gaussian_model.py:160), so d(loss)/d(rotation) is mathematically zero and both sides hold
         only rounding noise — which Adam then turns into +-lr steps, in the reference as well.
@@ -157,12 +181,22 @@ def check_train_matches_cpu_oracle(dev, iters, Wm=16, W=32, fused_step=False):
     assert abs(float(loss) - float(loss_c)) <= 1e-6
     assert float((img.detach().cpu() - img_c.detach()).abs().max()) <= 1e-4
     gscale = max(float(cpu.p[k].grad.abs().max()) for k in ("xyz", "scaling", "opacity"))
+    g64 = None
     for name, t in params.items():
         a, b = t.grad.detach().cpu(), cpu.p[name].grad
         if name == "rotation":
             assert float((a - b).abs().max()) <= 1e-5 * gscale, name
-        elif float(b.norm()) > 0:
-            assert float((a - b).norm() / b.norm()) <= 1e-4, (name, float((a - b).norm() / b.norm()))
+        elif float(b.norm()) > 0 and float((a - b).norm() / b.norm()) > 1e-4:
+            # Outside the small-size criterion against the fp32 oracle: whose error is it?  The same frame through the SAME oracle
+            # in float64 decides (BASELINE.md 3.1's oracle-relative contract): one pixel whose |image - gt| is below rounding flips
+            # the sign of its L1 term in one fp32 implementation and not in the other, which moves every gradient of a 2000-Gaussian
+            # scene by 1e-3 (tools/fuzz_ops.py seed 41, Wm 27 / W 96: the device stood 1.9e-5 from float64, the fp32 ORACLE 1.1e-3;
+            # profiles/r06_diag_train_case_seed41.txt).
+            if g64 is None:
+                g64 = oracle_frame_grads(params, cam, st.gt_images[cam.uid], torch.float64)
+            e_dev = float((a.double() - g64[name]).norm() / g64[name].norm())
+            e_ref = float((b.double() - g64[name]).norm() / g64[name].norm())
+            assert e_dev <= max(1e-4, 2.5 * e_ref), (name, "device vs fp64", e_dev, "fp32 oracle vs fp64", e_ref)
         t.grad = None
         cpu.p[name].grad = None
 
