@@ -760,62 +760,61 @@ def training(scene, device, iterations: int = 1000, log_every: int = 0, run_ahea
     # on some runs and 3500-3650 on others (profiles/r06_onek_probe_*.txt: a single stall of 87 ms at a varying iteration,
     # no allocator activity).  With the old objects frozen, the collections that do run inside the loop only walk what the loop
     # itself allocated.  Undone on the way out (the caller's process gets its collector back as it was).
-    gc_was_enabled = gc.isenabled()
     gc.collect()
     gc.freeze()
-    if is_cuda:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    first = last = None
-    one_call = bool(run_ahead and fused_loss and FusedTrainer.supported(st))
-    ra = RunAhead(st, fused_loss=fused_loss) if run_ahead and not one_call else None
-    ema = 0.0
-    report = {}
-    for i in range(int(first_iter), iterations):
-        if one_call:
-            last = train_iteration(st, fused_step=True)
-            first = last if first is None else first
-            ema = 0.4 * last + 0.6 * ema   # reference train.py:188
-            if log_every and (i + 1) % log_every == 0:
-                print(f"[iter {i + 1}] ema loss {ema:.6f}")
-        elif ra is not None:
-            ema = ra.step()
-            if first is None and ema is not None:
-                first = st.last_loss
-            if log_every and ema is not None and (i + 1) % log_every == 0:
-                print(f"[iter {i + 1}] ema loss {ema:.6f}")
-        else:
-            last = train_iteration(st, fused_loss=fused_loss)
-            first = last if first is None else first
-            if log_every and (i + 1) % log_every == 0:
-                print(f"[iter {i + 1}] loss {last:.6f}")
-        it = i + 1
-        if it == iterations and model_path:   # reference train.py:213-217: the time of the loop itself, before the last save
-            save_time(model_path, "[2] train_joint_TrainTime", time.perf_counter() - t0)
-        if it == iterations and (it in set(int(i) for i in testing_iterations) or it % 5000 == 0):   # train.py:218 (training_report)
-            cancel_prepared(st)
-            if ra is not None:
-                ra.flush()
-            report = training_report(st, it, testing_iterations, quiet=not log_every)
-        if it in saving or it in checkpoints:
-            cancel_prepared(st)
-            if ra is not None:
-                ra.flush()   # the window up to here is verified (and replayed if a frame overflowed) before anything is written
-            if it in saving:
-                _save_outputs(st, it, model_path, colmap_ids)
-            if it in checkpoints:
-                torch.save((st.gaussians.capture(), it), os.path.join(model_path, f"chkpnt{it}.pth"))
-    release_trainer(st)
-    if ra is not None:
-        ra.flush()
-        last = st.last_loss
-        BinningPolicy.reset("exact")
-    if is_cuda:
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gc.unfreeze()
-    if gc_was_enabled:
-        gc.enable()
+    try:   # (whatever happens in the loop, the caller gets its collector back)
+        if is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first = last = None
+        one_call = bool(run_ahead and fused_loss and FusedTrainer.supported(st))
+        ra = RunAhead(st, fused_loss=fused_loss) if run_ahead and not one_call else None
+        ema = 0.0
+        report = {}
+        for i in range(int(first_iter), iterations):
+            if one_call:
+                last = train_iteration(st, fused_step=True)
+                first = last if first is None else first
+                ema = 0.4 * last + 0.6 * ema   # reference train.py:188
+                if log_every and (i + 1) % log_every == 0:
+                    print(f"[iter {i + 1}] ema loss {ema:.6f}")
+            elif ra is not None:
+                ema = ra.step()
+                if first is None and ema is not None:
+                    first = st.last_loss
+                if log_every and ema is not None and (i + 1) % log_every == 0:
+                    print(f"[iter {i + 1}] ema loss {ema:.6f}")
+            else:
+                last = train_iteration(st, fused_loss=fused_loss)
+                first = last if first is None else first
+                if log_every and (i + 1) % log_every == 0:
+                    print(f"[iter {i + 1}] loss {last:.6f}")
+            it = i + 1
+            if it == iterations and model_path:   # reference train.py:213-217: the time of the loop itself, before the last save
+                save_time(model_path, "[2] train_joint_TrainTime", time.perf_counter() - t0)
+            if it == iterations and (it in set(int(i) for i in testing_iterations) or it % 5000 == 0):   # train.py:218 (training_report)
+                cancel_prepared(st)
+                if ra is not None:
+                    ra.flush()
+                report = training_report(st, it, testing_iterations, quiet=not log_every)
+            if it in saving or it in checkpoints:
+                cancel_prepared(st)
+                if ra is not None:
+                    ra.flush()   # the window up to here is verified (and replayed if a frame overflowed) before anything is written
+                if it in saving:
+                    _save_outputs(st, it, model_path, colmap_ids)
+                if it in checkpoints:
+                    torch.save((st.gaussians.capture(), it), os.path.join(model_path, f"chkpnt{it}.pth"))
+        release_trainer(st)
+        if ra is not None:
+            ra.flush()
+            last = st.last_loss
+            BinningPolicy.reset("exact")
+        if is_cuda:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.unfreeze()
     # the loss pair of the last iteration (train.py:171-176 as written) holds that frame's image, its render graph and four
     # image-sized buffers until the next l1_loss call: none will come from this loop
     from . import lazy_loss
