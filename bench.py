@@ -961,6 +961,31 @@ def main():
                 img_cpu = c2f()[0]
             cpu_baseline["c2_forward_ms_per_frame"] = 1e3 * (time.perf_counter() - tc) / 5
             configs_out["C2"]["max_abs_diff_vs_oracle"] = float((c2_img - img_cpu).abs().max())
+            # BASELINE configs[0] (C1': the plumbing run — 3 views, a 128 x 128 pointmap per view = 49,152 Gaussians, 256 x 256 images;
+            # MASt3R init is impossible offline): 50 train iterations on the CPU path and the same 50 on the device from
+            # the same start, loss by loss.  (C1 on the reference's own frames: tools/configs.py, tests/test_sora_gpu.py.)
+            st1 = setup_training(syn_pointmap(3, 128, 128, 256, 256, seed=0), dev)
+            g1 = st1.gaussians
+            g1.update_learning_rate(1)
+            lrs1 = {grp["name"]: grp["lr"] for grp in g1.optimizer.param_groups}
+            cpu1 = CpuTrainer(dict(xyz=g1._xyz, f_dc=g1._features_dc, f_rest=g1._features_rest, opacity=g1._opacity, scaling=g1._scaling,
+                                   rotation=g1._rotation, pose=g1.P), st1.cameras, st1.gt_images, g1.per_point_lr, lrs1)
+            t_dev1 = t_cpu1 = worst1 = 0.0
+            for _ in range(50):
+                dev_sync()
+                tc = time.perf_counter()
+                l_dev1 = train_iteration(st1)
+                dev_sync()
+                t_dev1 += time.perf_counter() - tc
+                for grp, dgrp in zip(cpu1.opt.param_groups, g1.optimizer.param_groups):
+                    grp["lr"] = dgrp["lr"]
+                tc = time.perf_counter()
+                l_cpu1 = cpu1.iteration()
+                t_cpu1 += time.perf_counter() - tc
+                worst1 = max(worst1, abs(l_dev1 - l_cpu1) / max(abs(l_cpu1), 1e-2))
+            configs_out["C1"] = {"gaussians": int(g1.get_xyz.shape[0]), "iterations": 50, "cpu_path_iters_per_sec": 50 / t_cpu1,
+                                 "device_iters_per_sec": 50 / t_dev1, "max_rel_loss_diff": worst1}
+            del st1, g1, cpu1
 
     # ---- N > 1: who ran where, and how the ranks compare (the driver gets one shot at the 8-GPU node: make it informative)
     multi = None

@@ -76,6 +76,8 @@ def test_bench_line_with_the_drivers_exact_argv_under_the_launcher(gpu):
     c = out["configs"]
     assert 0 < c["C2"]["ms_per_frame"] < 0.5 and c["C2"]["ms_per_frame_after_the_training_loops"] > 0 and c["C2"]["max_abs_diff_vs_oracle"] < 5e-3
     assert c["C4"]["ms_per_view"] > 0 and 0.02 < c["C4"]["bwd_frac"] < 1.0 and c["C4"]["gaussians"] == 995328
+    # configs[0]: the plumbing run (C1'), 50 iterations on the CPU path and on the device from the same start, loss by loss
+    assert c["C1"]["gaussians"] == 49152 and c["C1"]["max_rel_loss_diff"] < 3e-2 and c["C1"]["device_iters_per_sec"] > 5 * c["C1"]["cpu_path_iters_per_sec"] > 0
     m = out["multi_gpu"]   # a launcher started the rank: the process group is RCCL's and the per-rank table is filled
     assert out["collective_backend"] == "nccl" and m["world_size"] == 1 and 0.02 < m["per_rank"][0]["composite_bwd_frac_hbm"] < 1.0
     assert out["value_without_host_tricks"] > 0 and out["iters_per_sec_1k"]["reference_loop_autograd_both_readbacks"] > 0
